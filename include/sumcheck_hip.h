@@ -1,0 +1,174 @@
+/* sumcheck_hip.h -- C ABI of libsumcheck_hip.so: the MI355X (gfx950) prover hot path of the
+ * linear-time multilinear sumcheck, a drop-in for arkworks-rs/sumcheck's
+ *   IPForMLSumcheck::{prover_init, prove_round}      (reference src/ml_sumcheck/protocol/prover.rs:49,74)
+ *   DenseMultilinearExtension::fix_variables          (ark-poly; called at prover.rs:88)
+ *   MLSumcheck::{prove, prove_as_subprotocol}         (reference src/ml_sumcheck/mod.rs:42,50)
+ *   gkr_round_sumcheck::{initialize_phase_one, initialize_phase_two, GKRRoundSumcheck::prove}
+ *                                                      (reference src/gkr_round_sumcheck/mod.rs:22,57,93)
+ *
+ * The reference has no FFI of its own (it is pure Rust with #![forbid(unsafe_code)], src/lib.rs:1);
+ * these entry points are what a Rust `extern "C"` shim crate binds (INTEGRATION.md shows the stub).
+ *
+ * ELEMENT LAYOUT.  A field element is `uint64_t[4]`: the little-endian limbs of the MONTGOMERY form
+ * (R = 2^256) of a BLS12-381 scalar, always < p -- bit-for-bit the in-memory layout of
+ * ark_ff::Fp<MontBackend<FrConfig,4>,4>, so `evaluations.as_ptr() as *const u64` can be passed
+ * straight in and outputs can be wrapped back into `Fp` without conversion.  A table of 2^nv
+ * evaluations is 2^nv * 32 contiguous bytes, index bit k <-> variable k (ark-poly
+ * DenseMultilinearExtension).
+ *
+ * OWNERSHIP.  sc_prover_init copies its inputs (as prover_init deep-copies, prover.rs:55-59) unless
+ * SC_TABLES_BORROW is set; it never writes caller memory.  A handle owns its device memory until
+ * sc_prover_free.  Outputs go to caller-owned host buffers unless the parameter says "device".
+ *
+ * THREADING.  One handle = one host thread at a time.  Distinct handles are independent.  Calls are
+ * synchronous (return after the result is on the host) unless named *_async / *_partial.
+ *
+ * ERRORS.  Nothing aborts across the ABI.  The four misuse panics of the reference map to status codes
+ * (the shim turns them back into the same panic! messages); sc_last_error() gives detail.
+ * There is NO CPU fallback: without a usable HIP device every compute entry point returns SC_ERR_HIP.
+ */
+#ifndef SUMCHECK_HIP_H
+#define SUMCHECK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_ABI_VERSION 1
+#define SC_API __attribute__((visibility("default")))
+
+enum sc_status {
+    SC_OK = 0,
+    SC_ERR_CONSTANT_POLY = 1,       /* "Attempt to prove a constant."        prover.rs:50-52 */
+    SC_ERR_FIRST_ROUND_HAS_MSG = 2, /* "first round should be prover first." prover.rs:79-81 */
+    SC_ERR_MISSING_MSG = 3,         /* "verifier message is empty"           prover.rs:90-92 */
+    SC_ERR_NOT_ACTIVE = 4,          /* "Prover is not active"                prover.rs:96-98 */
+    SC_ERR_BAD_ARG = 5,             /* assert!/assert_eq! failures of data_structures.rs:78-84 and gkr mod.rs:28-29,61 */
+    SC_ERR_HIP = 6,                 /* HIP runtime failure or no device */
+    SC_ERR_OOM = 7,
+    SC_ERR_REJECT = 8               /* verifier: "Prover message is not consistent with the claim." verifier.rs:107-113 */
+};
+
+enum sc_flags {
+    SC_TABLES_ON_DEVICE = 1u << 0, /* `tables[]` are device pointers (HBM-resident), not host */
+    SC_TABLES_BORROW = 1u << 1     /* with ON_DEVICE: do not copy; tables are only read and must outlive the handle */
+};
+
+/* Flattened ListOfProductsOfPolynomials (reference src/ml_sumcheck/data_structures.rs:25-35):
+ * products[k] = (coeffs[k], prod_indices[prod_offsets[k] .. prod_offsets[k+1]]) indexing `tables`. */
+typedef struct sc_poly_desc {
+    uint32_t num_vars;            /* num_variables */
+    uint32_t max_multiplicands;   /* must equal max_k m_k (data_structures.rs:79) */
+    uint32_t n_products;          /* K */
+    const uint64_t *coeffs;       /* K x 4 limbs (host) */
+    const uint32_t *prod_offsets; /* K+1 (host) */
+    const uint32_t *prod_indices; /* sum m_k entries (host), each < n_tables */
+    uint32_t n_tables;            /* U = flattened_ml_extensions.len() */
+    const uint64_t *const *tables;/* U pointers, each 2^num_vars x 4 limbs */
+    uint32_t flags;               /* sc_flags */
+} sc_poly_desc;
+
+typedef struct sc_prover sc_prover; /* ProverState (prover.rs:19-33) with tables resident in HBM */
+typedef struct sc_rng sc_rng;       /* Blake2b512Rng (reference src/rng.rs:22-25) */
+
+/* ---- library ------------------------------------------------------------------------------- */
+SC_API int sc_abi_version(void);
+SC_API const char *sc_last_error(void);     /* thread-local, valid until the next call on this thread */
+SC_API int sc_device_count(void);           /* number of visible HIP devices (0 => every compute call fails) */
+SC_API int sc_set_device(int ordinal);      /* device used by handles created afterwards on this thread */
+
+/* ---- IPForMLSumcheck::prover_init / prove_round (prover.rs:49-153) ------------------------- */
+SC_API int sc_prover_init(const sc_poly_desc *desc, sc_prover **out);
+/* r_or_null: NULL exactly on the first call, else the previous round's challenge (4 limbs).
+ * out_evals: (max_multiplicands+1) x 4 limbs = [P(0), P(1), ..., P(deg)] (ProverMsg, prover.rs:13-17). */
+SC_API int sc_prove_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals);
+/* MLSumcheck::prove_as_subprotocol pushes the final challenge without binding it (mod.rs:65-67). */
+SC_API int sc_prover_push_randomness(sc_prover *p, const uint64_t *r);
+/* Copy ProverState back to the host.  randomness: up to num_vars x 4 limbs (may be NULL);
+ * tables_out: U x 2^(num_vars - bound) x 4 limbs, bound = max(round-1, 0) (may be NULL);
+ * *round, *n_randomness may be NULL. */
+SC_API int sc_prover_state(sc_prover *p, uint64_t *randomness, uint32_t *n_randomness, uint64_t *tables_out, uint32_t *round);
+SC_API void sc_prover_free(sc_prover *p);
+/* Run the handle's kernels on a caller stream (a hipStream_t cast to void*; NULL = the handle's own). */
+SC_API int sc_prover_set_stream(sc_prover *p, void *hip_stream);
+
+/* Sharded use: this handle holds one contiguous high-bit shard of every table.
+ * sc_prove_round_partial = prove_round on the shard, result left ON THE DEVICE as (deg+1) x 8 uint64
+ * lanes, lane j of evaluation t = 32-bit limb j zero-extended -- summable across ranks with an integer
+ * all-reduce (no modular all-reduce exists); asynchronous on the handle's stream.
+ * sc_wide_reduce folds summed lanes (host) back to canonical Montgomery limbs. */
+SC_API int sc_prove_round_partial(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide_out);
+SC_API int sc_wide_reduce(const uint64_t *wide, uint32_t n_elems, uint64_t *out);
+/* Bind the last local variable: tables of 2 entries -> 1 entry each, written to d_out (U x 4 limbs,
+ * device), asynchronous on the handle's stream.  After this the handle is exhausted. */
+SC_API int sc_prover_bind_final(sc_prover *p, const uint64_t *r, uint64_t *d_out);
+
+/* ---- DenseMultilinearExtension::fix_variables (ark-poly; prover.rs:88, gkr mod.rs:122) ------ */
+/* in: 2^nv x 4 limbs, point: k x 4 limbs (binds variables 0..k-1, LSB first), out: 2^(nv-k) x 4.
+ * flags: SC_TABLES_ON_DEVICE => `in` and `out` are device pointers. */
+SC_API int sc_fix_variables(const uint64_t *in, uint32_t nv, const uint64_t *point, uint32_t k, uint64_t *out, uint32_t flags);
+
+/* ---- Blake2b512Rng / FeedableRNG (reference src/rng.rs:11-81) -- host side ------------------- */
+SC_API sc_rng *sc_rng_setup(void);
+SC_API void sc_rng_free(sc_rng *rng);
+SC_API void sc_rng_feed_bytes(sc_rng *rng, const uint8_t *buf, size_t len);             /* feed() after serialization */
+SC_API void sc_rng_fill_bytes(sc_rng *rng, uint8_t *dest, size_t len);                  /* RngCore::fill_bytes */
+SC_API void sc_rng_feed_poly_info(sc_rng *rng, uint64_t max_multiplicands, uint64_t num_variables); /* feed(&PolynomialInfo) */
+SC_API void sc_rng_feed_prover_msg(sc_rng *rng, const uint64_t *evals, uint32_t n);     /* feed(&ProverMsg) */
+SC_API void sc_rng_sample_fr(sc_rng *rng, uint64_t *out);                               /* sample_round = F::rand, verifier.rs:128-131 */
+
+/* ---- MLSumcheck::prove / prove_as_subprotocol (reference src/ml_sumcheck/mod.rs:42-70) ------- */
+/* rng_or_null: NULL = fresh Blake2b512Rng::setup() (MLSumcheck::prove).  out_proof: num_vars x (deg+1) x 4.
+ * out_state_or_null: receives the ProverState handle (caller frees) as prove_as_subprotocol returns it. */
+SC_API int sc_ml_prove(const sc_poly_desc *desc, sc_rng *rng_or_null, uint64_t *out_proof, sc_prover **out_state_or_null);
+/* the same loop on an existing handle at round 0 (sc_prover_init / sc_prover_reset): no allocation per proof */
+SC_API int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *out_proof);
+
+/* ---- verifier (reference src/ml_sumcheck/protocol/verifier.rs:90-251) -- host side, O(nv*deg) - */
+SC_API int sc_interpolate_uni_poly(const uint64_t *p_i, uint32_t len, const uint64_t *eval_at, uint64_t *out);
+/* MLSumcheck::verify_as_subprotocol (mod.rs:84-100): returns SC_OK / SC_ERR_REJECT;
+ * out_point: num_vars x 4, out_expected: 4 limbs (SubClaim, verifier.rs:29-34). */
+SC_API int sc_ml_verify(uint32_t num_vars, uint32_t max_multiplicands, const uint64_t *claimed_sum, const uint64_t *proof,
+                 sc_rng *rng_or_null, uint64_t *out_point, uint64_t *out_expected);
+
+/* ---- GKR round sumcheck (reference src/gkr_round_sumcheck/mod.rs) ---------------------------- */
+/* f1 is a SparseMultilinearExtension over 3*dim variables given as nnz (index, value) pairs with
+ * distinct indices (index layout z | x<<dim | y<<2dim, mod.rs:34-35); f2,f3,g host arrays.
+ * initialize_phase_one (mod.rs:22-42): h_g = 2^dim x 4 out; f1_g out as sorted (index,value) pairs,
+ * capacity nnz, *f1g_nnz = count. */
+SC_API int sc_gkr_phase_one(const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim, const uint64_t *f3,
+                     const uint64_t *g, uint64_t *h_g, uint64_t *f1g_idx, uint64_t *f1g_vals, uint64_t *f1g_nnz);
+/* initialize_phase_two (mod.rs:57-63): f1_gu = 2^dim x 4 out */
+SC_API int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_vals, uint64_t nnz, uint32_t dim, const uint64_t *u,
+                     uint64_t *f1_gu);
+/* GKRRoundSumcheck::prove (mod.rs:93-139).  out_proof: 2 x dim x 3 x 4 limbs (phase1 then phase2
+ * messages); out_uv_or_null: 2 x dim x 4 (u then v). */
+SC_API int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim,
+                 const uint64_t *f2, const uint64_t *f3, const uint64_t *g, uint64_t *out_proof, uint64_t *out_uv_or_null);
+
+/* ---- synthetic inputs + instrumentation (bench / tests) ------------------------------------- */
+/* SplitMix64-keyed uniform field elements, generated on the device: n elements of
+ * stream `stream` starting at element `first`, written to device memory d_out (n x 4 limbs). */
+SC_API int sc_synth_table_device(uint64_t seed, uint64_t stream, uint64_t first, uint64_t n, uint64_t *d_out);
+/* Device-side timing of the handle's last sc_prove_round: milliseconds between HIP events recorded
+ * on the handle's stream around the round's kernels (excludes the D2H of the evaluations). */
+SC_API int sc_prover_last_round_ms(sc_prover *p, float *ms);
+/* Per-product instrumentation: with timing on, every product kernel launch is bracketed by HIP events on the
+ * handle's stream; sc_prover_get_timing returns the accumulated device milliseconds and launch counts per
+ * product (K entries each) and the accumulated per-round span (all kernels of a round incl. finalize). */
+SC_API int sc_prover_set_timing(sc_prover *p, int on);
+SC_API int sc_prover_get_timing(sc_prover *p, double *ms_per_product, uint64_t *launches_per_product, double *rounds_ms);
+/* Rewind a handle to round 0 without reallocating (repeated proofs over resident tables).  Borrowing handle:
+ * tables_or_null = new device pointers, or NULL for the same tables.  Copying handle: tables are required and
+ * copied in again (device pointers iff flags has SC_TABLES_ON_DEVICE). */
+SC_API int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_null, uint32_t flags);
+/* Elementwise micro-kernel: out[i] = a[i]*b[i] repeated `reps` times in registers (modmul ceiling). */
+SC_API int sc_bench_modmul(uint64_t n_threads, uint32_t reps, uint32_t variant, float *ms_out, uint64_t *checksum_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUMCHECK_HIP_H */

@@ -1,0 +1,114 @@
+"""ctypes loader for libsumcheck_hip.so -- the C ABI declared in include/sumcheck_hip.h.
+
+There is no CPU fallback: if the shared library is missing this raises, and on a machine without a
+HIP device every compute entry point returns SC_ERR_HIP (surfaced as SumcheckError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libsumcheck_hip.so")
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+SC_OK = 0
+SC_ERR_CONSTANT_POLY = 1
+SC_ERR_FIRST_ROUND_HAS_MSG = 2
+SC_ERR_MISSING_MSG = 3
+SC_ERR_NOT_ACTIVE = 4
+SC_ERR_BAD_ARG = 5
+SC_ERR_HIP = 6
+SC_ERR_OOM = 7
+SC_ERR_REJECT = 8
+
+SC_TABLES_ON_DEVICE = 1
+SC_TABLES_BORROW = 2
+
+
+class PolyDesc(C.Structure):
+    _fields_ = [
+        ("num_vars", C.c_uint32),
+        ("max_multiplicands", C.c_uint32),
+        ("n_products", C.c_uint32),
+        ("coeffs", u64p),
+        ("prod_offsets", u32p),
+        ("prod_indices", u32p),
+        ("n_tables", C.c_uint32),
+        ("tables", C.POINTER(C.c_void_p)),
+        ("flags", C.c_uint32),
+    ]
+
+
+# every symbol include/sumcheck_hip.h declares: (restype, argtypes)
+_V = C.c_void_p
+SIGNATURES = {
+    "sc_abi_version": (C.c_int, []),
+    "sc_last_error": (C.c_char_p, []),
+    "sc_device_count": (C.c_int, []),
+    "sc_set_device": (C.c_int, [C.c_int]),
+    "sc_prover_init": (C.c_int, [C.POINTER(PolyDesc), C.POINTER(_V)]),
+    "sc_prove_round": (C.c_int, [_V, _V, _V]),
+    "sc_prover_push_randomness": (C.c_int, [_V, _V]),
+    "sc_prover_state": (C.c_int, [_V, _V, u32p, _V, u32p]),
+    "sc_prover_free": (None, [_V]),
+    "sc_prover_set_stream": (C.c_int, [_V, _V]),
+    "sc_prove_round_partial": (C.c_int, [_V, _V, _V]),
+    "sc_wide_reduce": (C.c_int, [_V, C.c_uint32, _V]),
+    "sc_prover_bind_final": (C.c_int, [_V, _V, _V]),
+    "sc_fix_variables": (C.c_int, [_V, C.c_uint32, _V, C.c_uint32, _V, C.c_uint32]),
+    "sc_rng_setup": (_V, []),
+    "sc_rng_free": (None, [_V]),
+    "sc_rng_feed_bytes": (None, [_V, C.c_char_p, C.c_size_t]),
+    "sc_rng_fill_bytes": (None, [_V, _V, C.c_size_t]),
+    "sc_rng_feed_poly_info": (None, [_V, C.c_uint64, C.c_uint64]),
+    "sc_rng_feed_prover_msg": (None, [_V, _V, C.c_uint32]),
+    "sc_rng_sample_fr": (None, [_V, _V]),
+    "sc_ml_prove": (C.c_int, [C.POINTER(PolyDesc), _V, _V, C.POINTER(_V)]),
+    "sc_ml_prove_handle": (C.c_int, [_V, _V, _V]),
+    "sc_interpolate_uni_poly": (C.c_int, [_V, C.c_uint32, _V, _V]),
+    "sc_ml_verify": (C.c_int, [C.c_uint32, C.c_uint32, _V, _V, _V, _V, _V]),
+    "sc_gkr_phase_one": (C.c_int, [_V, _V, C.c_uint64, C.c_uint32, _V, _V, _V, _V, _V, u64p]),
+    "sc_gkr_phase_two": (C.c_int, [_V, _V, C.c_uint64, C.c_uint32, _V, _V]),
+    "sc_gkr_prove": (C.c_int, [_V, _V, _V, C.c_uint64, C.c_uint32, _V, _V, _V, _V, _V]),
+    "sc_synth_table_device": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _V]),
+    "sc_prover_last_round_ms": (C.c_int, [_V, C.POINTER(C.c_float)]),
+    "sc_prover_set_timing": (C.c_int, [_V, C.c_int]),
+    "sc_prover_get_timing": (C.c_int, [_V, C.POINTER(C.c_double), u64p, C.POINTER(C.c_double)]),
+    "sc_prover_reset": (C.c_int, [_V, _V, C.c_uint32]),
+    "sc_bench_modmul": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), u64p]),
+}
+
+_lib = None
+
+
+class SumcheckError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[sc_status {code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def lib():
+    """Load the HIP library (raises if it has not been built: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(sumcheck_amd has no CPU fallback)")
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != SC_OK:
+        raise SumcheckError(rc, lib().sc_last_error().decode("utf-8", "replace"))

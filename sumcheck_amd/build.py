@@ -1,0 +1,47 @@
+"""Build libsumcheck_hip.so (gfx950) in-tree with hipcc.  Cross-compiles without a GPU."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libsumcheck_hip.so")
+SOURCES = ["kernels.hip", "gkr.hip", "api.hip"]
+HEADERS = ["fr.cuh", "kernels.h", "host_fr.hpp", "transcript.hpp", os.path.join("..", "..", "include", "sumcheck_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for s in SOURCES:
+        o = os.path.join(HERE, "build", s + ".o")
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(o)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

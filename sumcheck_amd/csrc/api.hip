@@ -1,0 +1,799 @@
+// api.hip -- the C ABI of libsumcheck_hip.so (declared in include/sumcheck_hip.h): prover state
+// resident in HBM, the per-round launch plan, and the host-side protocol drivers that the reference
+// runs around prove_round (reference src/ml_sumcheck/mod.rs:50-70).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sumcheck_hip.h"
+#include "host_fr.hpp"
+#include "kernels.h"
+#include "transcript.hpp"
+
+using scd::FinProd;
+using scd::FrHost;
+using scd::ProdArgs;
+
+// ---------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static thread_local int g_device = 0;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                                   \
+    do {                                                                                                                \
+        hipError_t e_ = (expr);                                                                                         \
+        if (e_ != hipSuccess)                                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? SC_ERR_OOM : SC_ERR_HIP, "%s failed: %s (%s:%d)", #expr,            \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                                     \
+    } while (0)
+
+static inline FrHost to_dev(const sch::Fr &a) {
+    FrHost h;
+    std::memcpy(&h, &a, sizeof(h));
+    return h;
+}
+
+extern "C" int sc_abi_version(void) { return SC_ABI_VERSION; }
+extern "C" const char *sc_last_error(void) { return g_last_error.c_str(); }
+extern "C" int sc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+extern "C" int sc_set_device(int ordinal) {
+    HIP_TRY(hipSetDevice(ordinal));
+    g_device = ordinal;
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// transcript ABI (host)
+// ---------------------------------------------------------------------------------------------------
+struct sc_rng {
+    sch::Blake2b512Rng rng;
+};
+extern "C" sc_rng *sc_rng_setup(void) { return new (std::nothrow) sc_rng(); }
+extern "C" void sc_rng_free(sc_rng *rng) { delete rng; }
+extern "C" void sc_rng_feed_bytes(sc_rng *rng, const uint8_t *buf, size_t len) { rng->rng.feed_bytes(buf, len); }
+extern "C" void sc_rng_fill_bytes(sc_rng *rng, uint8_t *dest, size_t len) { rng->rng.fill_bytes(dest, len); }
+extern "C" void sc_rng_feed_poly_info(sc_rng *rng, uint64_t max_multiplicands, uint64_t num_variables) {
+    rng->rng.feed_poly_info(max_multiplicands, num_variables);
+}
+extern "C" void sc_rng_feed_prover_msg(sc_rng *rng, const uint64_t *evals, uint32_t n) {
+    rng->rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(evals), n);
+}
+extern "C" void sc_rng_sample_fr(sc_rng *rng, uint64_t *out) {
+    const sch::Fr a = rng->rng.sample_fr();
+    std::memcpy(out, a.l, 32);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ProverState in HBM
+// ---------------------------------------------------------------------------------------------------
+struct Product {
+    sch::Fr coeff;
+    std::vector<uint32_t> tables; // distinct tables of the product, first-occurrence order
+    std::vector<uint32_t> exps;   // multiplicity of each
+    uint32_t M = 0;               // number of multiplicands
+    bool fused = false;           // M <= kMaxFusedM: register-resident kernel, bind fused in
+    uint64_t partial_off = 0;     // element offset into d_partials
+    uint32_t slot_off = 0;        // generic path: offset into d_slot_table / d_slot_exp
+};
+
+struct Table {
+    const uint4 *cur = nullptr; // this round's evaluations
+    uint4 *buf[2] = {nullptr, nullptr};
+    int next = 0;               // buffer the next bind writes to
+};
+
+struct sc_prover {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    uint32_t nv = 0, max_mult = 0, D = 0, K = 0, U = 0, round = 0;
+    bool exhausted = false;
+    std::vector<sch::Fr> randomness;
+    std::vector<Product> prods;
+    std::vector<Table> tabs;
+    void *arena = nullptr;
+    FrHost *d_partials = nullptr;
+    FinProd *d_finprods = nullptr;
+    FrHost *d_scratch = nullptr;
+    FrHost *d_out = nullptr;
+    FrHost *h_out = nullptr; // pinned
+    bool any_generic = false;
+    const uint4 **d_cur_tables = nullptr;
+    const uint4 **h_cur_tables = nullptr; // pinned
+    uint32_t *d_slot_table = nullptr, *d_slot_exp = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    // reset support + per-product instrumentation
+    bool borrow = false;
+    std::vector<const uint4 *> origin; // borrowed table pointers (borrow mode)
+    bool timing = false, timing_pending = false;
+    std::vector<hipEvent_t> prod_ev;   // 2 per product
+    std::vector<double> prod_ms;       // accumulated device time of each product's kernel
+    std::vector<uint64_t> prod_launches;
+    double rounds_ms = 0.0;            // accumulated ev0..ev1 (all kernels of a round incl. finalize)
+};
+
+static void prover_destroy(sc_prover *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
+    if (p->arena) (void)hipFree(p->arena);
+    if (p->d_partials) (void)hipFree(p->d_partials);
+    if (p->d_finprods) (void)hipFree(p->d_finprods);
+    if (p->d_scratch) (void)hipFree(p->d_scratch);
+    if (p->d_out) (void)hipFree(p->d_out);
+    if (p->h_out) (void)hipHostFree(p->h_out);
+    if (p->d_cur_tables) (void)hipFree(p->d_cur_tables);
+    if (p->h_cur_tables) (void)hipHostFree(p->h_cur_tables);
+    if (p->d_slot_table) (void)hipFree(p->d_slot_table);
+    if (p->d_slot_exp) (void)hipFree(p->d_slot_exp);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    for (hipEvent_t e : p->prod_ev) (void)hipEventDestroy(e);
+    if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+    delete p;
+}
+
+extern "C" void sc_prover_free(sc_prover *p) { prover_destroy(p); }
+
+static int validate_desc(const sc_poly_desc *d) {
+    if (!d) return fail(SC_ERR_BAD_ARG, "null descriptor");
+    if (d->num_vars == 0) return fail(SC_ERR_CONSTANT_POLY, "Attempt to prove a constant.");
+    if (d->num_vars > 40) return fail(SC_ERR_BAD_ARG, "num_vars %u too large", d->num_vars);
+    if (d->n_tables == 0 || !d->tables) return fail(SC_ERR_BAD_ARG, "no tables");
+    if (d->n_products && (!d->coeffs || !d->prod_offsets || !d->prod_indices)) return fail(SC_ERR_BAD_ARG, "null product arrays");
+    uint32_t mx = 0;
+    for (uint32_t k = 0; k < d->n_products; ++k) {
+        if (d->prod_offsets[k + 1] <= d->prod_offsets[k]) return fail(SC_ERR_BAD_ARG, "product %u is empty", k); // data_structures.rs:78
+        mx = std::max(mx, d->prod_offsets[k + 1] - d->prod_offsets[k]);
+        for (uint32_t q = d->prod_offsets[k]; q < d->prod_offsets[k + 1]; ++q)
+            if (d->prod_indices[q] >= d->n_tables) return fail(SC_ERR_BAD_ARG, "product %u refers to table %u >= %u", k, d->prod_indices[q], d->n_tables);
+    }
+    if (mx != d->max_multiplicands) return fail(SC_ERR_BAD_ARG, "max_multiplicands %u != max product length %u", d->max_multiplicands, mx);
+    for (uint32_t u = 0; u < d->n_tables; ++u)
+        if (!d->tables[u]) return fail(SC_ERR_BAD_ARG, "table %u is null", u);
+    return SC_OK;
+}
+
+static int prover_build(const sc_poly_desc *d, sc_prover *p) {
+    if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    p->device = g_device;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
+    p->stream = p->own_stream;
+    HIP_TRY(hipEventCreate(&p->ev0));
+    HIP_TRY(hipEventCreate(&p->ev1));
+    p->nv = d->num_vars;
+    p->max_mult = d->max_multiplicands;
+    p->D = d->max_multiplicands + 1;
+    p->K = d->n_products;
+    p->U = d->n_tables;
+    p->randomness.reserve(p->nv);
+
+    // products: distinct tables + multiplicities
+    uint64_t partial_elems = 0;
+    std::vector<uint32_t> slot_table, slot_exp;
+    std::vector<FinProd> fin(p->K);
+    for (uint32_t k = 0; k < p->K; ++k) {
+        Product pr;
+        std::memcpy(&pr.coeff, d->coeffs + 4 * k, 32);
+        if (sch::geq_p(pr.coeff)) return fail(SC_ERR_BAD_ARG, "coefficient %u is not a canonical field element", k);
+        for (uint32_t q = d->prod_offsets[k]; q < d->prod_offsets[k + 1]; ++q) {
+            const uint32_t t = d->prod_indices[q];
+            auto it = std::find(pr.tables.begin(), pr.tables.end(), t);
+            if (it == pr.tables.end()) {
+                pr.tables.push_back(t);
+                pr.exps.push_back(1);
+            } else {
+                pr.exps[it - pr.tables.begin()]++;
+            }
+        }
+        pr.M = d->prod_offsets[k + 1] - d->prod_offsets[k];
+        pr.fused = pr.M <= (uint32_t)scd::kMaxFusedM;
+        if (!pr.fused) p->any_generic = true;
+        pr.partial_off = partial_elems;
+        partial_elems += (uint64_t)scd::kMaxGrid * (pr.M + 1);
+        pr.slot_off = (uint32_t)slot_table.size();
+        slot_table.insert(slot_table.end(), pr.tables.begin(), pr.tables.end());
+        slot_exp.insert(slot_exp.end(), pr.exps.begin(), pr.exps.end());
+        fin[k].M = pr.M;
+        fin[k].pad = 0;
+        fin[k].partial_off = pr.partial_off;
+        fin[k].coeff = to_dev(pr.coeff);
+        p->prods.push_back(std::move(pr));
+    }
+
+    // table memory: copy mode = A (2^nv) + B (2^(nv-1)); borrow mode = B (2^(nv-1)) + C (2^(nv-2))
+    const bool on_device = d->flags & SC_TABLES_ON_DEVICE;
+    const bool borrow = on_device && (d->flags & SC_TABLES_BORROW);
+    const uint64_t n = 1ULL << p->nv;
+    const uint64_t s0 = borrow ? std::max<uint64_t>(n >> 1, 1) : n;
+    const uint64_t s1 = borrow ? std::max<uint64_t>(n >> 2, 1) : std::max<uint64_t>(n >> 1, 1);
+    const uint64_t per_table = (s0 + s1) * 32;
+    HIP_TRY(hipMalloc(&p->arena, per_table * p->U));
+    p->tabs.resize(p->U);
+    p->borrow = borrow;
+    for (uint32_t u = 0; u < p->U; ++u) {
+        Table &t = p->tabs[u];
+        char *base = static_cast<char *>(p->arena) + per_table * u;
+        t.buf[0] = reinterpret_cast<uint4 *>(base);
+        t.buf[1] = reinterpret_cast<uint4 *>(base + s0 * 32);
+        if (borrow) {
+            t.cur = reinterpret_cast<const uint4 *>(d->tables[u]);
+            t.next = 0;
+            p->origin.push_back(t.cur);
+        } else {
+            HIP_TRY(hipMemcpyAsync(t.buf[0], d->tables[u], n * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, p->stream));
+            t.cur = t.buf[0];
+            t.next = 1;
+        }
+    }
+
+    HIP_TRY(hipMalloc(&p->d_partials, std::max<uint64_t>(partial_elems, 1) * 32));
+    HIP_TRY(hipMalloc(&p->d_finprods, std::max<size_t>(p->K, 1) * sizeof(FinProd)));
+    if (p->K) HIP_TRY(hipMemcpyAsync(p->d_finprods, fin.data(), p->K * sizeof(FinProd), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMalloc(&p->d_scratch, (size_t)2 * std::max<uint32_t>(p->K, 1) * p->D * 32));
+    HIP_TRY(hipMalloc(&p->d_out, (size_t)p->D * 32));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_out), (size_t)p->D * 32, hipHostMallocDefault));
+    if (p->any_generic) {
+        HIP_TRY(hipMalloc(&p->d_cur_tables, p->U * sizeof(void *)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_cur_tables), p->U * sizeof(void *), hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&p->d_slot_table, slot_table.size() * 4));
+        HIP_TRY(hipMalloc(&p->d_slot_exp, slot_exp.size() * 4));
+        HIP_TRY(hipMemcpyAsync(p->d_slot_table, slot_table.data(), slot_table.size() * 4, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->d_slot_exp, slot_exp.data(), slot_exp.size() * 4, hipMemcpyHostToDevice, p->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream)); // inputs are copied: the caller may drop them now (prover.rs:55-59)
+    return SC_OK;
+}
+
+extern "C" int sc_prover_init(const sc_poly_desc *desc, sc_prover **out) {
+    if (!out) return fail(SC_ERR_BAD_ARG, "null out");
+    *out = nullptr;
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    sc_prover *p = new (std::nothrow) sc_prover();
+    if (!p) return fail(SC_ERR_OOM, "host allocation failed");
+    rc = prover_build(desc, p);
+    if (rc) {
+        prover_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return SC_OK;
+}
+
+extern "C" int sc_prover_set_stream(sc_prover *p, void *hip_stream) {
+    if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : p->own_stream;
+    return SC_OK;
+}
+
+// fold the previous round's event pairs into the accumulators (blocks until that round has finished)
+static int collect_timing(sc_prover *p) {
+    if (!p->timing || !p->timing_pending) return SC_OK;
+    HIP_TRY(hipEventSynchronize(p->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    p->rounds_ms += ms;
+    for (uint32_t k = 0; k < p->K; ++k) {
+        HIP_TRY(hipEventElapsedTime(&ms, p->prod_ev[2 * k], p->prod_ev[2 * k + 1]));
+        p->prod_ms[k] += ms;
+        p->prod_launches[k] += 1;
+    }
+    p->timing_pending = false;
+    return SC_OK;
+}
+
+// Launch one round's kernels on p->stream.  On return the round polynomial is in p->d_out (and in
+// d_wide if non-null); nothing has been synchronised.
+static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide) {
+    // validation, same precedence as the reference's panics (prover.rs:78-98)
+    if (p->exhausted) return fail(SC_ERR_NOT_ACTIVE, "Prover is not active");
+    if (r_or_null && p->round == 0) return fail(SC_ERR_FIRST_ROUND_HAS_MSG, "first round should be prover first.");
+    if (!r_or_null && p->round > 0) return fail(SC_ERR_MISSING_MSG, "verifier message is empty");
+    if (p->round + 1 > p->nv) return fail(SC_ERR_NOT_ACTIVE, "Prover is not active");
+    sch::Fr r = sch::zero();
+    if (r_or_null) {
+        std::memcpy(&r, r_or_null, 32);
+        if (sch::geq_p(r)) return fail(SC_ERR_BAD_ARG, "challenge is not a canonical field element");
+    }
+    HIP_TRY(hipSetDevice(p->device));
+    {
+        int rc_t = collect_timing(p);
+        if (rc_t) return rc_t;
+    }
+    bool bind = r_or_null != nullptr;
+    if (bind) p->randomness.push_back(r);
+    p->round += 1;
+    const uint64_t n_pairs = 1ULL << (p->nv - p->round);
+    const FrHost rdev = to_dev(r);
+    const int grid = scd::grid_for_pairs(n_pairs);
+    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+
+    auto bind_table = [&](uint32_t u) -> hipError_t { // stand-alone bind of table u (2*n_pairs outputs)
+        Table &t = p->tabs[u];
+        uint4 *dst = t.buf[t.next];
+        hipError_t e = scd::launch_fix(t.cur, dst, rdev, 2 * n_pairs, p->stream);
+        t.cur = dst;
+        t.next ^= 1;
+        return e;
+    };
+
+    if (bind && p->any_generic) { // generic products read bound tables: bind everything up front
+        for (uint32_t u = 0; u < p->U; ++u) HIP_TRY(bind_table(u));
+        bind = false;
+    }
+    std::vector<uint8_t> bound(p->U, 0);
+    bool ptrs_uploaded = false;
+    for (uint32_t k = 0; k < p->K; ++k) {
+        const Product &pr = p->prods[k];
+        FrHost *partials = p->d_partials + pr.partial_off;
+        if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[2 * k], p->stream));
+        if (pr.fused) {
+            ProdArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.n_slots = (int)pr.tables.size();
+            for (size_t s = 0; s < pr.tables.size(); ++s) {
+                Table &t = p->tabs[pr.tables[s]];
+                a.slot[s].exp = pr.exps[s];
+                if (bind && !bound[pr.tables[s]]) { // first product touching this table this round binds it
+                    a.slot[s].mode = 1;
+                    a.slot[s].src = t.cur;
+                    a.slot[s].dst = t.buf[t.next];
+                    t.cur = t.buf[t.next];
+                    t.next ^= 1;
+                    bound[pr.tables[s]] = 1;
+                } else {
+                    a.slot[s].mode = 0;
+                    a.slot[s].src = t.cur;
+                    a.slot[s].dst = nullptr;
+                }
+            }
+            HIP_TRY(scd::launch_prod_round((int)pr.M, a, rdev, n_pairs, partials, grid, p->stream));
+        } else {
+            if (!ptrs_uploaded) {
+                for (uint32_t u = 0; u < p->U; ++u) p->h_cur_tables[u] = p->tabs[u].cur;
+                HIP_TRY(hipMemcpyAsync(p->d_cur_tables, p->h_cur_tables, p->U * sizeof(void *), hipMemcpyHostToDevice, p->stream));
+                ptrs_uploaded = true;
+            }
+            HIP_TRY(scd::launch_sum_generic(p->d_cur_tables, p->d_slot_table + pr.slot_off, p->d_slot_exp + pr.slot_off,
+                                            (int)pr.tables.size(), (int)pr.M, n_pairs, partials, grid, p->stream));
+        }
+        if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[2 * k + 1], p->stream));
+    }
+    if (bind) { // tables that no product refers to still follow the state machine
+        for (uint32_t u = 0; u < p->U; ++u)
+            if (!bound[u]) HIP_TRY(bind_table(u));
+    }
+    HIP_TRY(scd::launch_finalize(p->d_finprods, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide, p->stream));
+    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    p->timed = true;
+    p->timing_pending = p->timing;
+    return SC_OK;
+}
+
+extern "C" int sc_prove_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals) {
+    if (!p || !out_evals) return fail(SC_ERR_BAD_ARG, "null argument");
+    int rc = launch_round(p, r_or_null, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(p->h_out, p->d_out, (size_t)p->D * 32, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    std::memcpy(out_evals, p->h_out, (size_t)p->D * 32);
+    return SC_OK;
+}
+
+extern "C" int sc_prove_round_partial(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide_out) {
+    if (!p || !d_wide_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    return launch_round(p, r_or_null, d_wide_out);
+}
+
+extern "C" int sc_prover_bind_final(sc_prover *p, const uint64_t *r, uint64_t *d_out) {
+    if (!p || !r || !d_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (p->exhausted || p->round != p->nv) return fail(SC_ERR_NOT_ACTIVE, "bind_final needs a prover that has finished its last local round");
+    sch::Fr rr;
+    std::memcpy(&rr, r, 32);
+    if (sch::geq_p(rr)) return fail(SC_ERR_BAD_ARG, "challenge is not a canonical field element");
+    HIP_TRY(hipSetDevice(p->device));
+    p->randomness.push_back(rr);
+    for (uint32_t u = 0; u < p->U; ++u)
+        HIP_TRY(scd::launch_fix(p->tabs[u].cur, reinterpret_cast<uint4 *>(d_out + 4 * (size_t)u), to_dev(rr), 1, p->stream));
+    p->exhausted = true;
+    return SC_OK;
+}
+
+extern "C" int sc_prover_push_randomness(sc_prover *p, const uint64_t *r) {
+    if (!p || !r) return fail(SC_ERR_BAD_ARG, "null argument");
+    sch::Fr rr;
+    std::memcpy(&rr, r, 32);
+    p->randomness.push_back(rr);
+    return SC_OK;
+}
+
+extern "C" int sc_prover_state(sc_prover *p, uint64_t *randomness, uint32_t *n_randomness, uint64_t *tables_out, uint32_t *round) {
+    if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    if (randomness && !p->randomness.empty()) std::memcpy(randomness, p->randomness.data(), p->randomness.size() * 32);
+    if (n_randomness) *n_randomness = (uint32_t)p->randomness.size();
+    if (round) *round = p->round;
+    if (tables_out) {
+        if (p->exhausted) return fail(SC_ERR_NOT_ACTIVE, "tables were consumed by sc_prover_bind_final");
+        HIP_TRY(hipSetDevice(p->device));
+        const uint32_t bound = p->round > 0 ? p->round - 1 : 0;
+        const uint64_t n = 1ULL << (p->nv - bound);
+        for (uint32_t u = 0; u < p->U; ++u)
+            HIP_TRY(hipMemcpyAsync(tables_out + 4 * n * u, p->tabs[u].cur, n * 32, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
+    return SC_OK;
+}
+
+extern "C" int sc_prover_last_round_ms(sc_prover *p, float *ms) {
+    if (!p || !ms) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (!p->timed) return fail(SC_ERR_BAD_ARG, "no round has been launched");
+    HIP_TRY(hipEventSynchronize(p->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, p->ev0, p->ev1));
+    return SC_OK;
+}
+
+extern "C" int sc_prover_set_timing(sc_prover *p, int on) {
+    if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    HIP_TRY(hipSetDevice(p->device));
+    if (on && p->prod_ev.empty()) {
+        p->prod_ev.resize(2 * (size_t)p->K);
+        for (auto &e : p->prod_ev) HIP_TRY(hipEventCreate(&e));
+    }
+    p->timing = on != 0;
+    p->timing_pending = false;
+    p->prod_ms.assign(p->K, 0.0);
+    p->prod_launches.assign(p->K, 0);
+    p->rounds_ms = 0.0;
+    return SC_OK;
+}
+
+extern "C" int sc_prover_get_timing(sc_prover *p, double *ms_per_product, uint64_t *launches_per_product, double *rounds_ms) {
+    if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    if (!p->timing) return fail(SC_ERR_BAD_ARG, "timing is not enabled on this handle");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = collect_timing(p);
+    if (rc) return rc;
+    for (uint32_t k = 0; k < p->K; ++k) {
+        if (ms_per_product) ms_per_product[k] = p->prod_ms[k];
+        if (launches_per_product) launches_per_product[k] = p->prod_launches[k];
+    }
+    if (rounds_ms) *rounds_ms = p->rounds_ms;
+    return SC_OK;
+}
+
+// Rewind a handle to round 0 without reallocating.  Borrow mode: tables_or_null = new borrowed device
+// pointers (NULL = the same tables again).  Copy mode: tables must be given and are copied in again
+// (host pointers, or device pointers when flags has SC_TABLES_ON_DEVICE).
+extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_null, uint32_t flags) {
+    if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    HIP_TRY(hipSetDevice(p->device));
+    {
+        int rc_t = collect_timing(p);
+        if (rc_t) return rc_t;
+    }
+    const uint64_t n = 1ULL << p->nv;
+    if (p->borrow) {
+        for (uint32_t u = 0; u < p->U; ++u) {
+            if (tables_or_null) {
+                if (!tables_or_null[u]) return fail(SC_ERR_BAD_ARG, "table %u is null", u);
+                p->origin[u] = reinterpret_cast<const uint4 *>(tables_or_null[u]);
+            }
+            p->tabs[u].cur = p->origin[u];
+            p->tabs[u].next = 0;
+        }
+    } else {
+        if (!tables_or_null) return fail(SC_ERR_BAD_ARG, "a copying handle needs the tables again to reset");
+        const bool on_device = flags & SC_TABLES_ON_DEVICE;
+        for (uint32_t u = 0; u < p->U; ++u) {
+            if (!tables_or_null[u]) return fail(SC_ERR_BAD_ARG, "table %u is null", u);
+            HIP_TRY(hipMemcpyAsync(p->tabs[u].buf[0], tables_or_null[u], n * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                   p->stream));
+            p->tabs[u].cur = p->tabs[u].buf[0];
+            p->tabs[u].next = 1;
+        }
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
+    p->round = 0;
+    p->exhausted = false;
+    p->randomness.clear();
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// DenseMultilinearExtension::fix_variables
+// ---------------------------------------------------------------------------------------------------
+extern "C" int sc_fix_variables(const uint64_t *in, uint32_t nv, const uint64_t *point, uint32_t k, uint64_t *out, uint32_t flags) {
+    if (!in || !out || (k && !point)) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (k > nv || nv > 40) return fail(SC_ERR_BAD_ARG, "invalid partial point dimension"); // ark-poly's assert
+    if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    HIP_TRY(hipSetDevice(g_device));
+    const bool on_device = flags & SC_TABLES_ON_DEVICE;
+    const uint64_t n = 1ULL << nv;
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    void *a = nullptr;
+    int rc = SC_OK;
+    auto cleanup = [&]() {
+        if (a) (void)hipFree(a);
+        (void)hipStreamDestroy(s);
+    };
+#define FV_TRY(expr)                                                                                                    \
+    do {                                                                                                                \
+        hipError_t e_ = (expr);                                                                                         \
+        if (e_ != hipSuccess) {                                                                                         \
+            rc = fail(e_ == hipErrorOutOfMemory ? SC_ERR_OOM : SC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            cleanup();                                                                                                  \
+            return rc;                                                                                                  \
+        }                                                                                                               \
+    } while (0)
+    void *w[2] = {nullptr, nullptr}; // ping-pong work buffers: w[0] holds n/2, w[1] holds n/4
+    auto cleanup_w = [&]() {
+        if (w[0]) (void)hipFree(w[0]);
+        if (w[1]) (void)hipFree(w[1]);
+    };
+    const uint4 *cur;
+    if (on_device) {
+        cur = reinterpret_cast<const uint4 *>(in);
+    } else {
+        FV_TRY(hipMalloc(&a, n * 32));
+        FV_TRY(hipMemcpyAsync(a, in, n * 32, hipMemcpyHostToDevice, s));
+        cur = static_cast<const uint4 *>(a);
+    }
+    uint64_t m = n;
+    for (uint32_t i = 0; i < k; ++i) {
+        sch::Fr r;
+        std::memcpy(&r, point + 4 * i, 32);
+        if (sch::geq_p(r)) {
+            rc = fail(SC_ERR_BAD_ARG, "point[%u] is not a canonical field element", i);
+            cleanup_w();
+            cleanup();
+            return rc;
+        }
+        m >>= 1;
+        uint4 *target;
+        if (i + 1 == k && on_device) {
+            target = reinterpret_cast<uint4 *>(out);
+        } else {
+            if (!w[i & 1]) {
+                hipError_t e_ = hipMalloc(&w[i & 1], std::max<uint64_t>(m, 1) * 32);
+                if (e_ != hipSuccess) {
+                    rc = fail(SC_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e_));
+                    cleanup_w();
+                    cleanup();
+                    return rc;
+                }
+            }
+            target = static_cast<uint4 *>(w[i & 1]);
+        }
+        hipError_t e_ = scd::launch_fix(cur, target, to_dev(r), m, s);
+        if (e_ != hipSuccess) {
+            rc = fail(SC_ERR_HIP, "launch_fix failed: %s", hipGetErrorString(e_));
+            cleanup_w();
+            cleanup();
+            return rc;
+        }
+        cur = target;
+    }
+    if (!(k > 0 && on_device)) {
+        hipError_t e_ = hipMemcpyAsync(out, cur, m * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s);
+        if (e_ == hipSuccess) e_ = hipStreamSynchronize(s);
+        if (e_ != hipSuccess) {
+            rc = fail(SC_ERR_HIP, "copy-out failed: %s", hipGetErrorString(e_));
+            cleanup_w();
+            cleanup();
+            return rc;
+        }
+    }
+    {
+        hipError_t e_ = hipStreamSynchronize(s);
+        cleanup_w();
+        if (e_ != hipSuccess) {
+            rc = fail(SC_ERR_HIP, "sync failed: %s", hipGetErrorString(e_));
+            cleanup();
+            return rc;
+        }
+    }
+    FV_TRY(hipStreamSynchronize(s));
+    cleanup();
+#undef FV_TRY
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MLSumcheck::prove_as_subprotocol (reference src/ml_sumcheck/mod.rs:50-70)
+// ---------------------------------------------------------------------------------------------------
+// The Fiat-Shamir loop of mod.rs:54-67 on an existing handle at round 0 (fresh from sc_prover_init or sc_prover_reset).
+extern "C" int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *out_proof) {
+    if (!p || !out_proof) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (p->round != 0) return fail(SC_ERR_BAD_ARG, "handle is not at round 0");
+    sc_rng local;
+    sch::Blake2b512Rng &rng = rng_or_null ? rng_or_null->rng : local.rng;
+    rng.feed_poly_info(p->max_mult, p->nv); // mod.rs:54
+    const uint32_t D = p->D;
+    sch::Fr vm = sch::zero();
+    bool have = false;
+    for (uint32_t i = 0; i < p->nv; ++i) {
+        uint64_t *pm = out_proof + (size_t)i * D * 4;
+        int rc = sc_prove_round(p, have ? vm.l : nullptr, pm);
+        if (rc) return rc;
+        rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(pm), D); // mod.rs:61
+        vm = rng.sample_fr();                                           // mod.rs:63
+        have = true;
+    }
+    p->randomness.push_back(vm); // mod.rs:65-67: recorded, never bound
+    return SC_OK;
+}
+
+extern "C" int sc_ml_prove(const sc_poly_desc *desc, sc_rng *rng_or_null, uint64_t *out_proof, sc_prover **out_state_or_null) {
+    if (!desc || !out_proof) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (out_state_or_null) *out_state_or_null = nullptr;
+    sc_prover *p = nullptr;
+    int rc = sc_prover_init(desc, &p); // prover_init panics on a constant before anything is proved (prover.rs:50-52)
+    if (rc) return rc;
+    rc = sc_ml_prove_handle(p, rng_or_null, out_proof);
+    if (rc) {
+        prover_destroy(p);
+        return rc;
+    }
+    if (out_state_or_null) *out_state_or_null = p;
+    else prover_destroy(p);
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// verifier side (host; O(nv * deg) scalar work) -- reference src/ml_sumcheck/protocol/verifier.rs
+// ---------------------------------------------------------------------------------------------------
+static sch::Fr interpolate(const sch::Fr *y, uint32_t len, const sch::Fr &x) {
+    // verifier.rs:139-251: value at x of the unique degree < len polynomial through (i, y[i]).
+    sch::Fr node = sch::zero();
+    for (uint32_t i = 0; i < len; ++i) { // verifier.rs:152-164: x is one of the nodes
+        if (sch::eq(x, node)) return y[i];
+        node = sch::add(node, sch::kOne);
+    }
+    // barycentric form: sum_i y_i * w_i / (x - i) * prod_j (x - j), w_i = 1 / prod_{j != i} (i - j)
+    std::vector<sch::Fr> diff(len);
+    sch::Fr full = sch::kOne;
+    for (uint32_t j = 0; j < len; ++j) {
+        diff[j] = sch::sub(x, sch::from_u64(j));
+        full = sch::mul(full, diff[j]);
+    }
+    sch::Fr acc = sch::zero();
+    for (uint32_t i = 0; i < len; ++i) {
+        sch::Fr den = diff[i];
+        for (uint32_t j = 0; j < len; ++j) {
+            if (j == i) continue;
+            const sch::Fr d = i > j ? sch::from_u64(i - j) : sch::neg(sch::from_u64(j - i));
+            den = sch::mul(den, d);
+        }
+        acc = sch::add(acc, sch::mul(sch::mul(y[i], full), sch::inverse(den)));
+    }
+    return acc;
+}
+
+extern "C" int sc_interpolate_uni_poly(const uint64_t *p_i, uint32_t len, const uint64_t *eval_at, uint64_t *out) {
+    if (!p_i || !eval_at || !out || len == 0) return fail(SC_ERR_BAD_ARG, "null argument");
+    sch::Fr x;
+    std::memcpy(&x, eval_at, 32);
+    const sch::Fr v = interpolate(reinterpret_cast<const sch::Fr *>(p_i), len, x);
+    std::memcpy(out, v.l, 32);
+    return SC_OK;
+}
+
+extern "C" int sc_ml_verify(uint32_t num_vars, uint32_t max_multiplicands, const uint64_t *claimed_sum, const uint64_t *proof,
+                            sc_rng *rng_or_null, uint64_t *out_point, uint64_t *out_expected) {
+    if (!claimed_sum || !proof || !out_point || !out_expected) return fail(SC_ERR_BAD_ARG, "null argument");
+    sc_rng local;
+    sch::Blake2b512Rng &rng = rng_or_null ? rng_or_null->rng : local.rng;
+    const uint32_t D = max_multiplicands + 1;
+    rng.feed_poly_info(max_multiplicands, num_vars); // mod.rs:90
+    const sch::Fr *msgs = reinterpret_cast<const sch::Fr *>(proof);
+    std::vector<sch::Fr> rs(num_vars);
+    for (uint32_t i = 0; i < num_vars; ++i) { // mod.rs:92-97, verify_round = store + sample (verifier.rs:54-83)
+        rng.feed_prover_msg(msgs + (size_t)i * D, D);
+        rs[i] = rng.sample_fr();
+    }
+    sch::Fr expected;
+    std::memcpy(&expected, claimed_sum, 32);
+    for (uint32_t i = 0; i < num_vars; ++i) { // check_and_generate_subclaim, verifier.rs:90-121
+        const sch::Fr *ev = msgs + (size_t)i * D;
+        if (!sch::eq(sch::add(ev[0], ev[1]), expected)) return fail(SC_ERR_REJECT, "Prover message is not consistent with the claim.");
+        expected = interpolate(ev, D, rs[i]);
+    }
+    if (num_vars) std::memcpy(out_point, rs.data(), (size_t)num_vars * 32);
+    std::memcpy(out_expected, expected.l, 32);
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// integer all-reduce lanes -> field
+// ---------------------------------------------------------------------------------------------------
+extern "C" int sc_wide_reduce(const uint64_t *wide, uint32_t n_elems, uint64_t *out) {
+    if (!wide || !out) return fail(SC_ERR_BAD_ARG, "null argument");
+    for (uint32_t e = 0; e < n_elems; ++e) {
+        // V = sum_j lane_j * 2^(32 j), lanes < 2^64  =>  V < 2^(64+224) ; keep 5 x u64
+        uint64_t v[6] = {0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < 8; ++j) {
+            const uint64_t lane = wide[8 * (size_t)e + j];
+            const int w = j >> 1, sh = (j & 1) * 32;
+            sch::u128 add = (sch::u128)lane << sh; // up to 96 bits
+            sch::u128 c = (sch::u128)v[w] + (uint64_t)add;
+            v[w] = (uint64_t)c;
+            c = (c >> 64) + (uint64_t)(add >> 64);
+            for (int q = w + 1; q < 6 && c != 0; ++q) {
+                c += v[q];
+                v[q] = (uint64_t)c;
+                c >>= 64;
+            }
+        }
+        if (v[5] != 0) return fail(SC_ERR_BAD_ARG, "wide lanes overflow");
+        // V = lo + hi * 2^256, hi < 2^64:  V mod p = (lo mod p) + hi * R   where R = 2^256 mod p = mont_mul(hi, R^2)
+        sch::Fr lo = {{v[0], v[1], v[2], v[3]}};
+        while (sch::geq_p(lo)) lo = sch::sub_p(lo); // lo < 2^256 < 3p: at most two subtractions
+        const sch::Fr hi = sch::mul(sch::Fr{{v[4], 0, 0, 0}}, sch::kR2);
+        const sch::Fr res = sch::add(lo, hi);
+        std::memcpy(out + 4 * (size_t)e, res.l, 32);
+    }
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// synthetic inputs + instrumentation
+// ---------------------------------------------------------------------------------------------------
+extern "C" int sc_synth_table_device(uint64_t seed, uint64_t stream, uint64_t first, uint64_t n, uint64_t *d_out) {
+    if (!d_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible");
+    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(scd::launch_synth(seed, stream, first, n, reinterpret_cast<uint4 *>(d_out), nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return SC_OK;
+}
+
+extern "C" int sc_bench_modmul(uint64_t n_threads, uint32_t reps, uint32_t variant, float *ms_out, uint64_t *checksum_out) {
+    if (!ms_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible");
+    HIP_TRY(hipSetDevice(g_device));
+    uint64_t *d_sink = nullptr;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipMalloc(&d_sink, 8));
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(scd::launch_bench_modmul(n_threads, 8, variant, d_sink, nullptr)); // warm-up
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    HIP_TRY(scd::launch_bench_modmul(n_threads, reps, variant, d_sink, nullptr));
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(ms_out, e0, e1));
+    if (checksum_out) HIP_TRY(hipMemcpy(checksum_out, d_sink, 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_sink);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return SC_OK;
+}

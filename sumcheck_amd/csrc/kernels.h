@@ -1,0 +1,56 @@
+// kernels.h -- host-callable launchers for the gfx950 kernels in kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scd {
+
+constexpr int kBlock = 256;    // 4 wavefronts of 64
+constexpr int kMaxFusedM = 8;  // products up to this many multiplicands run register-resident and fused with the bind
+constexpr int kMaxGrid = 2048; // 256 CUs x 8 resident 256-thread blocks; longer ranges are grid-strided
+
+struct FrHost {
+    uint64_t l[4];
+};
+
+// One distinct table of a product.  mode 0: `src` already holds this round's table (2*n_pairs entries).
+// mode 1: `src` holds the previous round's table (4*n_pairs entries); the kernel binds the previous
+// challenge on the fly, writes this round's table (2*n_pairs entries) to `dst`, and sums from registers.
+struct Slot {
+    const uint4 *src;
+    uint4 *dst;
+    uint32_t mode;
+    uint32_t exp; // multiplicity of the table inside the product (e.g. [1,4,4] -> table 4 has exp 2)
+};
+
+struct ProdArgs {
+    Slot slot[kMaxFusedM];
+    int n_slots;
+};
+
+// static per-product record for the finalize kernel (device memory)
+struct FinProd {
+    uint32_t M;           // multiplicands = degree of this product's round polynomial
+    uint32_t pad;
+    uint64_t partial_off; // offset (in field elements) of this product's partial sums
+    FrHost coeff;
+};
+
+int grid_for_pairs(uint64_t n_pairs);
+
+// product k of one round: partials[blk*(M+1)+t] = sum over this block's pairs of prod_j line_j(t), t = 0..M
+hipError_t launch_prod_round(int M, const ProdArgs &args, const FrHost &r, uint64_t n_pairs, FrHost *d_partials, int grid,
+                             hipStream_t stream);
+// generic (any M): tables already bound; slot lists in device memory
+hipError_t launch_sum_generic(const uint4 *const *d_cur_tables, const uint32_t *d_slot_table, const uint32_t *d_slot_exp,
+                              int n_slots, int M, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
+// out[b] = in[2b] + r*(in[2b+1]-in[2b]), b < n_out
+hipError_t launch_fix(const uint4 *src, uint4 *dst, const FrHost &r, uint64_t n_out, hipStream_t stream);
+// combine per-block partials of all products into the round polynomial (D evaluations)
+hipError_t launch_finalize(const FinProd *d_prods, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
+                           FrHost *d_out, uint64_t *d_out_wide, hipStream_t stream);
+hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);
+hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t n, hipStream_t stream);
+hipError_t launch_bench_modmul(uint64_t n_threads, uint32_t reps, uint32_t variant, uint64_t *d_sink, hipStream_t stream);
+
+} // namespace scd

@@ -1,0 +1,371 @@
+// kernels.hip -- gfx950 kernels of the sumcheck prover hot path.
+//
+// K2/K3/K4 of SURVEY.md 2.2: the per-round sum over the hypercube (reference
+// src/ml_sumcheck/protocol/prover.rs:110-148) fused with the previous challenge's bind
+// (prover.rs:84-89 -> DenseMultilinearExtension::fix_variables).  Integer modular arithmetic on the
+// VALU; no MFMA (this is not a dense contraction).
+//
+// Work decomposition (per product k with M multiplicands, per round with n_pairs hypercube points):
+//   lane b owns pair b: entries (2b, 2b+1) of this round's tables.  In fused mode it reads the four
+//   entries (4b..4b+3) of the previous round's table, binds r twice, stores the two new entries and
+//   keeps them in registers for the sum -- each table is read once and written once per round.
+//   Only the M+1 evaluations that determine this product's degree-M round polynomial are summed;
+//   the coefficient c_k and the extension to the message's deg+1 points are applied once per round
+//   in k_finalize (exact field arithmetic => the same canonical bits as the reference's
+//   per-point evaluation at all deg+1 points).
+//   Per-lane accumulators -> wave64 shuffle reduction -> LDS across the 4 waves -> one partial per
+//   block -> k_finalize.
+#include "fr.cuh"
+#include "kernels.h"
+
+namespace scd {
+
+__device__ __forceinline__ Fr fr_from_host(const FrHost &h) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r.v[2 * i] = (uint32_t)h.l[i];
+        r.v[2 * i + 1] = (uint32_t)(h.l[i] >> 32);
+    }
+    return r;
+}
+
+__device__ __forceinline__ Fr fr_shfl_down(const Fr &a, int off) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = __shfl_down(a.v[i], off, 64);
+    return r;
+}
+
+// Sum `acc` over the 256 threads of the block; thread 0 returns the total (others: partial garbage).
+__device__ __forceinline__ Fr block_sum(Fr acc, uint32_t (*sm)[8]) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc = fr_add(acc, fr_shfl_down(acc, off));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads(); // sm reuse across calls
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sm[wave][i] = acc.v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) {
+            Fr o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] = sm[w][i];
+            acc = fr_add(acc, o);
+        }
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: fused bind + product-sum for one product with M multiplicands (M <= kMaxFusedM)
+// ------------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const FrHost r_h, const uint64_t n_pairs,
+                                                       uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    const Fr r = fr_from_host(r_h);
+    Fr acc[M + 1];
+#pragma unroll
+    for (int t = 0; t <= M; ++t) acc[t] = fr_zero();
+
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_pairs; b += stride) {
+        Fr prod[M + 1];
+        bool first = true;
+        for (int s = 0; s < A.n_slots; ++s) {
+            Fr lo, hi;
+            if (A.slot[s].mode == 0) {
+                const uint4 *p = A.slot[s].src + 4 * b; // pair b = 64 contiguous bytes
+                lo = fr_load(p);
+                hi = fr_load(p + 2);
+            } else {
+                const uint4 *p = A.slot[s].src + 8 * b; // entries 4b..4b+3 = 128 contiguous bytes
+                const Fr e0 = fr_load(p), e1 = fr_load(p + 2), e2 = fr_load(p + 4), e3 = fr_load(p + 6);
+                lo = fr_add(e0, fr_mul(r, fr_sub(e1, e0)));
+                hi = fr_add(e2, fr_mul(r, fr_sub(e3, e2)));
+                uint4 *q = A.slot[s].dst + 4 * b;
+                fr_store(q, lo);
+                fr_store(q + 2, hi);
+            }
+            const Fr step = fr_sub(hi, lo);
+            const uint32_t e = A.slot[s].exp;
+            Fr cur = lo;
+#pragma unroll
+            for (int t = 0; t <= M; ++t) {
+                if (t == 1) cur = hi;
+                if (t >= 2) cur = fr_add(cur, step);
+                uint32_t k = 0;
+                if (first) { prod[t] = cur; k = 1; }
+                for (; k < e; ++k) prod[t] = fr_mul(prod[t], cur);
+            }
+            first = false;
+        }
+#pragma unroll
+        for (int t = 0; t <= M; ++t) acc[t] = fr_add(acc[t], prod[t]);
+    }
+#pragma unroll
+    for (int t = 0; t <= M; ++t) {
+        const Fr s = block_sum(acc[t], sm);
+        if (threadIdx.x == 0) fr_store(partials + 2 * ((uint64_t)blockIdx.x * (M + 1) + t), s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic product-sum (any number of multiplicands): grid.y = evaluation point t, tables already bound.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_sum_generic(const uint4 *const *__restrict__ cur_tables,
+                                                        const uint32_t *__restrict__ slot_table,
+                                                        const uint32_t *__restrict__ slot_exp, const int n_slots, const int M,
+                                                        const uint64_t n_pairs, uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    const uint32_t t = blockIdx.y;
+    const Fr tf = fr_from_u32(t);
+    Fr acc = fr_zero();
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_pairs; b += stride) {
+        Fr prod = fr_one();
+        for (int s = 0; s < n_slots; ++s) {
+            const uint4 *p = cur_tables[slot_table[s]] + 4 * b;
+            const Fr lo = fr_load(p), hi = fr_load(p + 2);
+            Fr val;
+            if (t == 0) val = lo;
+            else if (t == 1) val = hi;
+            else val = fr_add(lo, fr_mul(tf, fr_sub(hi, lo)));
+            for (uint32_t k = 0; k < slot_exp[s]; ++k) prod = fr_mul(prod, val);
+        }
+        acc = fr_add(acc, prod);
+    }
+    const Fr s = block_sum(acc, sm);
+    if (threadIdx.x == 0) fr_store(partials + 2 * ((uint64_t)blockIdx.x * (M + 1) + t), s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: stand-alone bind of one variable: out[b] = in[2b] + r*(in[2b+1]-in[2b])
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_fix(const uint4 *__restrict__ src, uint4 *__restrict__ dst, const FrHost r_h,
+                                                const uint64_t n_out) {
+    const Fr r = fr_from_host(r_h);
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_out; b += stride) {
+        const uint4 *p = src + 4 * b;
+        const Fr lo = fr_load(p), hi = fr_load(p + 2);
+        fr_store(dst + 2 * b, fr_add(lo, fr_mul(r, fr_sub(hi, lo))));
+    }
+}
+
+// out[i] = s * in[i]   (start_phase2_sumcheck's f3 * f2(u), reference src/gkr_round_sumcheck/mod.rs:71-75)
+__global__ __launch_bounds__(kBlock) void k_scale(const uint4 *__restrict__ src, uint4 *__restrict__ dst, const FrHost s_h,
+                                                  const uint64_t n) {
+    const Fr s = fr_from_host(s_h);
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        fr_store(dst + 2 * i, fr_mul(s, fr_load(src + 2 * i)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Finalize: per-block partials of every product -> the round's ProverMsg (D = deg+1 evaluations).
+//   phase 1  S_k[t] = sum over blocks of partial_k[blk][t]                       (t <= M_k)
+//   phase 2  extend S_k to t = M_k+1 .. D-1 by forward differences (additions only)
+//   phase 3  out[t] = sum_k c_k * S_k[t]
+// One block of 256 threads; everything here is O(K*D) field operations.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_finalize(const FinProd *__restrict__ prods, const int K, const int D, const int nblocks,
+                                                     const uint4 *__restrict__ partials, uint4 *__restrict__ scratch,
+                                                     uint4 *__restrict__ out, uint64_t *__restrict__ out_wide) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // phase 1: one wave per (k,t) combination
+    for (int combo = wave; combo < K * D; combo += kBlock / 64) {
+        const int k = combo / D, t = combo % D;
+        const int M = (int)prods[k].M;
+        if (t > M) continue;
+        const uint4 *base = partials + 2 * prods[k].partial_off;
+        Fr acc = fr_zero();
+        for (int blk = lane; blk < nblocks; blk += 64) acc = fr_add(acc, fr_load(base + 2 * ((uint64_t)blk * (M + 1) + t)));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc = fr_add(acc, fr_shfl_down(acc, off));
+        if (lane == 0) fr_store(scratch + 2 * (k * D + t), acc);
+    }
+    __syncthreads();
+    // phase 2: thread k extends product k (trailing forward differences, in place on a copy)
+    for (int k = threadIdx.x; k < K; k += kBlock) {
+        const int M = (int)prods[k].M;
+        if (M + 1 >= D) continue;
+        uint4 *S = scratch + 2 * (k * D);
+        uint4 *W = scratch + 2 * ((K + k) * D); // work area: M+1 trailing differences
+        for (int i = 0; i <= M; ++i) fr_store(W + 2 * i, fr_load(S + 2 * i));
+        for (int l = 1; l <= M; ++l)
+            for (int i = 0; i <= M - l; ++i) fr_store(W + 2 * i, fr_sub(fr_load(W + 2 * (i + 1)), fr_load(W + 2 * i)));
+        // W[M-l] = l-th difference ending at y_M; W[M] = y_M
+        for (int t = M + 1; t < D; ++t) {
+            for (int i = 1; i <= M; ++i) fr_store(W + 2 * i, fr_add(fr_load(W + 2 * i), fr_load(W + 2 * (i - 1))));
+            fr_store(S + 2 * t, fr_load(W + 2 * M));
+        }
+    }
+    __syncthreads();
+    // phase 3a: scale by the coefficient
+    for (int combo = threadIdx.x; combo < K * D; combo += kBlock) {
+        const int k = combo / D;
+        const Fr c = fr_from_host(prods[k].coeff);
+        fr_store(scratch + 2 * combo, fr_mul(c, fr_load(scratch + 2 * combo)));
+    }
+    __syncthreads();
+    // phase 3b: sum over products
+    for (int t = threadIdx.x; t < D; t += kBlock) {
+        Fr acc = fr_zero();
+        for (int k = 0; k < K; ++k) acc = fr_add(acc, fr_load(scratch + 2 * (k * D + t)));
+        if (out) fr_store(out + 2 * t, acc);
+        if (out_wide) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) out_wide[8 * t + i] = acc.v[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Synthetic uniform field elements: SplitMix64 keyed by (seed, stream, index); the same
+// specification as oracle/oracle.c:orc_synth_table and oracle/pyoracle.py:synth_mont_limbs.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(kBlock) void k_synth(const uint64_t key, const uint64_t first, const uint64_t n, uint4 *__restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t index = first + i;
+        for (uint64_t attempt = 0;; ++attempt) {
+            uint64_t l[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) l[k] = splitmix64(key ^ splitmix64(index * 4 + k + (attempt << 62)));
+            l[3] &= 0xffffffffffffffffULL >> 1;
+            // accept iff < p
+            const uint64_t P[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+            bool lt = false, decided = false;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                if (!decided && l[k] != P[k]) { lt = l[k] < P[k]; decided = true; }
+            }
+            if (lt) {
+                out[2 * i] = make_uint4((uint32_t)l[0], (uint32_t)(l[0] >> 32), (uint32_t)l[1], (uint32_t)(l[1] >> 32));
+                out[2 * i + 1] = make_uint4((uint32_t)l[2], (uint32_t)(l[2] >> 32), (uint32_t)l[3], (uint32_t)(l[3] >> 32));
+                break;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// modmul ceiling micro-kernel: a dependent chain of `reps` Montgomery products per lane, 4 independent
+// chains per lane for ILP.  variant 0: fr_mul; variant 1: fr_add chain (VALU add/sub ceiling).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_bench_modmul(const uint32_t reps, const uint32_t variant, uint64_t *__restrict__ sink) {
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    Fr x[4], y;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[c].v[i] = (uint32_t)splitmix64(gid * 64 + c * 8 + i) & (i == 7 ? 0x3fffffffu : 0xffffffffu);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y.v[i] = (uint32_t)splitmix64(~gid * 8 + i) & (i == 7 ? 0x3fffffffu : 0xffffffffu);
+    if (variant == 0) {
+        for (uint32_t k = 0; k < reps; ++k) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = fr_mul(x[c], y);
+        }
+    } else {
+        for (uint32_t k = 0; k < reps; ++k) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = fr_add(x[c], y);
+        }
+    }
+    uint64_t h = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h = h * 0x100000001B3ULL + x[c].v[i];
+    }
+    if (h == 0x1234567ULL || gid == 0) sink[0] = h; // keep the chain alive
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+int grid_for_pairs(uint64_t n_pairs) {
+    uint64_t g = (n_pairs + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)kMaxGrid) g = kMaxGrid;
+    return (int)g;
+}
+
+template <int M>
+static hipError_t launch_prod_round_t(const ProdArgs &args, const FrHost &r, uint64_t n_pairs, FrHost *d_partials, int grid,
+                                      hipStream_t stream) {
+    hipLaunchKernelGGL(k_prod_round<M>, dim3(grid), dim3(kBlock), 0, stream, args, r, n_pairs, (uint4 *)d_partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_prod_round(int M, const ProdArgs &args, const FrHost &r, uint64_t n_pairs, FrHost *d_partials, int grid,
+                             hipStream_t stream) {
+    switch (M) {
+    case 1: return launch_prod_round_t<1>(args, r, n_pairs, d_partials, grid, stream);
+    case 2: return launch_prod_round_t<2>(args, r, n_pairs, d_partials, grid, stream);
+    case 3: return launch_prod_round_t<3>(args, r, n_pairs, d_partials, grid, stream);
+    case 4: return launch_prod_round_t<4>(args, r, n_pairs, d_partials, grid, stream);
+    case 5: return launch_prod_round_t<5>(args, r, n_pairs, d_partials, grid, stream);
+    case 6: return launch_prod_round_t<6>(args, r, n_pairs, d_partials, grid, stream);
+    case 7: return launch_prod_round_t<7>(args, r, n_pairs, d_partials, grid, stream);
+    case 8: return launch_prod_round_t<8>(args, r, n_pairs, d_partials, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_sum_generic(const uint4 *const *d_cur_tables, const uint32_t *d_slot_table, const uint32_t *d_slot_exp,
+                              int n_slots, int M, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sum_generic, dim3(grid, M + 1), dim3(kBlock), 0, stream, d_cur_tables, d_slot_table, d_slot_exp, n_slots, M,
+                       n_pairs, (uint4 *)d_partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_fix(const uint4 *src, uint4 *dst, const FrHost &r, uint64_t n_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fix, dim3(grid_for_pairs(n_out)), dim3(kBlock), 0, stream, src, dst, r, n_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_scale, dim3(grid_for_pairs(n)), dim3(kBlock), 0, stream, src, dst, s, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const FinProd *d_prods, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
+                           FrHost *d_out, uint64_t *d_out_wide, hipStream_t stream) {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, stream, d_prods, K, D, nblocks, (const uint4 *)d_partials,
+                       (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream) {
+    // host-side SplitMix64 for the key (same function as on the device)
+    uint64_t x = seed ^ (stream_id * 0xD1342543DE82EF95ULL);
+    x += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    const uint64_t key = z ^ (z >> 31);
+    hipLaunchKernelGGL(k_synth, dim3(grid_for_pairs(n)), dim3(kBlock), 0, stream, key, first, n, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_bench_modmul(uint64_t n_threads, uint32_t reps, uint32_t variant, uint64_t *d_sink, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bench_modmul, dim3((unsigned)((n_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, reps, variant, d_sink);
+    return hipGetLastError();
+}
+
+} // namespace scd

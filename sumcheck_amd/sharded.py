@@ -1,0 +1,184 @@
+"""Multi-GPU sharded prover: one process per GPU, tables partitioned by the HIGH index bits.
+
+Because the protocol binds variables LSB first (reference src/ml_sumcheck/protocol/prover.rs:119-120 pairs
+entries 2b, 2b+1), a contiguous block of 2^(nv - log2 G) entries of every table is itself a table over the low
+nv - log2 G variables, and stays contiguous under every halving.  Per round each shard computes its partial
+round polynomial with the ordinary kernels; the only exchange is an integer all-reduce (RCCL over xGMI via
+torch.distributed; `gloo` on CPU) of the (deg+1) x 8 zero-extended 32-bit limbs -- 64 bytes per evaluation --
+which every rank folds back into the field identically (sc_wide_reduce), feeds to its own copy of the
+transcript and so derives the same challenge with no further communication.  When a shard is down to one
+element per table (after nv - log2 G rounds) the G elements are all-gathered and the last log2 G rounds run
+on a G-entry table on every rank.
+
+The per-shard compute engine is pluggable only so that the collective logic can be unit-tested on CPU with
+`gloo`; the product engine is HipShardEngine (libsumcheck_hip.so) and there is no default fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import field
+from ._lib import SC_TABLES_BORROW, SC_TABLES_ON_DEVICE, PolyDesc, check, lib
+from .ml_sumcheck import Blake2b512Rng, PolynomialInfo, ProverMsg
+
+
+def _log2(x: int) -> int:
+    assert x > 0 and x & (x - 1) == 0, "shard count must be a power of two"
+    return x.bit_length() - 1
+
+
+def wide_reduce(wide: np.ndarray) -> np.ndarray:
+    """(n,8) summed uint64 lanes -> (n,4) canonical Montgomery limbs (host; sc_wide_reduce)"""
+    wide = np.ascontiguousarray(wide, dtype=np.uint64).reshape(-1, 8)
+    out = np.empty((wide.shape[0], 4), dtype=np.uint64)
+    check(lib().sc_wide_reduce(C.c_void_p(wide.ctypes.data), wide.shape[0], C.c_void_p(out.ctypes.data)))
+    return out
+
+
+class HipShardEngine:
+    """One shard on one GPU: an sc_prover over the shard's local tables, driven through
+    sc_prove_round_partial / sc_prover_bind_final on torch's current stream."""
+
+    def __init__(self, nv_local: int, shapes: Sequence[Sequence[int]], coeffs: np.ndarray, tables, device, borrow: bool = True):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        self.nv = nv_local
+        self.U = len(tables)
+        self.D = max(len(s) for s in shapes) + 1
+        self._tables = []
+        for t in tables:
+            if not isinstance(t, torch.Tensor):
+                t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.uint64).view(np.int64))
+            self._tables.append(t.to(self.device).contiguous())
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        offs, idx = [0], []
+        for s in shapes:
+            idx.extend(int(i) for i in s)
+            offs.append(len(idx))
+        offsets = np.asarray(offs, dtype=np.uint32)
+        indices = np.asarray(idx, dtype=np.uint32)
+        tabs = (C.c_void_p * self.U)(*[t.data_ptr() for t in self._tables])
+        d = PolyDesc()
+        d.num_vars, d.max_multiplicands, d.n_products = nv_local, self.D - 1, len(shapes)
+        d.coeffs = coeffs.ctypes.data_as(C.POINTER(C.c_uint64))
+        d.prod_offsets = offsets.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.prod_indices = indices.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.n_tables = self.U
+        d.tables = C.cast(tabs, C.POINTER(C.c_void_p))
+        d.flags = SC_TABLES_ON_DEVICE | (SC_TABLES_BORROW if borrow else 0)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().sc_set_device(self.device.index or 0))
+            check(lib().sc_prover_init(C.byref(d), C.byref(self._h)))
+            check(lib().sc_prover_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def round_partial(self, r: Optional[np.ndarray]):
+        """-> (D,8) int64 tensor on the GPU: zero-extended 32-bit limbs of this shard's partial evaluations"""
+        out = self.torch.empty((self.D, 8), dtype=self.torch.int64, device=self.device)
+        rp = C.c_void_p(np.ascontiguousarray(r, dtype=np.uint64).ctypes.data) if r is not None else None
+        check(lib().sc_prove_round_partial(self._h, rp, C.c_void_p(out.data_ptr())))
+        return out
+
+    def bind_final(self, r: np.ndarray):
+        """-> (U,4) int64 tensor: the single remaining element of every local table"""
+        out = self.torch.empty((self.U, 4), dtype=self.torch.int64, device=self.device)
+        check(lib().sc_prover_bind_final(self._h, C.c_void_p(np.ascontiguousarray(r, dtype=np.uint64).ctypes.data),
+                                         C.c_void_p(out.data_ptr())))
+        return out
+
+    def reset(self):
+        """rewind to round 0 over the same resident shard (borrowing handles only)"""
+        check(lib().sc_prover_reset(self._h, None, 0))
+
+    def close(self):
+        if self._h:
+            self.torch.cuda.synchronize(self.device)
+            lib().sc_prover_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DistComm:
+    """torch.distributed world ("nccl" = RCCL on ROCm, "gloo" on CPU)"""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+
+    def all_reduce_sum(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
+    def all_gather(self, t):
+        import torch
+        if self.world == 1:
+            return t.unsqueeze(0)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return torch.stack(out)
+
+
+def prove_sharded(engines: Sequence, comm: DistComm, nv_total: int, max_multiplicands: int, tail_factory,
+                  fs_rng: Optional[Blake2b512Rng] = None):
+    """MLSumcheck::prove_as_subprotocol (reference src/ml_sumcheck/mod.rs:50-70) over G = len(engines) * comm.world
+    shards.  `engines` are this process's shards in increasing global order (normally exactly one per GPU).
+    tail_factory(nv_tail, tables[(U, G, 4) int64 tensor]) builds the engine for the last log2 G rounds.
+    Returns (proof (nv, D, 4) uint64, randomness (nv, 4) uint64); identical on every rank."""
+    import torch
+    L = len(engines)
+    G = L * comm.world
+    k = _log2(G)
+    nv_local = nv_total - k
+    assert nv_local >= 1, "each shard needs at least two entries per table"
+    rng = fs_rng or Blake2b512Rng.setup()
+    rng.feed(PolynomialInfo(max_multiplicands, nv_total))  # mod.rs:54
+    D = max_multiplicands + 1
+    proof = np.empty((nv_total, D, 4), dtype=np.uint64)
+    rand = np.empty((nv_total, 4), dtype=np.uint64)
+    r = None
+    for i in range(nv_local):
+        wide = engines[0].round_partial(r)
+        for e in engines[1:]:
+            wide = wide + e.round_partial(r)
+        wide = comm.all_reduce_sum(wide)
+        evals = wide_reduce(wide.cpu().numpy().view(np.uint64))
+        proof[i] = evals
+        rng.feed(ProverMsg(evals))  # mod.rs:61
+        r = rng.sample_fr()         # mod.rs:63
+        rand[i] = r
+    if k > 0:
+        local = torch.stack([e.bind_final(r) for e in engines])        # (L, U, 4)
+        allsh = comm.all_gather(local)                                  # (world, L, U, 4)
+        U = local.shape[1]
+        tables = allsh.reshape(G, U, 4).permute(1, 0, 2).contiguous()   # (U, G, 4): entry g of table u came from shard g
+        tail = tail_factory(k, tables)
+        rt = None
+        for j in range(k):
+            evals = wide_reduce(tail.round_partial(rt).cpu().numpy().view(np.uint64))
+            proof[nv_local + j] = evals
+            rng.feed(ProverMsg(evals))
+            rt = rng.sample_fr()
+            rand[nv_local + j] = rt
+    return proof, rand
+
+
+def prove_logical_shards(nv: int, shapes, tables: Sequence[np.ndarray], coeffs: np.ndarray, G: int, device):
+    """Single-process, single-GPU run of the sharded protocol with G logical shards (tests / debugging)."""
+    k = _log2(G)
+    n_loc = 1 << (nv - k)
+    engines = [HipShardEngine(nv - k, shapes, coeffs, [t[g * n_loc:(g + 1) * n_loc] for t in tables], device, borrow=True)
+               for g in range(G)]
+    tail_factory = lambda nvt, tabs: HipShardEngine(nvt, shapes, coeffs, [tabs[u] for u in range(tabs.shape[0])], device, borrow=False)
+    return prove_sharded(engines, DistComm(), nv, max(len(s) for s in shapes), tail_factory)

@@ -1,0 +1,156 @@
+"""CPU tests of the product's host side (no GPU, no compute calls): the C-ABI library loads and exports every
+symbol include/sumcheck_hip.h declares, and the host-only entry points (transcript, verifier, lane folding)
+agree with the oracle / golden vectors.  Compute entry points must fail loudly without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sumcheck_amd as sc
+from oracle import cref
+from oracle import pyoracle as po
+from sumcheck_amd import _lib, field
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "sumcheck_hip.h")).read()
+    declared = re.findall(r"SC_API\s+[\w\s\*]+?\b(sc_\w+)\s*\(", hdr)
+    assert len(declared) >= 30
+    L = C.CDLL(_lib.SO_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/sumcheck_hip.h but not exported"
+    assert set(declared) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
+    assert sc.lib().sc_abi_version() == 1
+
+
+def test_transcript_matches_golden():
+    g = H.load("transcript.json")
+    r = sc.Blake2b512Rng.setup()
+    for op in g["ops"]:
+        if op[0] == "feed":
+            r.feed(bytes.fromhex(op[1]))
+        elif op[0] == "fill":
+            assert r.fill_bytes(op[1]).hex() == op[2]
+        else:
+            assert field.to_int(r.sample_fr()) == H.hx(op[1])
+    s = g["structured"]
+    r = sc.Blake2b512Rng.setup()
+    r.feed(sc.PolynomialInfo(*s["info"]))
+    r.feed(sc.ProverMsg(H.mont(s["msg"])))
+    assert field.to_int(r.sample_fr()) == H.hx(s["sample"])
+    assert r.fill_bytes(64).hex() == s["next64"]
+
+
+def test_transcript_determinism_like_reference():
+    # shape of reference src/rng.rs:110-169 (feed / F::rand interleavings incl. unaligned 127/777-byte squeezes)
+    rng = np.random.default_rng(5)
+    msgs = [rng.bytes(128) for _ in range(7)]
+
+    def run(mk, feed, fill, sample):
+        r = mk()
+        o = []
+        feed(r, msgs[0]); o += [sample(r), sample(r)]
+        feed(r, msgs[1]); feed(r, msgs[2]); o.append(sample(r))
+        feed(r, msgs[3]); o += [sample(r), sample(r)]
+        for m in msgs[4:]:
+            feed(r, m)
+        f1, f2 = sample(r), sample(r)
+        assert f1 != f2
+        b1 = fill(r, 127); feed(r, b1)
+        b2 = fill(r, 128); b3 = fill(r, 777)
+        assert b2[:64] != b3[:64]
+        o.append(sample(r)); feed(r, b3); o.append(sample(r))
+        return o + [f1, f2]
+
+    a = run(sc.Blake2b512Rng.setup, lambda r, m: r.feed(m), lambda r, n: r.fill_bytes(n), lambda r: field.to_int(r.sample_fr()))
+    b = run(sc.Blake2b512Rng.setup, lambda r, m: r.feed(m), lambda r, n: r.fill_bytes(n), lambda r: field.to_int(r.sample_fr()))
+    c = run(po.Blake2b512Rng, lambda r, m: r.feed_bytes(m), lambda r, n: r.fill_bytes(n), po.sample_fr)
+    assert a == b == c
+
+
+@pytest.mark.parametrize("name", H.ml_cases())
+def test_verifier_accepts_golden_proofs(name):
+    case = H.load(name)
+    proof = [sc.ProverMsg(H.mont(r)) for r in case["fs_proof"]]
+    info = sc.PolynomialInfo(max(len(s) for s in case["shapes"]), case["nv"])
+    sub = sc.MLSumcheck.verify(info, H.mont([case["sum"]])[0], proof)
+    assert field.to_ints(sub.point) == [H.hx(x) for x in case["fs_randomness"]]
+    assert field.to_int(sub.expected_evaluation) == H.hx(case["subclaim_expected"])
+    assert field.to_int(sc.MLSumcheck.extract_sum(proof)) == H.hx(case["sum"])
+    with pytest.raises(sc.SumcheckError, match="Prover message is not consistent with the claim"):
+        sc.MLSumcheck.verify(info, field.from_int(H.hx(case["sum"]) + 1), proof)
+    # different transcripts fail (reference test.rs:168-186)
+    pr, vr = sc.Blake2b512Rng.setup(), sc.Blake2b512Rng.setup()
+    pr.feed(b"Test Trivial Works"); vr.feed(b"Test Trivial Fails")
+    if case["nv"] > 1:
+        with pytest.raises(sc.SumcheckError):
+            sc.MLSumcheck.verify_as_subprotocol(vr, info, H.mont([case["sum"]])[0], proof)
+
+
+def test_interpolate_uni_poly():
+    assert field.to_int(sc.interpolate_uni_poly(field.from_ints([0, 1, 4, 9]), field.from_int(3))) == 9  # verifier.rs:327-331
+    rng = np.random.default_rng(4)
+    for n in (2, 5, 13, 20, 21, 33, 34, 40):  # the reference's three tiers switch at 20 and 33 points
+        coef = [int.from_bytes(rng.bytes(32), "little") % po.P for _ in range(n)]
+        f = lambda x: sum(c * pow(x, i, po.P) for i, c in enumerate(coef)) % po.P
+        ys = [f(i) for i in range(n)]
+        x = int.from_bytes(rng.bytes(32), "little") % po.P
+        assert field.to_int(sc.interpolate_uni_poly(field.from_ints(ys), field.from_int(x))) == f(x)
+        assert field.to_int(sc.interpolate_uni_poly(field.from_ints(ys), field.from_int(n - 1))) == ys[n - 1]
+
+
+def test_wide_reduce_folds_integer_allreduce_lanes():
+    rng = np.random.default_rng(6)
+    for ranks in (1, 2, 8, 1000):
+        elems = [[int.from_bytes(rng.bytes(32), "little") % po.P for _ in range(ranks)] for _ in range(5)]
+        wide = np.zeros((5, 8), dtype=np.uint64)
+        for e in range(5):
+            for v in elems[e]:
+                m = v * po.R % po.P  # Montgomery representation, split into 32-bit limbs, lanes summed as integers
+                for j in range(8):
+                    wide[e, j] += np.uint64((m >> (32 * j)) & 0xFFFFFFFF)
+        out = np.empty((5, 4), dtype=np.uint64)
+        _lib.check(sc.lib().sc_wide_reduce(C.c_void_p(wide.ctypes.data), 5, C.c_void_p(out.ctypes.data)))
+        assert field.to_ints(out) == [sum(e) % po.P for e in elems]
+
+
+def test_compute_calls_fail_loudly_without_a_device():
+    if sc.lib().sc_device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    case = H.load("ml_nv3_c1shape.json")
+    poly, _ = H.hip_poly(case)
+    with pytest.raises(sc.SumcheckError) as e:
+        sc.IPForMLSumcheck.prover_init(poly)
+    assert e.value.code == _lib.SC_ERR_HIP and "no CPU fallback" in e.value.msg
+    with pytest.raises(sc.SumcheckError):
+        sc.MLSumcheck.prove(poly)
+    with pytest.raises(sc.SumcheckError):
+        poly.flattened_ml_extensions[0].fix_variables(field.from_ints([5]))
+
+
+def test_argument_validation_matches_reference_asserts():
+    # data_structures.rs:78 (empty product), :81-84 (wrong num_vars), prover.rs:50-52 (constant)
+    poly = sc.ListOfProductsOfPolynomials.new(2)
+    t2 = sc.DenseMultilinearExtension(2, np.zeros((4, 4), np.uint64))
+    t3 = sc.DenseMultilinearExtension(3, np.zeros((8, 4), np.uint64))
+    with pytest.raises(AssertionError):
+        poly.add_product([], field.ONE)
+    with pytest.raises(AssertionError, match="wrong number of variables"):
+        poly.add_product([t2, t3], field.ONE)
+    p0 = sc.ListOfProductsOfPolynomials.new(0)
+    p0.add_product([sc.DenseMultilinearExtension(0, np.zeros((1, 4), np.uint64))], field.ONE)
+    with pytest.raises(sc.SumcheckError, match="Attempt to prove a constant"):
+        sc.IPForMLSumcheck.prover_init(p0)
+    with pytest.raises(sc.SumcheckError, match="Attempt to prove a constant"):
+        sc.MLSumcheck.prove(p0)
+    # shared references are stored once (reference test.rs:254)
+    p = sc.ListOfProductsOfPolynomials.new(2)
+    ts = [sc.DenseMultilinearExtension(2, np.zeros((4, 4), np.uint64)) for _ in range(5)]
+    for sh in ([2, 3, 0], [1, 4, 4], [3, 2, 1], [0, 0], [4]):
+        p.add_product([ts[i] for i in sh], field.ONE)
+    assert len(p.flattened_ml_extensions) == 5 and p.max_multiplicands == 3
