@@ -560,7 +560,7 @@ void orc_synth_table(uint64_t seed, uint64_t stream, uint64_t first, uint64_t n,
         uint64_t index = first + i;
         for (uint64_t attempt = 0;; ++attempt) {
             fr_t a;
-            for (int k = 0; k < 4; ++k) a.l[k] = splitmix64(key ^ splitmix64(index * 4 + k + (attempt << 62)));
+            for (int k = 0; k < 4; ++k) a.l[k] = splitmix64(key ^ (splitmix64(index * 4 + k) + attempt * 0x9E3779B97F4A7C15ULL));
             a.l[3] &= 0xffffffffffffffffULL >> 1;
             if (!fr_geq_p(&a)) { ((fr_t *)out)[i] = a; break; }
         }

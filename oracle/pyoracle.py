@@ -467,8 +467,8 @@ def _splitmix64(x: int) -> int:
 
 def synth_mont_limbs(seed: int, stream: int, index: int) -> Tuple[int, int, int, int]:
     """The synthetic table generator shared (by specification, not by code) with the HIP
-    generator kernel and oracle.c: limb k of attempt a is
-    splitmix64(splitmix64(seed ^ stream*C1) ^ (index*8 + a*4... see body)); top bit cleared;
+    generator kernel and oracle.c: key = splitmix64(seed ^ stream*0xD1342543DE82EF95); limb k of attempt a is
+    splitmix64(key ^ (splitmix64(4*index + k) + a*0x9E3779B97F4A7C15)); top bit cleared;
     first attempt with value < P wins.  Limbs are taken directly as Montgomery form, the same
     shape as ark-ff's sampler."""
     key = _splitmix64((seed ^ (stream * 0xD1342543DE82EF95)) & MASK64)
@@ -476,8 +476,8 @@ def synth_mont_limbs(seed: int, stream: int, index: int) -> Tuple[int, int, int,
     while True:
         limbs = []
         for k in range(4):
-            ctr = (index * 4 + k + (attempt << 62)) & MASK64
-            limbs.append(_splitmix64(key ^ _splitmix64(ctr)))
+            x = (_splitmix64((index * 4 + k) & MASK64) + attempt * 0x9E3779B97F4A7C15) & MASK64
+            limbs.append(_splitmix64(key ^ x))
         limbs[3] &= MASK64 >> 1
         m = sum(limbs[i] << (64 * i) for i in range(4))
         if m < P:

@@ -240,10 +240,10 @@ __global__ __launch_bounds__(kBlock) void k_synth(const uint64_t key, const uint
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const uint64_t index = first + i;
-        for (uint64_t attempt = 0;; ++attempt) {
+        for (uint64_t attempt = 0; attempt < 64; ++attempt) { // P(reject) = 0.094 per attempt
             uint64_t l[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) l[k] = splitmix64(key ^ splitmix64(index * 4 + k + (attempt << 62)));
+            for (int k = 0; k < 4; ++k) l[k] = splitmix64(key ^ (splitmix64(index * 4 + k) + attempt * 0x9E3779B97F4A7C15ULL));
             l[3] &= 0xffffffffffffffffULL >> 1;
             // accept iff < p
             const uint64_t P[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
