@@ -60,11 +60,11 @@ def cpu_baseline(shapes, n_tables, budget_s=15.0):
         cref.ml_prove(d, threads=threads)
         return time.perf_counter() - t0
 
-    nv = 16
+    nv = 18
     t = run(nv)
     rate = field_ops(nv, shapes, n_tables) / t
     nv_big = nv
-    while nv_big < 22 and field_ops(nv_big + 1, shapes, n_tables) / rate < budget_s:
+    while nv_big < 24 and field_ops(nv_big + 1, shapes, n_tables) / rate < budget_s:
         nv_big += 1
     if nv_big > nv:
         t = run(nv_big)

@@ -92,8 +92,10 @@ SC_API int sc_prover_push_randomness(sc_prover *p, const uint64_t *r);
  * *round, *n_randomness may be NULL. */
 SC_API int sc_prover_state(sc_prover *p, uint64_t *randomness, uint32_t *n_randomness, uint64_t *tables_out, uint32_t *round);
 SC_API void sc_prover_free(sc_prover *p);
-/* Run the handle's kernels on a caller stream (a hipStream_t cast to void*; NULL = the handle's own). */
-SC_API int sc_prover_set_stream(sc_prover *p, void *hip_stream);
+/* Run the handle's kernels on a caller stream (a hipStream_t cast to void*; NULL is the legacy default stream,
+ * which is what torch.cuda.current_stream().cuda_stream is unless a side stream is active), or -- use_own != 0 --
+ * back on the handle's own non-blocking stream. */
+SC_API int sc_prover_set_stream(sc_prover *p, void *hip_stream, int use_own);
 
 /* Sharded use: this handle holds one contiguous high-bit shard of every table.
  * sc_prove_round_partial = prove_round on the shard, result left ON THE DEVICE as (deg+1) x 8 uint64

@@ -55,7 +55,7 @@ SIGNATURES = {
     "sc_prover_push_randomness": (C.c_int, [_V, _V]),
     "sc_prover_state": (C.c_int, [_V, _V, u32p, _V, u32p]),
     "sc_prover_free": (None, [_V]),
-    "sc_prover_set_stream": (C.c_int, [_V, _V]),
+    "sc_prover_set_stream": (C.c_int, [_V, _V, C.c_int]),
     "sc_prove_round_partial": (C.c_int, [_V, _V, _V]),
     "sc_wide_reduce": (C.c_int, [_V, C.c_uint32, _V]),
     "sc_prover_bind_final": (C.c_int, [_V, _V, _V]),

@@ -287,10 +287,11 @@ extern "C" int sc_prover_init(const sc_poly_desc *desc, sc_prover **out) {
     return SC_OK;
 }
 
-extern "C" int sc_prover_set_stream(sc_prover *p, void *hip_stream) {
+extern "C" int sc_prover_set_stream(sc_prover *p, void *hip_stream, int use_own) {
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    p->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : p->own_stream;
+    p->stream = use_own ? p->own_stream : static_cast<hipStream_t>(hip_stream); // NULL = the legacy default stream
     return SC_OK;
 }
 

@@ -74,7 +74,7 @@ class HipShardEngine:
         with torch.cuda.device(self.device):
             check(lib().sc_set_device(self.device.index or 0))
             check(lib().sc_prover_init(C.byref(d), C.byref(self._h)))
-            check(lib().sc_prover_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+            check(lib().sc_prover_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), 0))
 
     def round_partial(self, r: Optional[np.ndarray]):
         """-> (D,8) int64 tensor on the GPU: zero-extended 32-bit limbs of this shard's partial evaluations"""
