@@ -167,7 +167,11 @@ SC_API int sc_prover_get_timing(sc_prover *p, double *ms_per_product, uint64_t *
  * tables_or_null = new device pointers, or NULL for the same tables.  Copying handle: tables are required and
  * copied in again (device pointers iff flags has SC_TABLES_ON_DEVICE). */
 SC_API int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_null, uint32_t flags);
-/* Elementwise micro-kernel: out[i] = a[i]*b[i] repeated `reps` times in registers (modmul ceiling). */
+/* Elementwise field arithmetic on host arrays of n elements, computed on the GPU (arithmetic parity tests):
+ * op 0 mul (production path) | 1 add | 2 sub | 3 mul, plain-C++ CIOS | 4 mul, Comba asm | 5 a[i] * b[0] with b[0] uniform. */
+SC_API int sc_fr_elementwise(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n);
+/* Elementwise micro-kernel: dependent chains of `reps` field ops per lane, 4 chains per lane (ceilings):
+ * variant 0 mul CIOS | 1 add | 2 mul Comba | 3 mul Comba by a uniform operand. */
 SC_API int sc_bench_modmul(uint64_t n_threads, uint32_t reps, uint32_t variant, float *ms_out, uint64_t *checksum_out);
 
 #ifdef __cplusplus

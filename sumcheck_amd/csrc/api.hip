@@ -777,6 +777,28 @@ extern "C" int sc_synth_table_device(uint64_t seed, uint64_t stream, uint64_t fi
     return SC_OK;
 }
 
+extern "C" int sc_fr_elementwise(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n) {
+    if (!a || !b || !out) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (op < 0 || op > 5) return fail(SC_ERR_BAD_ARG, "unknown op %d", op);
+    if (n == 0) return SC_OK;
+    if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    HIP_TRY(hipSetDevice(g_device));
+    void *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&da, n * 32));
+    HIP_TRY(hipMalloc(&db, n * 32));
+    HIP_TRY(hipMalloc(&dout, n * 32));
+    HIP_TRY(hipMemcpy(da, a, n * 32, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b, n * 32, hipMemcpyHostToDevice));
+    FrHost u;
+    std::memcpy(&u, b, 32); // op 5 multiplies every a[i] by the uniform element b[0]
+    HIP_TRY(scd::launch_fr_elementwise(op, static_cast<const uint4 *>(da), static_cast<const uint4 *>(db), u, static_cast<uint4 *>(dout), n, nullptr));
+    HIP_TRY(hipMemcpy(out, dout, n * 32, hipMemcpyDeviceToHost));
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dout);
+    return SC_OK;
+}
+
 extern "C" int sc_bench_modmul(uint64_t n_threads, uint32_t reps, uint32_t variant, float *ms_out, uint64_t *checksum_out) {
     if (!ms_out) return fail(SC_ERR_BAD_ARG, "null argument");
     if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible");

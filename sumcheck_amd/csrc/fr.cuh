@@ -103,8 +103,10 @@ __device__ __forceinline__ Fr fr_sub(const Fr &a, const Fr &b) {
     return r;
 }
 
-// Montgomery product a*b*R^-1 mod p, canonical output.  Interleaved (CIOS) form, 32-bit limbs.
-__device__ __forceinline__ Fr fr_mul(const Fr &a, const Fr &b) {
+// Montgomery product a*b*R^-1 mod p, canonical output.  Interleaved (CIOS) form, 32-bit limbs, plain C++:
+// the compiler's rendering spends ~3 v_mov + one 64-bit add per v_mad_u64_u32 (kept as the cross-check
+// implementation; the production product is fr_mul_comba below).
+__device__ __forceinline__ Fr fr_mul_cios(const Fr &a, const Fr &b) {
     uint32_t t[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = 0;
@@ -134,6 +136,36 @@ __device__ __forceinline__ Fr fr_mul(const Fr &a, const Fr &b) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = t[i];
     return fr_reduce_once(r);
+}
+
+// A wave-uniform element (e.g. the round challenge, a kernel argument): limbs live in SGPRs.
+struct FrU {
+    uint32_t v[8];
+};
+
+#include "fr_mac.inc"
+#include "fr_mul_gen.inc"
+
+#ifndef SC_MUL_IMPL
+#define SC_MUL_IMPL 1
+#endif
+__device__ __forceinline__ Fr fr_mul(const Fr &a, const Fr &b) {
+#if SC_MUL_IMPL == 0
+    return fr_mul_cios(a, b);
+#else
+    return fr_mul_comba(a, b);
+#endif
+}
+// a * u with u wave-uniform
+__device__ __forceinline__ Fr fr_mul_u(const Fr &a, const FrU &u) {
+#if SC_MUL_IMPL == 0
+    Fr b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b.v[i] = u.v[i];
+    return fr_mul_cios(a, b);
+#else
+    return fr_mul_comba_u(a, u);
+#endif
 }
 
 // small integer -> Montgomery form

@@ -51,6 +51,7 @@ hipError_t launch_finalize(const FinProd *d_prods, int K, int D, int nblocks, co
                            FrHost *d_out, uint64_t *d_out_wide, hipStream_t stream);
 hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);
 hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t n, hipStream_t stream);
+hipError_t launch_fr_elementwise(int op, const uint4 *a, const uint4 *b, const FrHost &u, uint4 *out, uint64_t n, hipStream_t stream);
 hipError_t launch_bench_modmul(uint64_t n_threads, uint32_t reps, uint32_t variant, uint64_t *d_sink, hipStream_t stream);
 
 } // namespace scd

@@ -30,6 +30,16 @@ __device__ __forceinline__ Fr fr_from_host(const FrHost &h) {
     return r;
 }
 
+__device__ __forceinline__ FrU fru_from_host(const FrHost &h) {
+    FrU r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r.v[2 * i] = (uint32_t)h.l[i];
+        r.v[2 * i + 1] = (uint32_t)(h.l[i] >> 32);
+    }
+    return r;
+}
+
 __device__ __forceinline__ Fr fr_shfl_down(const Fr &a, int off) {
     Fr r;
 #pragma unroll
@@ -67,7 +77,7 @@ template <int M>
 __global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const FrHost r_h, const uint64_t n_pairs,
                                                        uint4 *__restrict__ partials) {
     __shared__ uint32_t sm[kBlock / 64][8];
-    const Fr r = fr_from_host(r_h);
+    const FrU r = fru_from_host(r_h); // the challenge is a kernel argument: its limbs stay in SGPRs
     Fr acc[M + 1];
 #pragma unroll
     for (int t = 0; t <= M; ++t) acc[t] = fr_zero();
@@ -85,8 +95,8 @@ __global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const F
             } else {
                 const uint4 *p = A.slot[s].src + 8 * b; // entries 4b..4b+3 = 128 contiguous bytes
                 const Fr e0 = fr_load(p), e1 = fr_load(p + 2), e2 = fr_load(p + 4), e3 = fr_load(p + 6);
-                lo = fr_add(e0, fr_mul(r, fr_sub(e1, e0)));
-                hi = fr_add(e2, fr_mul(r, fr_sub(e3, e2)));
+                lo = fr_add(e0, fr_mul_u(fr_sub(e1, e0), r));
+                hi = fr_add(e2, fr_mul_u(fr_sub(e3, e2), r));
                 uint4 *q = A.slot[s].dst + 4 * b;
                 fr_store(q, lo);
                 fr_store(q + 2, hi);
@@ -148,22 +158,22 @@ __global__ __launch_bounds__(kBlock) void k_sum_generic(const uint4 *const *__re
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_fix(const uint4 *__restrict__ src, uint4 *__restrict__ dst, const FrHost r_h,
                                                 const uint64_t n_out) {
-    const Fr r = fr_from_host(r_h);
+    const FrU r = fru_from_host(r_h);
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_out; b += stride) {
         const uint4 *p = src + 4 * b;
         const Fr lo = fr_load(p), hi = fr_load(p + 2);
-        fr_store(dst + 2 * b, fr_add(lo, fr_mul(r, fr_sub(hi, lo))));
+        fr_store(dst + 2 * b, fr_add(lo, fr_mul_u(fr_sub(hi, lo), r)));
     }
 }
 
 // out[i] = s * in[i]   (start_phase2_sumcheck's f3 * f2(u), reference src/gkr_round_sumcheck/mod.rs:71-75)
 __global__ __launch_bounds__(kBlock) void k_scale(const uint4 *__restrict__ src, uint4 *__restrict__ dst, const FrHost s_h,
                                                   const uint64_t n) {
-    const Fr s = fr_from_host(s_h);
+    const FrU s = fru_from_host(s_h);
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
-        fr_store(dst + 2 * i, fr_mul(s, fr_load(src + 2 * i)));
+        fr_store(dst + 2 * i, fr_mul_u(fr_load(src + 2 * i), s));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -278,7 +288,20 @@ __global__ __launch_bounds__(kBlock) void k_bench_modmul(const uint32_t reps, co
     if (variant == 0) {
         for (uint32_t k = 0; k < reps; ++k) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) x[c] = fr_mul(x[c], y);
+            for (int c = 0; c < 4; ++c) x[c] = fr_mul_cios(x[c], y);
+        }
+    } else if (variant == 2) {
+        for (uint32_t k = 0; k < reps; ++k) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = fr_mul_comba(x[c], y);
+        }
+    } else if (variant == 3) {
+        FrU u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u.v[i] = __builtin_amdgcn_readfirstlane(y.v[i]);
+        for (uint32_t k = 0; k < reps; ++k) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = fr_mul_comba_u(x[c], u);
         }
     } else {
         for (uint32_t k = 0; k < reps; ++k) {
@@ -293,6 +316,29 @@ __global__ __launch_bounds__(kBlock) void k_bench_modmul(const uint32_t reps, co
         for (int i = 0; i < 8; ++i) h = h * 0x100000001B3ULL + x[c].v[i];
     }
     if (h == 0x1234567ULL || gid == 0) sink[0] = h; // keep the chain alive
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise field ops on arrays (parity tests of the arithmetic itself, every implementation)
+//   op 0 mul (production) | 1 add | 2 sub | 3 mul CIOS (plain C++) | 4 mul Comba (asm) | 5 mul by uniform u
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_fr_elementwise(const int op, const uint4 *__restrict__ a, const uint4 *__restrict__ b,
+                                                           const FrHost u_h, uint4 *__restrict__ out, const uint64_t n) {
+    const FrU u = fru_from_host(u_h);
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const Fr x = fr_load(a + 2 * i), y = fr_load(b + 2 * i);
+        Fr z;
+        switch (op) {
+        case 0: z = fr_mul(x, y); break;
+        case 1: z = fr_add(x, y); break;
+        case 2: z = fr_sub(x, y); break;
+        case 3: z = fr_mul_cios(x, y); break;
+        case 4: z = fr_mul_comba(x, y); break;
+        default: z = fr_mul_comba_u(x, u); break;
+        }
+        fr_store(out + 2 * i, z);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -360,6 +406,11 @@ hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint6
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     const uint64_t key = z ^ (z >> 31);
     hipLaunchKernelGGL(k_synth, dim3(grid_for_pairs(n)), dim3(kBlock), 0, stream, key, first, n, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_fr_elementwise(int op, const uint4 *a, const uint4 *b, const FrHost &u, uint4 *out, uint64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fr_elementwise, dim3(grid_for_pairs(n)), dim3(kBlock), 0, stream, op, a, b, u, out, n);
     return hipGetLastError();
 }
 

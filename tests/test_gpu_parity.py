@@ -24,6 +24,37 @@ def _torch_dev():
     return torch.device("cuda:0")
 
 
+@pytest.mark.parametrize("op,name", [(0, "mul"), (1, "add"), (2, "sub"), (3, "mul"), (4, "mul"), (5, "mulu")])
+def test_field_arithmetic_every_implementation(op, name):
+    """each device implementation of Fr mul/add/sub against the oracle on edge values and 100k random pairs"""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(op)
+    edge = [0, 1, 2, po.P - 1, po.P - 2, (po.P - 1) // 2, (po.P + 1) // 2, po.R, po.R2, (1 << 255) % po.P, 0xFFFFFFFF, 1 << 32,
+            (1 << 64) - 1, 1 << 64, po.P - (1 << 32), po.P - (1 << 224)]
+    ea = cref.ints_to_mont([x for x in edge for _ in edge])
+    eb = cref.ints_to_mont([y for _ in edge for y in edge])
+    n = 100_000
+    a = np.concatenate([ea, cref.synth_table(1, 2 * op, n)])
+    b = np.concatenate([eb, cref.synth_table(1, 2 * op + 1, n)])
+    if name == "mulu":
+        b = np.repeat(b[len(edge) * 3 + 5][None, :], a.shape[0], axis=0)  # uniform operand
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    out = np.empty_like(a)
+    _lib.check(sc.lib().sc_fr_elementwise(op, C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(out.ctypes.data), a.shape[0]))
+    # oracle: canonical residues via python ints on a sample + the C oracle on everything
+    want = np.empty_like(a)
+    fn = {"mul": "mul", "mulu": "mul", "add": "add", "sub": "sub"}[name]
+    L = cref.lib()
+    f = getattr(L, "orc_fr_" + fn)
+    u64p = C.POINTER(C.c_uint64)
+    for i in range(a.shape[0]):
+        f(a[i].ctypes.data_as(u64p), b[i].ctypes.data_as(u64p), want[i].ctypes.data_as(u64p))
+    assert np.array_equal(out, want)
+    ai, bi, oi = cref.mont_to_ints(a[:300]), cref.mont_to_ints(b[:300]), cref.mont_to_ints(out[:300])
+    pyf = {"mul": lambda x, y: x * y % po.P, "add": lambda x, y: (x + y) % po.P, "sub": lambda x, y: (x - y) % po.P}[fn]
+    assert oi == [pyf(x, y) for x, y in zip(ai, bi)]
+
+
 def _interactive(poly, challenges, borrow=False):
     st = sc.IPForMLSumcheck.prover_init(poly, borrow=borrow)
     msgs, v = [], None

@@ -9,10 +9,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sumcheck_amd as sc
 from sumcheck_amd import _lib
 
-for variant, name in ((0, "fr_mul"), (1, "fr_add")):
-    for blocks_per_cu in (4, 8, 16):
+for variant, name in ((0, "fr_mul_cios"), (2, "fr_mul_comba"), (3, "fr_mul_comba_uniform"), (1, "fr_add")):
+    for blocks_per_cu in (8, 16):
         n_threads = 256 * 256 * blocks_per_cu
-        reps = 2000 if variant == 0 else 20000
+        reps = 2000 if variant != 1 else 20000
         ms = C.c_float()
         chk = C.c_uint64()
         _lib.check(sc.lib().sc_bench_modmul(n_threads, reps, variant, C.byref(ms), C.byref(chk)))
