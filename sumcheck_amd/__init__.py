@@ -6,3 +6,5 @@ this package is the thin host-side mirror of the reference's public interface.
 from ._lib import SumcheckError, lib  # noqa: F401
 from .ml_sumcheck import (Blake2b512Rng, DenseMultilinearExtension, IPForMLSumcheck, ListOfProductsOfPolynomials,  # noqa: F401
                           MLSumcheck, PolynomialInfo, ProverMsg, ProverState, SubClaim, VerifierMsg, interpolate_uni_poly)
+from .gkr_round_sumcheck import (GKRProof, GKRRoundSumcheck, GKRRoundSumcheckSubClaim, SparseMultilinearExtension,  # noqa: F401
+                                 initialize_phase_one, initialize_phase_two, start_phase1_sumcheck, start_phase2_sumcheck)

@@ -36,6 +36,16 @@ static int fail(int code, const char *fmt, ...) {
     g_last_error = buf;
     return code;
 }
+// shared with gkr.hip
+int sc_internal_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
 #define HIP_TRY(expr)                                                                                                   \
     do {                                                                                                                \
         hipError_t e_ = (expr);                                                                                         \

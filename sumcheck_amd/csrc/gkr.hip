@@ -1,8 +1,469 @@
-// gkr.hip -- GKR round sumcheck initialisation on the GPU (placeholder until the sparse kernels land).
+// gkr.hip -- GKR round sumcheck (Libra section 3.3) initialisation on the GPU and the two-phase driver.
+//
+// Replaces, on the device:
+//   SparseMultilinearExtension::fix_variables (ark-poly; called at reference src/gkr_round_sumcheck/mod.rs:31,62)
+//   initialize_phase_one  (mod.rs:22-42)   h_g[x] = sum_y f1(g,x,y) * f3[y]
+//   initialize_phase_two  (mod.rs:57-63)   f1(g,u,.) as a dense table
+//   start_phase2_sumcheck's f3 * f2(u)      (mod.rs:71-75) and f2.evaluate(u) (mod.rs:122)
+//   GKRRoundSumcheck::prove (mod.rs:93-139) driver: both sumcheck phases over tables that never leave HBM.
+//
+// The reference folds sparse entries through hash maps; there is no atomic field addition on a GPU, so the
+// fold is restated as  sort by index (once) -> multiply by the eq table -> segmented field sum of equal keys
+// (rocPRIM reduce_by_key with the modular-add functor).  Binding the LOW k variables maps index i to key i >> k,
+// which keeps a sorted list sorted, so only the scatter by x in phase one needs a second sort.  Field
+// arithmetic is exact, hence the result is the same canonical table whatever the summation order.
 #include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce_by_key.hpp>
+
 #include "../../include/sumcheck_hip.h"
-extern "C" int sc_gkr_phase_one(const uint64_t *, const uint64_t *, uint64_t, uint32_t, const uint64_t *, const uint64_t *, uint64_t *,
-                                uint64_t *, uint64_t *, uint64_t *) { return SC_ERR_BAD_ARG; }
-extern "C" int sc_gkr_phase_two(const uint64_t *, const uint64_t *, uint64_t, uint32_t, const uint64_t *, uint64_t *) { return SC_ERR_BAD_ARG; }
-extern "C" int sc_gkr_prove(sc_rng *, const uint64_t *, const uint64_t *, uint64_t, uint32_t, const uint64_t *, const uint64_t *,
-                            const uint64_t *, uint64_t *, uint64_t *) { return SC_ERR_BAD_ARG; }
+#include "fr.cuh"
+#include "host_fr.hpp"
+#include "kernels.h"
+#include "transcript.hpp"
+
+using scd::Fr;
+using scd::FrHost;
+using scd::FrU;
+using scd::kBlock;
+
+int sc_internal_fail(int code, const char *fmt, ...); // api.hip
+struct sc_rng {
+    sch::Blake2b512Rng rng;
+};
+
+namespace {
+
+struct FrAdd {
+    __device__ Fr operator()(const Fr &a, const Fr &b) const { return scd::fr_add(a, b); }
+};
+
+__device__ __forceinline__ FrU fru(const FrHost &h) {
+    FrU r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r.v[2 * i] = (uint32_t)h.l[i];
+        r.v[2 * i + 1] = (uint32_t)(h.l[i] >> 32);
+    }
+    return r;
+}
+__device__ __forceinline__ Fr fr_ld(const Fr *p) { return scd::fr_load(reinterpret_cast<const uint4 *>(p)); }
+__device__ __forceinline__ void fr_st(Fr *p, const Fr &a) { scd::fr_store(reinterpret_cast<uint4 *>(p), a); }
+
+// precompute_eq (ark-poly): level i doubles the table: dp[b + 2^i] = dp[b] * g_i ; dp[b] -= dp[b + 2^i]
+__global__ __launch_bounds__(kBlock) void k_eq_init(Fr *dp, const FrHost g0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        Fr g;
+        const FrU gu = fru(g0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g.v[i] = gu.v[i];
+        fr_st(dp + 0, scd::fr_sub(scd::fr_one(), g));
+        fr_st(dp + 1, g);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_eq_level(Fr *dp, const uint64_t half, const FrHost gi) {
+    const FrU g = fru(gi);
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < half; b += stride) {
+        const Fr prev = fr_ld(dp + b);
+        const Fr hi = scd::fr_mul_u(prev, g);
+        fr_st(dp + b + half, hi);
+        fr_st(dp + b, scd::fr_sub(prev, hi));
+    }
+}
+// w[i] = eq[idx[i] & mask] * vals[perm ? perm[i] : i] ; key[i] = idx[i] >> k
+__global__ __launch_bounds__(kBlock) void k_sparse_scale(const uint64_t *__restrict__ idx, const Fr *__restrict__ vals,
+                                                         const uint32_t *__restrict__ perm, const Fr *__restrict__ eq, const uint32_t k,
+                                                         const uint64_t n, uint64_t *__restrict__ key, Fr *__restrict__ w) {
+    const uint64_t mask = (k >= 64) ? ~0ULL : ((1ULL << k) - 1);
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t id = idx[i];
+        const Fr v = fr_ld(vals + (perm ? perm[i] : i));
+        fr_st(w + i, scd::fr_mul(fr_ld(eq + (id & mask)), v));
+        key[i] = id >> k;
+    }
+}
+// eq(point, idx & mask) evaluated directly (no 2^k table): used when 2^k entries would not be worth building
+__global__ __launch_bounds__(kBlock) void k_sparse_scale_direct(const uint64_t *__restrict__ idx, const Fr *__restrict__ vals,
+                                                                const uint32_t *__restrict__ perm, const Fr *__restrict__ point,
+                                                                const uint32_t k, const uint64_t n, uint64_t *__restrict__ key,
+                                                                Fr *__restrict__ w) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t id = idx[i];
+        Fr acc = fr_ld(vals + (perm ? perm[i] : i));
+        for (uint32_t j = 0; j < k; ++j) {
+            const Fr gj = fr_ld(point + j);
+            acc = scd::fr_mul(acc, ((id >> j) & 1) ? gj : scd::fr_sub(scd::fr_one(), gj));
+        }
+        fr_st(w + i, acc);
+        key[i] = (k >= 64) ? 0 : (id >> k);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_iota(uint32_t *p, const uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) p[i] = (uint32_t)i;
+}
+// phase one scatter terms (mod.rs:32-38): key_x = xy & mask, t = v * f3[xy >> dim]
+__global__ __launch_bounds__(kBlock) void k_hg_terms(const uint64_t *__restrict__ xy, const Fr *__restrict__ v, const Fr *__restrict__ f3,
+                                                     const uint32_t dim, const uint64_t n, uint64_t *__restrict__ key_x,
+                                                     Fr *__restrict__ t) {
+    const uint64_t mask = (1ULL << dim) - 1;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t id = xy[i];
+        key_x[i] = id & mask;
+        fr_st(t + i, scd::fr_mul(fr_ld(v + i), fr_ld(f3 + (id >> dim))));
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_gather(const Fr *__restrict__ src, const uint32_t *__restrict__ perm, const uint64_t n,
+                                                   Fr *__restrict__ dst) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) fr_st(dst + i, fr_ld(src + perm[i]));
+}
+// dense[key[i]] = val[i] for i < *count (keys unique)
+__global__ __launch_bounds__(kBlock) void k_scatter_dense(const uint64_t *__restrict__ key, const Fr *__restrict__ val,
+                                                          const unsigned int *__restrict__ count, Fr *__restrict__ dense) {
+    const uint64_t n = *count;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) fr_st(dense + key[i], fr_ld(val + i));
+}
+
+#define G_TRY(expr)                                                                                                      \
+    do {                                                                                                                 \
+        hipError_t e_ = (expr);                                                                                          \
+        if (e_ != hipSuccess)                                                                                            \
+            return sc_internal_fail(e_ == hipErrorOutOfMemory ? SC_ERR_OOM : SC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                                    hipGetErrorString(e_), __FILE__, __LINE__);                                          \
+    } while (0)
+
+struct DevBuf { // owns device allocations for the lifetime of one API call
+    std::vector<void *> ptrs;
+    ~DevBuf() {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    hipError_t alloc(T **out, size_t n) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
+        if (e == hipSuccess) {
+            ptrs.push_back(p);
+            *out = static_cast<T *>(p);
+        }
+        return e;
+    }
+};
+
+inline int grid_for(uint64_t n) { return scd::grid_for_pairs(n); }
+inline FrHost hostfr(const sch::Fr &a) {
+    FrHost h;
+    std::memcpy(&h, &a, 32);
+    return h;
+}
+
+// Sort (idx, vals) by idx on the device.  out_idx / out_vals are n-element device buffers.
+int sort_sparse(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_t n, uint32_t bits, uint64_t *out_idx, Fr *out_vals,
+                hipStream_t s) {
+    if (n == 0) return SC_OK;
+    uint32_t *iota = nullptr, *perm = nullptr;
+    G_TRY(mem.alloc(&iota, n));
+    G_TRY(mem.alloc(&perm, n));
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(n)), dim3(kBlock), 0, s, iota, n);
+    size_t tmp_bytes = 0;
+    G_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_idx, out_idx, iota, perm, n, 0, bits, s));
+    char *tmp = nullptr;
+    G_TRY(mem.alloc(&tmp, tmp_bytes));
+    G_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, d_idx, out_idx, iota, perm, n, 0, bits, s));
+    hipLaunchKernelGGL(k_gather, dim3(grid_for(n)), dim3(kBlock), 0, s, d_vals, perm, n, out_vals);
+    G_TRY(hipGetLastError());
+    return SC_OK;
+}
+
+// SparseMultilinearExtension::fix_variables over the low k variables of a list sorted by index.
+// Output: merged (key, value) list (sorted, unique keys) in out_key/out_val (capacity n) and *d_count on device.
+int sparse_fix(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_t n, const sch::Fr *point, uint32_t k, uint64_t *out_key,
+               Fr *out_val, unsigned int *d_count, hipStream_t s) {
+    if (n == 0) {
+        G_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned int), s));
+        return SC_OK;
+    }
+    uint64_t *key = nullptr;
+    Fr *w = nullptr;
+    G_TRY(mem.alloc(&key, n));
+    G_TRY(mem.alloc(&w, n));
+    const bool use_table = k >= 1 && k <= 26 && (1ULL << k) <= 8 * n + 1024;
+    if (k == 0) {
+        G_TRY(hipMemcpyAsync(key, d_idx, n * 8, hipMemcpyDeviceToDevice, s));
+        G_TRY(hipMemcpyAsync(w, d_vals, n * 32, hipMemcpyDeviceToDevice, s));
+    } else if (use_table) {
+        Fr *eq = nullptr;
+        G_TRY(mem.alloc(&eq, (size_t)1 << k));
+        hipLaunchKernelGGL(k_eq_init, dim3(1), dim3(kBlock), 0, s, eq, hostfr(point[0]));
+        for (uint32_t i = 1; i < k; ++i) {
+            const uint64_t half = 1ULL << i;
+            hipLaunchKernelGGL(k_eq_level, dim3(grid_for(half)), dim3(kBlock), 0, s, eq, half, hostfr(point[i]));
+        }
+        hipLaunchKernelGGL(k_sparse_scale, dim3(grid_for(n)), dim3(kBlock), 0, s, d_idx, d_vals, (const uint32_t *)nullptr, eq, k, n, key, w);
+    } else {
+        Fr *d_point = nullptr;
+        G_TRY(mem.alloc(&d_point, k));
+        G_TRY(hipMemcpyAsync(d_point, point, (size_t)k * 32, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_sparse_scale_direct, dim3(grid_for(n)), dim3(kBlock), 0, s, d_idx, d_vals, (const uint32_t *)nullptr, d_point, k, n,
+                           key, w);
+    }
+    G_TRY(hipGetLastError());
+    size_t tmp_bytes = 0;
+    G_TRY(rocprim::reduce_by_key(nullptr, tmp_bytes, key, w, n, out_key, out_val, d_count, FrAdd(), rocprim::equal_to<uint64_t>(), s));
+    char *tmp = nullptr;
+    G_TRY(mem.alloc(&tmp, tmp_bytes));
+    G_TRY(rocprim::reduce_by_key(tmp, tmp_bytes, key, w, n, out_key, out_val, d_count, FrAdd(), rocprim::equal_to<uint64_t>(), s));
+    return SC_OK;
+}
+
+// initialize_phase_one on the device (inputs sorted by index).  Outputs: d_hg (2^dim), f1_g list + count.
+int phase_one_device(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_t nnz, uint32_t dim, const Fr *d_f3, const sch::Fr *g,
+                     Fr *d_hg, uint64_t *d_f1g_idx, Fr *d_f1g_vals, unsigned int *d_n1, uint64_t *h_n1, hipStream_t s) {
+    int rc = sparse_fix(mem, d_idx, d_vals, nnz, g, dim, d_f1g_idx, d_f1g_vals, d_n1, s); // mod.rs:31
+    if (rc) return rc;
+    unsigned int n1 = 0;
+    G_TRY(hipMemcpyAsync(&n1, d_n1, sizeof(n1), hipMemcpyDeviceToHost, s));
+    G_TRY(hipStreamSynchronize(s));
+    *h_n1 = n1;
+    const uint64_t N = 1ULL << dim;
+    G_TRY(hipMemsetAsync(d_hg, 0, N * 32, s)); // a_hg starts at zero (mod.rs:30)
+    if (n1 == 0) return SC_OK;
+    uint64_t *key_x = nullptr, *key_xs = nullptr, *ux = nullptr;
+    Fr *t = nullptr, *ts = nullptr, *sums = nullptr;
+    uint32_t *iota = nullptr, *perm = nullptr;
+    unsigned int *d_cnt = nullptr;
+    G_TRY(mem.alloc(&key_x, n1));
+    G_TRY(mem.alloc(&key_xs, n1));
+    G_TRY(mem.alloc(&ux, n1));
+    G_TRY(mem.alloc(&t, n1));
+    G_TRY(mem.alloc(&ts, n1));
+    G_TRY(mem.alloc(&sums, n1));
+    G_TRY(mem.alloc(&iota, n1));
+    G_TRY(mem.alloc(&perm, n1));
+    G_TRY(mem.alloc(&d_cnt, 1));
+    hipLaunchKernelGGL(k_hg_terms, dim3(grid_for(n1)), dim3(kBlock), 0, s, d_f1g_idx, d_f1g_vals, d_f3, dim, (uint64_t)n1, key_x, t); // mod.rs:34-36
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(n1)), dim3(kBlock), 0, s, iota, (uint64_t)n1);
+    size_t tb = 0;
+    G_TRY(rocprim::radix_sort_pairs(nullptr, tb, key_x, key_xs, iota, perm, n1, 0, dim ? dim : 1, s));
+    char *tmp = nullptr;
+    G_TRY(mem.alloc(&tmp, tb));
+    G_TRY(rocprim::radix_sort_pairs(tmp, tb, key_x, key_xs, iota, perm, n1, 0, dim ? dim : 1, s));
+    hipLaunchKernelGGL(k_gather, dim3(grid_for(n1)), dim3(kBlock), 0, s, t, perm, (uint64_t)n1, ts);
+    size_t tb2 = 0;
+    G_TRY(rocprim::reduce_by_key(nullptr, tb2, key_xs, ts, n1, ux, sums, d_cnt, FrAdd(), rocprim::equal_to<uint64_t>(), s));
+    char *tmp2 = nullptr;
+    G_TRY(mem.alloc(&tmp2, tb2));
+    G_TRY(rocprim::reduce_by_key(tmp2, tb2, key_xs, ts, n1, ux, sums, d_cnt, FrAdd(), rocprim::equal_to<uint64_t>(), s));
+    hipLaunchKernelGGL(k_scatter_dense, dim3(grid_for(n1)), dim3(kBlock), 0, s, ux, sums, d_cnt, d_hg);
+    G_TRY(hipGetLastError());
+    return SC_OK;
+}
+
+// initialize_phase_two on the device: dense 2^dim table of f1(g,u,.)
+int phase_two_device(DevBuf &mem, const uint64_t *d_f1g_idx, const Fr *d_f1g_vals, uint64_t n1, uint32_t dim, const sch::Fr *u, Fr *d_out,
+                     hipStream_t s) {
+    const uint64_t N = 1ULL << dim;
+    G_TRY(hipMemsetAsync(d_out, 0, N * 32, s));
+    if (n1 == 0) return SC_OK;
+    uint64_t *ky = nullptr;
+    Fr *vy = nullptr;
+    unsigned int *d_cnt = nullptr;
+    G_TRY(mem.alloc(&ky, n1));
+    G_TRY(mem.alloc(&vy, n1));
+    G_TRY(mem.alloc(&d_cnt, 1));
+    int rc = sparse_fix(mem, d_f1g_idx, d_f1g_vals, n1, u, dim, ky, vy, d_cnt, s); // mod.rs:62
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scatter_dense, dim3(grid_for(n1)), dim3(kBlock), 0, s, ky, vy, d_cnt, d_out); // to_dense_multilinear_extension
+    G_TRY(hipGetLastError());
+    return SC_OK;
+}
+
+int check_gkr_args(uint64_t nnz, uint32_t dim) {
+    if (dim == 0) return sc_internal_fail(SC_ERR_CONSTANT_POLY, "Attempt to prove a constant.");
+    if (dim > 21) return sc_internal_fail(SC_ERR_BAD_ARG, "dim %u: 3*dim index bits do not fit 64-bit indices", dim);
+    if (nnz >= (1ULL << 32)) return sc_internal_fail(SC_ERR_BAD_ARG, "nnz too large");
+    if (sc_device_count() <= 0) return sc_internal_fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    return SC_OK;
+}
+int check_points(const uint64_t *pt, uint32_t n, const char *what) {
+    for (uint32_t i = 0; i < n; ++i) {
+        sch::Fr a;
+        std::memcpy(&a, pt + 4 * i, 32);
+        if (sch::geq_p(a)) return sc_internal_fail(SC_ERR_BAD_ARG, "%s[%u] is not a canonical field element", what, i);
+    }
+    return SC_OK;
+}
+
+} // namespace
+
+extern "C" int sc_gkr_phase_one(const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim, const uint64_t *f3,
+                                const uint64_t *g, uint64_t *h_g, uint64_t *f1g_idx, uint64_t *f1g_vals, uint64_t *f1g_nnz) {
+    if ((nnz && (!f1_idx || !f1_vals)) || !f3 || !g || !h_g || !f1g_nnz || (nnz && (!f1g_idx || !f1g_vals)))
+        return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    int rc = check_gkr_args(nnz, dim);
+    if (rc) return rc;
+    if ((rc = check_points(g, dim, "g"))) return rc;
+    for (uint64_t i = 0; i < nnz; ++i)
+        if (dim < 21 && (f1_idx[i] >> (3 * dim)) != 0) return sc_internal_fail(SC_ERR_BAD_ARG, "f1 index %llu out of range", (unsigned long long)i);
+    hipStream_t s = nullptr;
+    DevBuf mem;
+    const uint64_t N = 1ULL << dim;
+    uint64_t *d_idx = nullptr, *d_idx_s = nullptr, *d_gi = nullptr;
+    Fr *d_vals = nullptr, *d_vals_s = nullptr, *d_f3 = nullptr, *d_hg = nullptr, *d_gv = nullptr;
+    unsigned int *d_n1 = nullptr;
+    G_TRY(mem.alloc(&d_idx, nnz));
+    G_TRY(mem.alloc(&d_idx_s, nnz));
+    G_TRY(mem.alloc(&d_vals, nnz));
+    G_TRY(mem.alloc(&d_vals_s, nnz));
+    G_TRY(mem.alloc(&d_f3, N));
+    G_TRY(mem.alloc(&d_hg, N));
+    G_TRY(mem.alloc(&d_gi, nnz));
+    G_TRY(mem.alloc(&d_gv, nnz));
+    G_TRY(mem.alloc(&d_n1, 1));
+    if (nnz) {
+        G_TRY(hipMemcpyAsync(d_idx, f1_idx, nnz * 8, hipMemcpyHostToDevice, s));
+        G_TRY(hipMemcpyAsync(d_vals, f1_vals, nnz * 32, hipMemcpyHostToDevice, s));
+    }
+    G_TRY(hipMemcpyAsync(d_f3, f3, N * 32, hipMemcpyHostToDevice, s));
+    if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 3 * dim, d_idx_s, d_vals_s, s))) return rc;
+    uint64_t n1 = 0;
+    if ((rc = phase_one_device(mem, d_idx_s, d_vals_s, nnz, dim, d_f3, reinterpret_cast<const sch::Fr *>(g), d_hg, d_gi, d_gv, d_n1, &n1, s))) return rc;
+    G_TRY(hipMemcpyAsync(h_g, d_hg, N * 32, hipMemcpyDeviceToHost, s));
+    if (n1) {
+        G_TRY(hipMemcpyAsync(f1g_idx, d_gi, n1 * 8, hipMemcpyDeviceToHost, s));
+        G_TRY(hipMemcpyAsync(f1g_vals, d_gv, n1 * 32, hipMemcpyDeviceToHost, s));
+    }
+    G_TRY(hipStreamSynchronize(s));
+    *f1g_nnz = n1;
+    return SC_OK;
+}
+
+extern "C" int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_vals, uint64_t nnz, uint32_t dim, const uint64_t *u,
+                                uint64_t *f1_gu) {
+    if ((nnz && (!f1g_idx || !f1g_vals)) || !u || !f1_gu) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    int rc = check_gkr_args(nnz, dim);
+    if (rc) return rc;
+    if ((rc = check_points(u, dim, "u"))) return rc;
+    for (uint64_t i = 0; i < nnz; ++i)
+        if ((f1g_idx[i] >> (2 * dim)) != 0) return sc_internal_fail(SC_ERR_BAD_ARG, "f1_g index %llu out of range", (unsigned long long)i);
+    hipStream_t s = nullptr;
+    DevBuf mem;
+    const uint64_t N = 1ULL << dim;
+    uint64_t *d_idx = nullptr, *d_idx_s = nullptr;
+    Fr *d_vals = nullptr, *d_vals_s = nullptr, *d_out = nullptr;
+    G_TRY(mem.alloc(&d_idx, nnz));
+    G_TRY(mem.alloc(&d_idx_s, nnz));
+    G_TRY(mem.alloc(&d_vals, nnz));
+    G_TRY(mem.alloc(&d_vals_s, nnz));
+    G_TRY(mem.alloc(&d_out, N));
+    if (nnz) {
+        G_TRY(hipMemcpyAsync(d_idx, f1g_idx, nnz * 8, hipMemcpyHostToDevice, s));
+        G_TRY(hipMemcpyAsync(d_vals, f1g_vals, nnz * 32, hipMemcpyHostToDevice, s));
+    }
+    if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 2 * dim, d_idx_s, d_vals_s, s))) return rc;
+    if ((rc = phase_two_device(mem, d_idx_s, d_vals_s, nnz, dim, reinterpret_cast<const sch::Fr *>(u), d_out, s))) return rc;
+    G_TRY(hipMemcpyAsync(f1_gu, d_out, N * 32, hipMemcpyDeviceToHost, s));
+    G_TRY(hipStreamSynchronize(s));
+    return SC_OK;
+}
+
+// One sumcheck phase: product 1*(A*B) over two device tables (start_phase{1,2}_sumcheck, mod.rs:45-54,66-82), dim rounds
+// of prove_round / feed / sample (mod.rs:111-119,126-133).
+static int run_phase(sch::Blake2b512Rng &rng, const Fr *dA, const Fr *dB, uint32_t dim, uint64_t *out_msgs, sch::Fr *challenges) {
+    const uint32_t offs[2] = {0, 2}, idx[2] = {0, 1};
+    const uint64_t *tabs[2] = {reinterpret_cast<const uint64_t *>(dA), reinterpret_cast<const uint64_t *>(dB)};
+    sc_poly_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.num_vars = dim;
+    d.max_multiplicands = 2;
+    d.n_products = 1;
+    d.coeffs = sch::kOne.l; // F::one()
+    d.prod_offsets = offs;
+    d.prod_indices = idx;
+    d.n_tables = 2;
+    d.tables = tabs;
+    d.flags = SC_TABLES_ON_DEVICE | SC_TABLES_BORROW; // the inputs are this call's own scratch: no second copy
+    sc_prover *p = nullptr;
+    int rc = sc_prover_init(&d, &p);
+    if (rc) return rc;
+    sch::Fr vm = sch::zero();
+    bool have = false;
+    for (uint32_t i = 0; i < dim; ++i) {
+        uint64_t *pm = out_msgs + (size_t)i * 12;
+        rc = sc_prove_round(p, have ? vm.l : nullptr, pm);
+        if (rc) {
+            sc_prover_free(p);
+            return rc;
+        }
+        rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(pm), 3);
+        vm = rng.sample_fr();
+        have = true;
+        challenges[i] = vm;
+    }
+    sc_prover_free(p);
+    return SC_OK;
+}
+
+extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim, const uint64_t *f2,
+                            const uint64_t *f3, const uint64_t *g, uint64_t *out_proof, uint64_t *out_uv_or_null) {
+    if (!rng || (nnz && (!f1_idx || !f1_vals)) || !f2 || !f3 || !g || !out_proof) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    int rc = check_gkr_args(nnz, dim);
+    if (rc) return rc;
+    if ((rc = check_points(g, dim, "g"))) return rc;
+    for (uint64_t i = 0; i < nnz; ++i)
+        if (dim < 21 && (f1_idx[i] >> (3 * dim)) != 0) return sc_internal_fail(SC_ERR_BAD_ARG, "f1 index %llu out of range", (unsigned long long)i);
+    hipStream_t s = nullptr;
+    DevBuf mem;
+    const uint64_t N = 1ULL << dim;
+    uint64_t *d_idx = nullptr, *d_idx_s = nullptr, *d_gi = nullptr;
+    Fr *d_vals = nullptr, *d_vals_s = nullptr, *d_f2 = nullptr, *d_f3 = nullptr, *d_hg = nullptr, *d_gv = nullptr, *d_f1gu = nullptr, *d_f3s = nullptr;
+    unsigned int *d_n1 = nullptr;
+    G_TRY(mem.alloc(&d_idx, nnz));
+    G_TRY(mem.alloc(&d_idx_s, nnz));
+    G_TRY(mem.alloc(&d_vals, nnz));
+    G_TRY(mem.alloc(&d_vals_s, nnz));
+    G_TRY(mem.alloc(&d_f2, N));
+    G_TRY(mem.alloc(&d_f3, N));
+    G_TRY(mem.alloc(&d_hg, N));
+    G_TRY(mem.alloc(&d_gi, nnz));
+    G_TRY(mem.alloc(&d_gv, nnz));
+    G_TRY(mem.alloc(&d_f1gu, N));
+    G_TRY(mem.alloc(&d_f3s, N));
+    G_TRY(mem.alloc(&d_n1, 1));
+    if (nnz) {
+        G_TRY(hipMemcpyAsync(d_idx, f1_idx, nnz * 8, hipMemcpyHostToDevice, s));
+        G_TRY(hipMemcpyAsync(d_vals, f1_vals, nnz * 32, hipMemcpyHostToDevice, s));
+    }
+    G_TRY(hipMemcpyAsync(d_f2, f2, N * 32, hipMemcpyHostToDevice, s));
+    G_TRY(hipMemcpyAsync(d_f3, f3, N * 32, hipMemcpyHostToDevice, s));
+    if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 3 * dim, d_idx_s, d_vals_s, s))) return rc;
+    uint64_t n1 = 0;
+    if ((rc = phase_one_device(mem, d_idx_s, d_vals_s, nnz, dim, d_f3, reinterpret_cast<const sch::Fr *>(g), d_hg, d_gi, d_gv, d_n1, &n1, s))) return rc; // mod.rs:106
+    G_TRY(hipStreamSynchronize(s));
+    std::vector<sch::Fr> u(dim), v(dim);
+    if ((rc = run_phase(rng->rng, d_hg, d_f2, dim, out_proof, u.data()))) return rc; // mod.rs:107-119
+    if ((rc = phase_two_device(mem, d_gi, d_gv, n1, dim, u.data(), d_f1gu, s))) return rc; // mod.rs:121
+    // f2.evaluate(&u) (mod.rs:122): bind all dim variables on the device
+    sch::Fr f2_u;
+    G_TRY(hipStreamSynchronize(s));
+    rc = sc_fix_variables(reinterpret_cast<const uint64_t *>(d_f2), dim, u[0].l, dim, reinterpret_cast<uint64_t *>(d_hg), SC_TABLES_ON_DEVICE);
+    if (rc) return rc;
+    G_TRY(hipMemcpy(&f2_u, d_hg, 32, hipMemcpyDeviceToHost));
+    G_TRY(scd::launch_scale(reinterpret_cast<const uint4 *>(d_f3), reinterpret_cast<uint4 *>(d_f3s), hostfr(f2_u), N, s)); // mod.rs:71-75
+    G_TRY(hipStreamSynchronize(s));
+    if ((rc = run_phase(rng->rng, d_f1gu, d_f3s, dim, out_proof + (size_t)dim * 12, v.data()))) return rc; // mod.rs:122-133
+    if (out_uv_or_null) {
+        std::memcpy(out_uv_or_null, u.data(), (size_t)dim * 32);
+        std::memcpy(out_uv_or_null + (size_t)dim * 4, v.data(), (size_t)dim * 32);
+    }
+    return SC_OK;
+}

@@ -245,3 +245,86 @@ def test_sharded_partial_rounds_single_gpu():
     got, rand = sharded.prove_logical_shards(nv, shapes, tabs, coefs, G, dev)
     assert np.array_equal(got, want)
     assert np.array_equal(rand, wrand)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GKR round sumcheck (BASELINE config 5): reference src/gkr_round_sumcheck/{mod.rs,test.rs}
+# ------------------------------------------------------------------------------------------------------------------
+def _gkr_inputs_from_golden(g):
+    dim = g["dim"]
+    f1 = sc.SparseMultilinearExtension(3 * dim, np.asarray(g["f1_idx"], dtype=np.uint64), H.mont(g["f1_vals"]))
+    f2 = sc.DenseMultilinearExtension(dim, H.mont(g["f2"]))
+    f3 = sc.DenseMultilinearExtension(dim, H.mont(g["f3"]))
+    return dim, f1, f2, f3, H.mont(g["g"])
+
+
+@pytest.mark.parametrize("name", H.gkr_cases())
+def test_gkr_golden(name):
+    g = H.load(name)
+    dim, f1, f2, f3, gg = _gkr_inputs_from_golden(g)
+    # shuffled input order must not matter (the reference's f1 is a BTreeMap)
+    perm = np.random.default_rng(1).permutation(f1.indices.shape[0])
+    f1s = sc.SparseMultilinearExtension(3 * dim, f1.indices[perm], f1.values[perm])
+    h_g, f1_g = sc.initialize_phase_one(f1s, f3, gg)
+    assert field.to_ints(h_g.evaluations) == [H.hx(x) for x in g["h_g"]]
+    assert f1_g.indices.tolist() == g["f1_g_idx"]
+    assert field.to_ints(f1_g.values) == [H.hx(x) for x in g["f1_g_vals"]]
+    f1_gu = sc.initialize_phase_two(f1_g, H.mont(g["u"]))
+    assert field.to_ints(f1_gu.evaluations) == [H.hx(x) for x in g["f1_gu"]]
+    proof = sc.GKRRoundSumcheck.prove(sc.Blake2b512Rng.setup(), f1s, f2, f3, gg)
+    for i in range(dim):
+        assert field.to_ints(proof.phase1_sumcheck_msgs[i].evaluations) == [H.hx(x) for x in g["phase1"][i]]
+        assert field.to_ints(proof.phase2_sumcheck_msgs[i].evaluations) == [H.hx(x) for x in g["phase2"][i]]
+    assert field.to_int(proof.extract_sum()) == H.hx(g["sum"])  # gkr test.rs:76-88
+    sub = sc.GKRRoundSumcheck.verify(sc.Blake2b512Rng.setup(), dim, proof, H.mont([g["sum"]])[0])
+    assert field.to_ints(sub.u) == [H.hx(x) for x in g["u"]] and field.to_ints(sub.v) == [H.hx(x) for x in g["v"]]
+    assert field.to_int(sub.expected_evaluation) == H.hx(g["expected"])
+    assert sub.verify_subclaim(f1, f2, f3, gg)  # gkr test.rs:58-68
+    # the interactive pieces (start_phase1_sumcheck) agree with the fused driver
+    st = sc.start_phase1_sumcheck(h_g, f2)
+    assert np.array_equal(sc.IPForMLSumcheck.prove_round(st, None).evaluations, proof.phase1_sumcheck_msgs[0].evaluations)
+
+
+def _random_gkr(dim, seed, collide=False):
+    rng = np.random.default_rng(seed)
+    n = 1 << dim
+    if collide:  # force many (x,y) collisions after binding z, and many x collisions in the scatter
+        idx = np.unique((rng.integers(0, 1 << dim, size=4 * n, dtype=np.uint64)) | (rng.integers(0, 4, size=4 * n, dtype=np.uint64) << np.uint64(dim))
+                        | (rng.integers(0, 3, size=4 * n, dtype=np.uint64) << np.uint64(2 * dim)))[:n]
+    else:
+        idx = np.unique(rng.integers(0, 1 << (3 * dim), size=2 * n, dtype=np.uint64))[:n]
+    vals = cref.synth_table(seed, 1, idx.shape[0])
+    return idx, vals, cref.synth_table(seed, 2, n), cref.synth_table(seed, 3, n), cref.synth_table(seed, 4, dim)
+
+
+@pytest.mark.parametrize("dim,collide", [(1, False), (3, True), (9, False), (12, True), (16, False)])
+def test_gkr_vs_oracle(dim, collide):
+    """reference gkr test.rs:71-74 (dim 9) plus collision-heavy inputs; every stage against the C oracle"""
+    idx, vals, f2, f3, g = _random_gkr(dim, 1000 + dim, collide)
+    f1 = sc.SparseMultilinearExtension(3 * dim, idx, vals)
+    mf2, mf3 = sc.DenseMultilinearExtension(dim, f2), sc.DenseMultilinearExtension(dim, f3)
+    h_g, f1_g = sc.initialize_phase_one(f1, mf3, g)
+    wh, wi, wv = cref.gkr_phase_one(idx, vals, dim, f3, g)
+    assert np.array_equal(h_g.evaluations, wh) and np.array_equal(f1_g.indices, wi) and np.array_equal(f1_g.values, wv)
+    want, wuv = cref.gkr_prove(idx, vals, dim, f2, f3, g, threads=cref.max_threads())
+    proof = sc.GKRRoundSumcheck.prove(sc.Blake2b512Rng.setup(), f1, mf2, mf3, g)
+    got1 = np.stack([m.evaluations for m in proof.phase1_sumcheck_msgs])
+    got2 = np.stack([m.evaluations for m in proof.phase2_sumcheck_msgs])
+    assert np.array_equal(got1, want[0]) and np.array_equal(got2, want[1])
+    f1_gu = sc.initialize_phase_two(f1_g, wuv[0])
+    assert np.array_equal(f1_gu.evaluations, cref.gkr_phase_two(wi, wv, dim, wuv[0]))
+    sub = sc.GKRRoundSumcheck.verify(sc.Blake2b512Rng.setup(), dim, proof, proof.extract_sum())
+    assert np.array_equal(sub.u, wuv[0]) and np.array_equal(sub.v, wuv[1])
+    if dim <= 12:
+        assert sub.verify_subclaim(f1, mf2, mf3, g)
+
+
+def test_gkr_config5_dim20():
+    """BASELINE config 5: GKRRoundSumcheck prove, dim=20, 2^20 non-zeros, bit-exact vs the oracle"""
+    dim = 20
+    idx, vals, f2, f3, g = _random_gkr(dim, 0x5C20241008)
+    want, _ = cref.gkr_prove(idx, vals, dim, f2, f3, g, threads=cref.max_threads())
+    proof = sc.GKRRoundSumcheck.prove(sc.Blake2b512Rng.setup(), sc.SparseMultilinearExtension(3 * dim, idx, vals),
+                                      sc.DenseMultilinearExtension(dim, f2), sc.DenseMultilinearExtension(dim, f3), g)
+    assert np.array_equal(np.stack([m.evaluations for m in proof.phase1_sumcheck_msgs]), want[0])
+    assert np.array_equal(np.stack([m.evaluations for m in proof.phase2_sumcheck_msgs]), want[1])
