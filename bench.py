@@ -174,6 +174,13 @@ def main():
         avg_ms = ms[dom] / max(launches, 1)
         bytes_per_launch = bytes_per_prove_dom * args.steps / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None  # measured off-line with rocprofv3 PMC passes (tools/profile.sh), per launch of the same kernel
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")))
+            if tj.get("kernel", "").endswith(f"k_prod_round<{len(shapes[dom])}>") and nv_local == 24:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         all_kernels_gbps = algorithmic_bytes(nv_local, U) * args.steps / (rounds_ms.value * 1e-3) / 1e9 if rounds_ms.value > 0 else 0.0
         out = {
             "metric": "MLSumcheck prover field-ops/s (BLS12-381 Fr, nv=24)",
@@ -185,7 +192,7 @@ def main():
                        "nv": nv_total, "nv_per_gpu": nv_local, "tables": U, "degree": max(len(s) for s in shapes),
                        "field_ops_per_step": ops, "sharding": f"high-bit x{world}" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": f"k_prod_round<{len(shapes[dom])}> (product {dom})",
+                         "traffic": traffic, "kernel": f"k_prod_round<{len(shapes[dom])}> (product {dom})",
                          "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "all_kernels_GBps": all_kernels_gbps, "all_kernels_ms_per_step": rounds_ms.value / args.steps,
                          "per_product_ms_per_step": [m / args.steps for m in ms]},
