@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,8 @@
 using scd::FinProd;
 using scd::FrHost;
 using scd::ProdArgs;
+using scd::Combo;
+using scd::TablePtrs;
 
 // ---------------------------------------------------------------------------------------------------
 // error plumbing
@@ -130,7 +133,13 @@ struct sc_prover {
     FinProd *d_finprods = nullptr;
     FrHost *d_scratch = nullptr;
     FrHost *d_out = nullptr;
-    FrHost *h_out = nullptr; // pinned
+    FrHost *h_out = nullptr;      // pinned, host-mapped: k_finalize writes the message here directly
+    uint32_t *h_flag = nullptr;   // pinned, host-mapped sequence flag raised by k_finalize
+    FrHost *h_out_dev = nullptr;  // device-side aliases of the two
+    uint32_t *h_flag_dev = nullptr;
+    uint32_t seq = 0;
+    Combo *d_combos = nullptr;    // (product, point) combinations for the small-round kernel
+    int n_combos = 0;
     bool any_generic = false;
     const uint4 **d_cur_tables = nullptr;
     const uint4 **h_cur_tables = nullptr; // pinned
@@ -157,6 +166,8 @@ static void prover_destroy(sc_prover *p) {
     if (p->d_scratch) (void)hipFree(p->d_scratch);
     if (p->d_out) (void)hipFree(p->d_out);
     if (p->h_out) (void)hipHostFree(p->h_out);
+    if (p->h_flag) (void)hipHostFree(p->h_flag);
+    if (p->d_combos) (void)hipFree(p->d_combos);
     if (p->d_cur_tables) (void)hipFree(p->d_cur_tables);
     if (p->h_cur_tables) (void)hipHostFree(p->h_cur_tables);
     if (p->d_slot_table) (void)hipFree(p->d_slot_table);
@@ -208,6 +219,7 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     uint64_t partial_elems = 0;
     std::vector<uint32_t> slot_table, slot_exp;
     std::vector<FinProd> fin(p->K);
+    std::vector<Combo> combos;
     for (uint32_t k = 0; k < p->K; ++k) {
         Product pr;
         std::memcpy(&pr.coeff, d->coeffs + 4 * k, 32);
@@ -234,6 +246,15 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
         fin[k].pad = 0;
         fin[k].partial_off = pr.partial_off;
         fin[k].coeff = to_dev(pr.coeff);
+        for (uint32_t t = 0; t <= pr.M; ++t) {
+            Combo c;
+            c.t = t;
+            c.M = pr.M;
+            c.slot_off = pr.slot_off;
+            c.n_slots = (uint32_t)pr.tables.size();
+            c.partial_off = pr.partial_off;
+            combos.push_back(c);
+        }
         p->prods.push_back(std::move(pr));
     }
 
@@ -268,14 +289,23 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     if (p->K) HIP_TRY(hipMemcpyAsync(p->d_finprods, fin.data(), p->K * sizeof(FinProd), hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMalloc(&p->d_scratch, (size_t)2 * std::max<uint32_t>(p->K, 1) * p->D * 32));
     HIP_TRY(hipMalloc(&p->d_out, (size_t)p->D * 32));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_out), (size_t)p->D * 32, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_out), (size_t)p->D * 32, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_flag), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *p->h_flag = 0;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_out_dev), p->h_out, 0));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_flag_dev), p->h_flag, 0));
+    p->n_combos = (int)combos.size();
+    HIP_TRY(hipMalloc(&p->d_combos, std::max<size_t>(combos.size(), 1) * sizeof(Combo)));
+    if (!combos.empty()) HIP_TRY(hipMemcpyAsync(p->d_combos, combos.data(), combos.size() * sizeof(Combo), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMalloc(&p->d_slot_table, std::max<size_t>(slot_table.size(), 1) * 4));
+    HIP_TRY(hipMalloc(&p->d_slot_exp, std::max<size_t>(slot_exp.size(), 1) * 4));
+    if (!slot_table.empty()) {
+        HIP_TRY(hipMemcpyAsync(p->d_slot_table, slot_table.data(), slot_table.size() * 4, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->d_slot_exp, slot_exp.data(), slot_exp.size() * 4, hipMemcpyHostToDevice, p->stream));
+    }
     if (p->any_generic) {
         HIP_TRY(hipMalloc(&p->d_cur_tables, p->U * sizeof(void *)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_cur_tables), p->U * sizeof(void *), hipHostMallocDefault));
-        HIP_TRY(hipMalloc(&p->d_slot_table, slot_table.size() * 4));
-        HIP_TRY(hipMalloc(&p->d_slot_exp, slot_exp.size() * 4));
-        HIP_TRY(hipMemcpyAsync(p->d_slot_table, slot_table.data(), slot_table.size() * 4, hipMemcpyHostToDevice, p->stream));
-        HIP_TRY(hipMemcpyAsync(p->d_slot_exp, slot_exp.data(), slot_exp.size() * 4, hipMemcpyHostToDevice, p->stream));
     }
     HIP_TRY(hipStreamSynchronize(p->stream)); // inputs are copied: the caller may drop them now (prover.rs:55-59)
     return SC_OK;
@@ -323,7 +353,7 @@ static int collect_timing(sc_prover *p) {
 
 // Launch one round's kernels on p->stream.  On return the round polynomial is in p->d_out (and in
 // d_wide if non-null); nothing has been synchronised.
-static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide) {
+static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool publish_to_host) {
     // validation, same precedence as the reference's panics (prover.rs:78-98)
     if (p->exhausted) return fail(SC_ERR_NOT_ACTIVE, "Prover is not active");
     if (r_or_null && p->round == 0) return fail(SC_ERR_FIRST_ROUND_HAS_MSG, "first round should be prover first.");
@@ -356,13 +386,42 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         return e;
     };
 
+    const bool small = n_pairs <= scd::kSmallRoundPairs && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0;
+    if (small) {
+        // latency-bound round: one launch binds every table, one launch sums every (product, point) combination
+        TablePtrs tp;
+        std::memset(&tp, 0, sizeof(tp));
+        if (bind) {
+            for (uint32_t u = 0; u < p->U; ++u) {
+                Table &t = p->tabs[u];
+                tp.src[u] = t.cur;
+                tp.dst[u] = t.buf[t.next];
+            }
+            HIP_TRY(scd::launch_fix_multi(tp, (int)p->U, rdev, 2 * n_pairs, p->stream));
+            for (uint32_t u = 0; u < p->U; ++u) {
+                Table &t = p->tabs[u];
+                t.cur = t.buf[t.next];
+                t.next ^= 1;
+            }
+        }
+        for (uint32_t u = 0; u < p->U; ++u) tp.src[u] = p->tabs[u].cur;
+        if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[0], p->stream));
+        HIP_TRY(scd::launch_sum_combos(tp, p->d_combos, p->n_combos, p->d_slot_table, p->d_slot_exp, n_pairs, p->d_partials, grid, p->stream));
+        if (p->timing) {
+            for (uint32_t k = 0; k < p->K; ++k) { // the single launch is attributed to product 0; the others record an empty span
+                if (k > 0) HIP_TRY(hipEventRecord(p->prod_ev[2 * k], p->stream));
+                HIP_TRY(hipEventRecord(p->prod_ev[2 * k + 1], p->stream));
+            }
+        }
+        bind = false;
+    }
     if (bind && p->any_generic) { // generic products read bound tables: bind everything up front
         for (uint32_t u = 0; u < p->U; ++u) HIP_TRY(bind_table(u));
         bind = false;
     }
     std::vector<uint8_t> bound(p->U, 0);
     bool ptrs_uploaded = false;
-    for (uint32_t k = 0; k < p->K; ++k) {
+    for (uint32_t k = 0; k < p->K && !small; ++k) {
         const Product &pr = p->prods[k];
         FrHost *partials = p->d_partials + pr.partial_off;
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[2 * k], p->stream));
@@ -402,7 +461,9 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         for (uint32_t u = 0; u < p->U; ++u)
             if (!bound[u]) HIP_TRY(bind_table(u));
     }
-    HIP_TRY(scd::launch_finalize(p->d_finprods, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide, p->stream));
+    p->seq += 1;
+    HIP_TRY(scd::launch_finalize(p->d_finprods, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide,
+                                 publish_to_host ? p->h_out_dev : nullptr, publish_to_host ? p->h_flag_dev : nullptr, p->seq, p->stream));
     HIP_TRY(hipEventRecord(p->ev1, p->stream));
     p->timed = true;
     p->timing_pending = p->timing;
@@ -411,17 +472,30 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
 
 extern "C" int sc_prove_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals) {
     if (!p || !out_evals) return fail(SC_ERR_BAD_ARG, "null argument");
-    int rc = launch_round(p, r_or_null, nullptr);
+    int rc = launch_round(p, r_or_null, nullptr, true);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(p->h_out, p->d_out, (size_t)p->D * 32, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    // The message is written by k_finalize straight into host-mapped pinned memory, followed by a system-scope release of
+    // the sequence flag: poll it instead of paying a DMA copy plus an interrupt-driven stream synchronise every round.
+    const uint32_t want = p->seq;
+    uint64_t spins = 0;
+    bool seen = false;
+    const auto t_start = std::chrono::steady_clock::now();
+    while (!(seen = (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) == want))) {
+        if ((++spins & 0xfff) == 0) {
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(2)) break; // fall back to a real sync
+        }
+    }
+    if (!seen) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) != want) return fail(SC_ERR_HIP, "round finished without publishing its message");
+    }
     std::memcpy(out_evals, p->h_out, (size_t)p->D * 32);
     return SC_OK;
 }
 
 extern "C" int sc_prove_round_partial(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide_out) {
     if (!p || !d_wide_out) return fail(SC_ERR_BAD_ARG, "null argument");
-    return launch_round(p, r_or_null, d_wide_out);
+    return launch_round(p, r_or_null, d_wide_out, false);
 }
 
 extern "C" int sc_prover_bind_final(sc_prover *p, const uint64_t *r, uint64_t *d_out) {

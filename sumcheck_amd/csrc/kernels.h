@@ -7,7 +7,9 @@ namespace scd {
 
 constexpr int kBlock = 256;    // 4 wavefronts of 64
 constexpr int kMaxFusedM = 8;  // products up to this many multiplicands run register-resident and fused with the bind
-constexpr int kMaxGrid = 2048; // 256 CUs x 8 resident 256-thread blocks; longer ranges are grid-strided
+constexpr int kMaxGrid = 1024; // 256 CUs x 4 resident 256-thread blocks; longer ranges are grid-strided
+constexpr int kMaxSmallTables = 32;         // table-pointer block that fits a kernel argument
+constexpr uint64_t kSmallRoundPairs = 1u << 16; // rounds at or below this many pairs are latency-bound: split finer
 
 struct FrHost {
     uint64_t l[4];
@@ -36,6 +38,20 @@ struct FinProd {
     FrHost coeff;
 };
 
+// table pointers passed by value (kernel argument) for the latency-bound small-round kernels
+struct TablePtrs {
+    const uint4 *src[kMaxSmallTables];
+    uint4 *dst[kMaxSmallTables];
+};
+// one (product, evaluation point) combination of the small-round sum kernel (device memory, static per prover)
+struct Combo {
+    uint32_t t;        // evaluation point
+    uint32_t M;        // multiplicands of the product
+    uint32_t slot_off; // into slot_table / slot_exp
+    uint32_t n_slots;
+    uint64_t partial_off;
+};
+
 int grid_for_pairs(uint64_t n_pairs);
 
 // product k of one round: partials[blk*(M+1)+t] = sum over this block's pairs of prod_j line_j(t), t = 0..M
@@ -46,9 +62,15 @@ hipError_t launch_sum_generic(const uint4 *const *d_cur_tables, const uint32_t *
                               int n_slots, int M, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
 // out[b] = in[2b] + r*(in[2b+1]-in[2b]), b < n_out
 hipError_t launch_fix(const uint4 *src, uint4 *dst, const FrHost &r, uint64_t n_out, hipStream_t stream);
+// small rounds: bind every table in one launch (grid.y = table) ...
+hipError_t launch_fix_multi(const TablePtrs &tp, int n_tables, const FrHost &r, uint64_t n_out, hipStream_t stream);
+// ... and one launch for every (product, evaluation point) combination (grid.y = combination), one lane per pair
+hipError_t launch_sum_combos(const TablePtrs &tp, const Combo *d_combos, int n_combos, const uint32_t *d_slot_table,
+                             const uint32_t *d_slot_exp, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
 // combine per-block partials of all products into the round polynomial (D evaluations)
 hipError_t launch_finalize(const FinProd *d_prods, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
-                           FrHost *d_out, uint64_t *d_out_wide, hipStream_t stream);
+                           FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
+                           hipStream_t stream);
 hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);
 hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t n, hipStream_t stream);
 hipError_t launch_fr_elementwise(int op, const uint4 *a, const uint4 *b, const FrHost &u, uint4 *out, uint64_t n, hipStream_t stream);

@@ -177,24 +177,84 @@ __global__ __launch_bounds__(kBlock) void k_scale(const uint4 *__restrict__ src,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small rounds (<= kSmallRoundPairs pairs): a lane's dependent chain in k_prod_round (2 binds + M-1 products for
+// each of M+1 points, ~25 Montgomery products = ~30 us) is the whole kernel time, so the work is split finer:
+// one launch binds every table (one product deep), one launch computes every (product, point) combination with
+// one lane per (combination, pair) (M-1 products deep).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_fix_multi(const TablePtrs tp, const FrHost r_h, const uint64_t n_out) {
+    const FrU r = fru_from_host(r_h);
+    const uint4 *__restrict__ src = tp.src[blockIdx.y];
+    uint4 *__restrict__ dst = tp.dst[blockIdx.y];
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_out; b += stride) {
+        const uint4 *p = src + 4 * b;
+        const Fr lo = fr_load(p), hi = fr_load(p + 2);
+        fr_store(dst + 2 * b, fr_add(lo, fr_mul_u(fr_sub(hi, lo), r)));
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const Combo *__restrict__ combos,
+                                                       const uint32_t *__restrict__ slot_table, const uint32_t *__restrict__ slot_exp,
+                                                       const uint64_t n_pairs, uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    const Combo c = combos[blockIdx.y];
+    const uint32_t t = c.t;
+    const Fr tf = fr_from_u32(t);
+    Fr acc = fr_zero();
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_pairs; b += stride) {
+        Fr prod;
+        bool first = true;
+        for (uint32_t s = 0; s < c.n_slots; ++s) {
+            const uint4 *p = tp.src[slot_table[c.slot_off + s]] + 4 * b;
+            Fr val;
+            if (t == 0) val = fr_load(p);
+            else if (t == 1) val = fr_load(p + 2);
+            else {
+                const Fr lo = fr_load(p), hi = fr_load(p + 2);
+                val = fr_add(lo, fr_mul(fr_sub(hi, lo), tf));
+            }
+            uint32_t k = 0;
+            if (first) { prod = val; k = 1; first = false; }
+            for (; k < slot_exp[c.slot_off + s]; ++k) prod = fr_mul(prod, val);
+        }
+        acc = fr_add(acc, prod);
+    }
+    const Fr s = block_sum(acc, sm);
+    if (threadIdx.x == 0) fr_store(partials + 2 * (c.partial_off + (uint64_t)blockIdx.x * (c.M + 1) + t), s);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Finalize: per-block partials of every product -> the round's ProverMsg (D = deg+1 evaluations).
 //   phase 1  S_k[t] = sum over blocks of partial_k[blk][t]                       (t <= M_k)
 //   phase 2  extend S_k to t = M_k+1 .. D-1 by forward differences (additions only)
 //   phase 3  out[t] = sum_k c_k * S_k[t]
 // One block of 256 threads; everything here is O(K*D) field operations.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_finalize(const FinProd *__restrict__ prods, const int K, const int D, const int nblocks,
-                                                     const uint4 *__restrict__ partials, uint4 *__restrict__ scratch,
-                                                     uint4 *__restrict__ out, uint64_t *__restrict__ out_wide) {
+constexpr int kFinBlock = 1024; // 16 wavefronts: one per (product, point) combination for typical shapes
+__global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restrict__ prods, const int K, const int D, const int nblocks,
+                                                        const uint4 *__restrict__ partials, uint4 *__restrict__ scratch,
+                                                        uint4 *__restrict__ out, uint64_t *__restrict__ out_wide,
+                                                        uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag, const uint32_t seq) {
+    constexpr int kBlock = kFinBlock; // shadows the 256-thread constant inside this kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // phase 1: one wave per (k,t) combination
+    // phase 1: one wave per (k,t) combination; two independent accumulators keep two loads in flight per lane
     for (int combo = wave; combo < K * D; combo += kBlock / 64) {
         const int k = combo / D, t = combo % D;
         const int M = (int)prods[k].M;
         if (t > M) continue;
         const uint4 *base = partials + 2 * prods[k].partial_off;
-        Fr acc = fr_zero();
-        for (int blk = lane; blk < nblocks; blk += 64) acc = fr_add(acc, fr_load(base + 2 * ((uint64_t)blk * (M + 1) + t)));
+        Fr acc = fr_zero(), acc2 = fr_zero();
+        int blk = lane;
+        for (; blk + 64 < nblocks; blk += 128) {
+            const Fr x = fr_load(base + 2 * ((uint64_t)blk * (M + 1) + t));
+            const Fr y = fr_load(base + 2 * ((uint64_t)(blk + 64) * (M + 1) + t));
+            acc = fr_add(acc, x);
+            acc2 = fr_add(acc2, y);
+        }
+        if (blk < nblocks) acc = fr_add(acc, fr_load(base + 2 * ((uint64_t)blk * (M + 1) + t)));
+        acc = fr_add(acc, acc2);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) acc = fr_add(acc, fr_shfl_down(acc, off));
         if (lane == 0) fr_store(scratch + 2 * (k * D + t), acc);
@@ -228,9 +288,17 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const FinProd *__restrict__
         Fr acc = fr_zero();
         for (int k = 0; k < K; ++k) acc = fr_add(acc, fr_load(scratch + 2 * (k * D + t)));
         if (out) fr_store(out + 2 * t, acc);
+        if (h_out) fr_store(h_out + 2 * t, acc); // host-mapped pinned memory: the message lands on the host without a copy
         if (out_wide) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) out_wide[8 * t + i] = acc.v[i];
+        }
+    }
+    if (h_flag) { // publish: every writer fences to system scope, then one lane raises the sequence flag
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -391,9 +459,22 @@ hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t 
 }
 
 hipError_t launch_finalize(const FinProd *d_prods, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
-                           FrHost *d_out, uint64_t *d_out_wide, hipStream_t stream) {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, stream, d_prods, K, D, nblocks, (const uint4 *)d_partials,
-                       (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide);
+                           FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinBlock), 0, stream, d_prods, K, D, nblocks, (const uint4 *)d_partials,
+                       (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_fix_multi(const TablePtrs &tp, int n_tables, const FrHost &r, uint64_t n_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fix_multi, dim3(grid_for_pairs(n_out), n_tables), dim3(kBlock), 0, stream, tp, r, n_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_combos(const TablePtrs &tp, const Combo *d_combos, int n_combos, const uint32_t *d_slot_table,
+                             const uint32_t *d_slot_exp, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sum_combos, dim3(grid, n_combos), dim3(kBlock), 0, stream, tp, d_combos, d_slot_table, d_slot_exp, n_pairs,
+                       (uint4 *)d_partials);
     return hipGetLastError();
 }
 
