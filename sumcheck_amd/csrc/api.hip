@@ -146,6 +146,7 @@ struct sc_prover {
     uint32_t *d_slot_table = nullptr, *d_slot_exp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool use_fe = true; // big rounds in carry-free arithmetic (fe.cuh); SC_FE=0 selects the saturated kernels
     // reset support + per-product instrumentation
     bool borrow = false;
     std::vector<const uint4 *> origin; // borrowed table pointers (borrow mode)
@@ -214,6 +215,7 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     p->K = d->n_products;
     p->U = d->n_tables;
     p->randomness.reserve(p->nv);
+    if (const char *e = std::getenv("SC_FE")) p->use_fe = std::atoi(e) != 0;
 
     // products: distinct tables + multiplicities
     uint64_t partial_elems = 0;
@@ -246,6 +248,11 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
         fin[k].pad = 0;
         fin[k].partial_off = pr.partial_off;
         fin[k].coeff = to_dev(pr.coeff);
+        {
+            sch::Fr sc = pr.coeff; // coeff * 2^(5(M-1)) in Montgomery form = Montgomery form doubled 5(M-1) times
+            for (uint32_t d = 0; d < 5 * (pr.M - 1); ++d) sc = sch::add(sc, sc);
+            fin[k].coeff_scaled = to_dev(sc);
+        }
         for (uint32_t t = 0; t <= pr.M; ++t) {
             Combo c;
             c.t = t;
@@ -374,6 +381,10 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     p->round += 1;
     const uint64_t n_pairs = 1ULL << (p->nv - p->round);
     const FrHost rdev = to_dev(r);
+    sch::Fr r32v = r; // r * 2^5 for the 2^261-radix kernels
+    for (int d = 0; d < 5; ++d) r32v = sch::add(r32v, r32v);
+    const FrHost r32 = to_dev(r32v);
+    int scaled = 0;
     const int grid = scd::grid_for_pairs(n_pairs);
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
 
@@ -445,7 +456,12 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
                     a.slot[s].dst = nullptr;
                 }
             }
-            HIP_TRY(scd::launch_prod_round((int)pr.M, a, rdev, n_pairs, partials, grid, p->stream));
+            if (p->use_fe) {
+                HIP_TRY(scd::launch_prod_round_fe((int)pr.M, a, r32, n_pairs, partials, grid, p->stream));
+                scaled = 1;
+            } else {
+                HIP_TRY(scd::launch_prod_round((int)pr.M, a, rdev, n_pairs, partials, grid, p->stream));
+            }
         } else {
             if (!ptrs_uploaded) {
                 for (uint32_t u = 0; u < p->U; ++u) p->h_cur_tables[u] = p->tabs[u].cur;
@@ -463,7 +479,8 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     }
     p->seq += 1;
     HIP_TRY(scd::launch_finalize(p->d_finprods, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide,
-                                 publish_to_host ? p->h_out_dev : nullptr, publish_to_host ? p->h_flag_dev : nullptr, p->seq, p->stream));
+                                 publish_to_host ? p->h_out_dev : nullptr, publish_to_host ? p->h_flag_dev : nullptr, p->seq, scaled,
+                                 p->stream));
     HIP_TRY(hipEventRecord(p->ev1, p->stream));
     p->timed = true;
     p->timing_pending = p->timing;

@@ -1,0 +1,160 @@
+// fe.cuh -- carry-free ("unsaturated") BLS12-381 Fr arithmetic for the big-round kernels on gfx950.
+//
+// Why a second representation.  On gfx950 a v_mad_u64_u32 costs the same issue time as a v_addc_co_u32
+// (profiles/r1_instr_bench.txt: both 1.66x a v_add_u32), and a VALU carry needs two wait states before it can
+// be consumed.  In the saturated 8 x 32-bit Montgomery product (fr.cuh) every one of the 128 multiply-adds
+// drags a carry instruction behind it, and every modular add/sub is three serial carry chains.  Here an element
+// is 9 signed limbs of 29 bits (radix 2^29, value = sum l_i 2^(29 i)): a column of the schoolbook product is at
+// most 9 products below 2^59 plus 9 reduction products below 2^58, which fits a signed 64-bit accumulator, so
+// the whole Montgomery product is 171 v_mad_i64_i32 with NO carry instruction, and add/sub are 9 independent
+// v_add/v_sub (lazy: limbs may leave [0, 2^29), they are renormalised only where a bound requires it).
+//
+// Montgomery radix.  9 x 29 = 261, so fe_mul(a, b) = a*b / 2^261 (mod p), while tables hold the reference's
+// R = 2^256 form.  Multiplying two R-form values therefore yields the R-form product times 2^-5.  The kernels
+// compensate exactly: the bound challenge is pre-multiplied by 2^5 on the host (so r*(hi-lo) lands in R-form
+// and can be added to `lo`), and a product of M multiplicands carries 2^(-5(M-1)), which is folded into that
+// product's coefficient before k_finalize multiplies by it.  Field arithmetic is exact, so the round polynomial
+// is bit-identical to the reference's.
+//
+// Bounds (|limb| of the two operands of fe_mul): one operand <= 2^30 (a normalised value plus one lazy add or
+// sub), the other <= 2^29 (normalised, or a difference of two normalised values).  Then every column is below
+// 9*2^59 + 9*2^58 + carry < 2^63.  Values (not limbs) stay below 2^259 in magnitude, results below 2^257.
+#pragma once
+#include "fr.cuh"
+#include "kernels.h"
+
+namespace scd {
+
+struct Fe {
+    int32_t l[9];
+};
+struct FeU { // wave-uniform (SGPR) element, normalised limbs
+    int32_t l[9];
+};
+
+constexpr int32_t kFeMask = 0x1fffffff;
+
+// p in radix 2^29
+__device__ __forceinline__ constexpr int32_t fe_p_limb(int i) {
+    return i == 0 ? 0x00000001 : i == 1 ? 0x1ffffff8 : i == 2 ? 0x1f96ffbf : i == 3 ? 0x1b4805ff : i == 4 ? 0x1d80553b
+         : i == 5 ? 0x0c0404d0 : i == 6 ? 0x1520cce7 : i == 7 ? 0x0a6533af : 0x0073eda7;
+}
+
+// 8 x u32 (value < 2^256) -> 9 x 29-bit limbs, same value
+__device__ __forceinline__ Fe fe_from_fr(const Fr &a) {
+    // limb i holds bits 29i .. 29i+28 = (word i-1 >> (32 - 3i)) | (word i << 3i), i = 1..7; limb 8 = bits 232..255
+    Fe r;
+    r.l[0] = (int32_t)(a.v[0] & (uint32_t)kFeMask);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) r.l[i] = (int32_t)(((a.v[i - 1] >> (32 - 3 * i)) | (a.v[i] << (3 * i))) & (uint32_t)kFeMask);
+    r.l[8] = (int32_t)(a.v[7] >> 8);
+    return r;
+}
+__device__ __forceinline__ FeU feu_from_host(const FrHost &h) {
+    Fr a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a.v[2 * i] = (uint32_t)h.l[i];
+        a.v[2 * i + 1] = (uint32_t)(h.l[i] >> 32);
+    }
+    const Fe e = fe_from_fr(a);
+    FeU u;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) u.l[i] = e.l[i];
+    return u;
+}
+
+__device__ __forceinline__ Fe fe_zero() {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = 0;
+    return r;
+}
+__device__ __forceinline__ Fe fe_add(const Fe &a, const Fe &b) { // lazy: no carry propagation
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+__device__ __forceinline__ Fe fe_sub(const Fe &a, const Fe &b) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] - b.l[i];
+    return r;
+}
+// carry propagation: limbs 0..7 into [0, 2^29), limb 8 keeps the (signed) rest.  Value unchanged.
+__device__ __forceinline__ Fe fe_normalize(const Fe &a) {
+    Fe r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int32_t t = a.l[i] + c;
+        r.l[i] = t & kFeMask;
+        c = t >> 29; // arithmetic
+    }
+    r.l[8] = a.l[8] + c;
+    return r;
+}
+
+// a * b / 2^261 (mod p), |result value| < 2^257; result limbs 0..7 in [0, 2^29), limb 8 signed and small.
+template <typename B>
+__device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {
+    int64_t acc = 0;
+    int32_t m[9];
+    Fe r;
+#pragma unroll
+    for (int k = 0; k <= 16; ++k) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int j = k - i;
+            if (j >= 0 && j < 9) acc += (int64_t)a.l[i] * (int64_t)b.l[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int l = k - j;
+            if (j < k && l >= 1 && l < 9) acc += (int64_t)m[j] * (int64_t)fe_p_limb(l);
+        }
+        if (k < 9) {
+            m[k] = (int32_t)((0u - (uint32_t)acc) & (uint32_t)kFeMask); // -p^-1 = -1 (mod 2^29)
+            acc += m[k];                                                  // p_0 = 1: clears the low 29 bits
+        } else {
+            r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask);
+        }
+        acc >>= 29; // arithmetic shift: exact because the low 29 bits are zero (k < 9) or were just extracted
+    }
+    r.l[8] = (int32_t)acc;
+    return r;
+}
+__device__ __forceinline__ Fe fe_mul(const Fe &a, const Fe &b) { return fe_mul_t<Fe>(a, b); }
+__device__ __forceinline__ Fe fe_mul_u(const Fe &a, const FeU &u) { return fe_mul_t<FeU>(a, u); }
+
+// Exact canonical conversion: any value with |v| < 2^260 -> the representative in [0, p) as 8 x u32.
+__device__ __forceinline__ Fr fe_to_fr(const Fe &a) {
+    // 1. normalise, estimate the quotient by p from the top limb (= floor(v / 2^232))
+    Fe n = fe_normalize(a);
+    constexpr int32_t PH = 0x0073eda7; // floor(p / 2^232)
+    // q = floor(top / (PH + 1)) for top >= 0, and -(floor((-top - 1) / PH) + 1) for top < 0, by float reciprocal
+    // (|top| < 2^28; the estimate only has to leave a remainder in [0, 2p), the exact step below finishes).
+    const int32_t top = n.l[8];
+    int32_t q;
+    if (top >= 0) q = (int32_t)((uint32_t)top / (uint32_t)(PH + 1));
+    else q = -(int32_t)(((uint32_t)(-top) + (uint32_t)PH - 1u) / (uint32_t)PH);
+    // 2. v -= q * p  (64-bit per limb, then carry-normalise)
+    int64_t c = 0;
+    uint32_t w[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int64_t t = (int64_t)n.l[i] - (int64_t)q * (int64_t)fe_p_limb(i) + c;
+        w[i] = (uint32_t)t & (uint32_t)kFeMask;
+        c = t >> 29;
+        if (i == 8) w[8] = (uint32_t)t; // top limb keeps everything (now in [0, 2^25))
+    }
+    // 3. pack 9 x 29 -> 8 x 32 (value now in [0, 2p + small) < 2^256): word k = (limb k >> 3k) | (limb k+1 << (29 - 3k))
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.v[k] = (w[k] >> (3 * k)) | (w[k + 1] << (29 - 3 * k));
+    // 4. exact: at most two conditional subtractions
+    return fr_reduce_once(fr_reduce_once(r));
+}
+
+} // namespace scd

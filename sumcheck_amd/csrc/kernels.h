@@ -36,6 +36,7 @@ struct FinProd {
     uint32_t pad;
     uint64_t partial_off; // offset (in field elements) of this product's partial sums
     FrHost coeff;
+    FrHost coeff_scaled;  // coeff * 2^(5(M-1)): undoes the 2^-5 per product of the 2^261-radix kernels (fe.cuh)
 };
 
 // table pointers passed by value (kernel argument) for the latency-bound small-round kernels
@@ -57,6 +58,9 @@ int grid_for_pairs(uint64_t n_pairs);
 // product k of one round: partials[blk*(M+1)+t] = sum over this block's pairs of prod_j line_j(t), t = 0..M
 hipError_t launch_prod_round(int M, const ProdArgs &args, const FrHost &r, uint64_t n_pairs, FrHost *d_partials, int grid,
                              hipStream_t stream);
+// the same in carry-free 29-bit-limb arithmetic; r32 = challenge * 2^5, partials carry 2^(-5(M-1))
+hipError_t launch_prod_round_fe(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
+                                hipStream_t stream);
 // generic (any M): tables already bound; slot lists in device memory
 hipError_t launch_sum_generic(const uint4 *const *d_cur_tables, const uint32_t *d_slot_table, const uint32_t *d_slot_exp,
                               int n_slots, int M, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
@@ -70,7 +74,7 @@ hipError_t launch_sum_combos(const TablePtrs &tp, const Combo *d_combos, int n_c
 // combine per-block partials of all products into the round polynomial (D evaluations)
 hipError_t launch_finalize(const FinProd *d_prods, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
                            FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
-                           hipStream_t stream);
+                           int scaled, hipStream_t stream);
 hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);
 hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t n, hipStream_t stream);
 hipError_t launch_fr_elementwise(int op, const uint4 *a, const uint4 *b, const FrHost &u, uint4 *out, uint64_t n, hipStream_t stream);

@@ -16,6 +16,7 @@
 //   Per-lane accumulators -> wave64 shuffle reduction -> LDS across the 4 waves -> one partial per
 //   block -> k_finalize.
 #include "fr.cuh"
+#include "fe.cuh"
 #include "kernels.h"
 
 namespace scd {
@@ -120,6 +121,71 @@ __global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const F
 #pragma unroll
     for (int t = 0; t <= M; ++t) {
         const Fr s = block_sum(acc[t], sm);
+        if (threadIdx.x == 0) fr_store(partials + 2 * ((uint64_t)blockIdx.x * (M + 1) + t), s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 in carry-free arithmetic (fe.cuh): the same fused bind + product-sum, 9 x 29-bit signed limbs.
+// `r32` is the challenge times 2^5 (host), so fe_mul_u(hi - lo, r32) is r*(hi-lo) in the tables' R = 2^256 form;
+// the M-1 products of a term leave the factor 2^(-5(M-1)), which k_finalize removes through the scaled coefficient.
+// ------------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, const FrHost r32_h, const uint64_t n_pairs,
+                                                          uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    const FeU r = feu_from_host(r32_h);
+    Fe acc[M + 1];
+#pragma unroll
+    for (int t = 0; t <= M; ++t) acc[t] = fe_zero();
+
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint32_t iter = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_pairs; b += stride, ++iter) {
+        Fe prod[M + 1];
+        bool first = true;
+        for (int s = 0; s < A.n_slots; ++s) {
+            Fe lo, hi;
+            if (A.slot[s].mode == 0) {
+                const uint4 *p = A.slot[s].src + 4 * b;
+                lo = fe_from_fr(fr_load(p));
+                hi = fe_from_fr(fr_load(p + 2));
+            } else {
+                const uint4 *p = A.slot[s].src + 8 * b;
+                const Fe e0 = fe_from_fr(fr_load(p)), e1 = fe_from_fr(fr_load(p + 2));
+                const Fe e2 = fe_from_fr(fr_load(p + 4)), e3 = fe_from_fr(fr_load(p + 6));
+                const Fe l0 = fe_add(e0, fe_mul_u(fe_sub(e1, e0), r));
+                const Fe h0 = fe_add(e2, fe_mul_u(fe_sub(e3, e2), r));
+                const Fr lc = fe_to_fr(l0), hc = fe_to_fr(h0); // tables stay canonical in the reference layout
+                uint4 *q = A.slot[s].dst + 4 * b;
+                fr_store(q, lc);
+                fr_store(q + 2, hc);
+                lo = fe_from_fr(lc);
+                hi = fe_from_fr(hc);
+            }
+            const Fe step = fe_sub(hi, lo); // limbs in (-2^29, 2^29)
+            const uint32_t e = A.slot[s].exp;
+            Fe cur = lo;
+#pragma unroll
+            for (int t = 0; t <= M; ++t) {
+                if (t == 1) cur = hi;
+                if (t >= 2) cur = fe_normalize(fe_add(cur, step));
+                uint32_t k = 0;
+                if (first) { prod[t] = cur; k = 1; }
+                for (; k < e; ++k) prod[t] = fe_mul(cur, prod[t]);
+            }
+            first = false;
+        }
+#pragma unroll
+        for (int t = 0; t <= M; ++t) acc[t] = fe_normalize(fe_add(acc[t], prod[t]));
+        if ((iter & 31u) == 31u) { // keep the top limb far from 2^31 on very long grid-stride loops
+#pragma unroll
+            for (int t = 0; t <= M; ++t) acc[t] = fe_from_fr(fe_to_fr(acc[t]));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t <= M; ++t) {
+        const Fr s = block_sum(fe_to_fr(acc[t]), sm);
         if (threadIdx.x == 0) fr_store(partials + 2 * ((uint64_t)blockIdx.x * (M + 1) + t), s);
     }
 }
@@ -236,7 +302,8 @@ constexpr int kFinBlock = 1024; // 16 wavefronts: one per (product, point) combi
 __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restrict__ prods, const int K, const int D, const int nblocks,
                                                         const uint4 *__restrict__ partials, uint4 *__restrict__ scratch,
                                                         uint4 *__restrict__ out, uint64_t *__restrict__ out_wide,
-                                                        uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag, const uint32_t seq) {
+                                                        uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag, const uint32_t seq,
+                                                        const int scaled) {
     constexpr int kBlock = kFinBlock; // shadows the 256-thread constant inside this kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // phase 1: one wave per (k,t) combination; two independent accumulators keep two loads in flight per lane
@@ -279,7 +346,8 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
     // phase 3a: scale by the coefficient
     for (int combo = threadIdx.x; combo < K * D; combo += kBlock) {
         const int k = combo / D;
-        const Fr c = fr_from_host(prods[k].coeff);
+        // products summed by k_prod_round_fe carry 2^(-5(M-1)); their coefficient is pre-multiplied by 2^(5(M-1))
+        const Fr c = fr_from_host((scaled && prods[k].M <= (uint32_t)kMaxFusedM) ? prods[k].coeff_scaled : prods[k].coeff);
         fr_store(scratch + 2 * combo, fr_mul(c, fr_load(scratch + 2 * combo)));
     }
     __syncthreads();
@@ -426,6 +494,28 @@ static hipError_t launch_prod_round_t(const ProdArgs &args, const FrHost &r, uin
     return hipGetLastError();
 }
 
+template <int M>
+static hipError_t launch_prod_round_fe_t(const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
+                                         hipStream_t stream) {
+    hipLaunchKernelGGL(k_prod_round_fe<M>, dim3(grid), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_prod_round_fe(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
+                                hipStream_t stream) {
+    switch (M) {
+    case 1: return launch_prod_round_fe_t<1>(args, r32, n_pairs, d_partials, grid, stream);
+    case 2: return launch_prod_round_fe_t<2>(args, r32, n_pairs, d_partials, grid, stream);
+    case 3: return launch_prod_round_fe_t<3>(args, r32, n_pairs, d_partials, grid, stream);
+    case 4: return launch_prod_round_fe_t<4>(args, r32, n_pairs, d_partials, grid, stream);
+    case 5: return launch_prod_round_fe_t<5>(args, r32, n_pairs, d_partials, grid, stream);
+    case 6: return launch_prod_round_fe_t<6>(args, r32, n_pairs, d_partials, grid, stream);
+    case 7: return launch_prod_round_fe_t<7>(args, r32, n_pairs, d_partials, grid, stream);
+    case 8: return launch_prod_round_fe_t<8>(args, r32, n_pairs, d_partials, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_prod_round(int M, const ProdArgs &args, const FrHost &r, uint64_t n_pairs, FrHost *d_partials, int grid,
                              hipStream_t stream) {
     switch (M) {
@@ -460,9 +550,9 @@ hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t 
 
 hipError_t launch_finalize(const FinProd *d_prods, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
                            FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
-                           hipStream_t stream) {
+                           int scaled, hipStream_t stream) {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinBlock), 0, stream, d_prods, K, D, nblocks, (const uint4 *)d_partials,
-                       (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq);
+                       (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq, scaled);
     return hipGetLastError();
 }
 
