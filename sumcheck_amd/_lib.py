@@ -101,6 +101,14 @@ def lib():
             raise ImportError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(sumcheck_amd has no CPU fallback)")
+        # PyTorch-ROCm ships its own libamdhip64.so; two HIP runtimes in one process do not see each other's devices or
+        # allocations.  Loading torch first makes the dynamic loader resolve our libamdhip64.so.N to the copy torch
+        # already mapped, so tensors' device pointers are valid inside the library.  (Pure C / Rust callers never load
+        # torch and use the system runtime.)
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
 #pragma unroll
             for (int t = 0; t <= M; ++t) {
                 if (t == 1) cur = hi;
-                if (t >= 2) cur = fe_normalize(fe_add(cur, step));
+                if (t >= 2) cur = fe_carry_pass(fe_add(cur, step));
                 uint32_t k = 0;
                 if (first) { prod[t] = cur; k = 1; }
                 for (; k < e; ++k) prod[t] = fe_mul(cur, prod[t]);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
             first = false;
         }
 #pragma unroll
-        for (int t = 0; t <= M; ++t) acc[t] = fe_normalize(fe_add(acc[t], prod[t]));
+        for (int t = 0; t <= M; ++t) acc[t] = fe_carry_pass(fe_add(acc[t], prod[t]));
         if ((iter & 31u) == 31u) { // keep the top limb far from 2^31 on very long grid-stride loops
 #pragma unroll
             for (int t = 0; t <= M; ++t) acc[t] = fe_from_fr(fe_to_fr(acc[t]));
