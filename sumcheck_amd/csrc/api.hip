@@ -131,6 +131,7 @@ struct sc_prover {
     void *arena = nullptr;
     FrHost *d_partials = nullptr;
     FinProd *d_finprods = nullptr;
+    FrHost *d_W = nullptr; // node -> message matrices of every product (see FinProd::w_off)
     FrHost *d_scratch = nullptr;
     FrHost *d_out = nullptr;
     FrHost *h_out = nullptr;      // pinned, host-mapped: k_finalize writes the message here directly
@@ -164,6 +165,7 @@ static void prover_destroy(sc_prover *p) {
     if (p->arena) (void)hipFree(p->arena);
     if (p->d_partials) (void)hipFree(p->d_partials);
     if (p->d_finprods) (void)hipFree(p->d_finprods);
+    if (p->d_W) (void)hipFree(p->d_W);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
     if (p->d_out) (void)hipFree(p->d_out);
     if (p->h_out) (void)hipHostFree(p->h_out);
@@ -201,6 +203,44 @@ static int validate_desc(const sc_poly_desc *d) {
     return SC_OK;
 }
 
+static sch::Fr fr_small(int64_t v) { return v >= 0 ? sch::from_u64((uint64_t)v) : sch::neg(sch::from_u64((uint64_t)(-v))); }
+
+// (deg+1) x (M+1) matrix taking a degree-M polynomial's values at the kernel nodes (scd::node_value: 0, 1, inf, -1, 2, ...)
+// to its values at 0..deg, times `scale`.  Exact Lagrange weights in the field; "inf" is the leading coefficient L:
+// P(t) = L t^M + sum_i (P(x_i) - L x_i^M) l_i(t) over the M finite nodes.
+static void build_node_matrix(uint32_t M, uint32_t D, const sch::Fr &scale, std::vector<sch::Fr> &out) {
+    std::vector<int64_t> xs;
+    std::vector<uint32_t> fin;
+    int inf_col = -1;
+    for (uint32_t s = 0; s <= M; ++s) {
+        const int32_t nv = scd::node_value((int)s);
+        if (nv == scd::kNodeInf) inf_col = (int)s;
+        else fin.push_back(s);
+        xs.push_back(nv);
+    }
+    out.assign((size_t)D * (M + 1), sch::zero());
+    for (uint32_t t = 0; t < D; ++t) {
+        sch::Fr inf_w = sch::kOne; // t^M
+        for (uint32_t e = 0; e < M; ++e) inf_w = sch::mul(inf_w, fr_small(t));
+        for (uint32_t s : fin) {
+            sch::Fr num = sch::kOne, den = sch::kOne;
+            for (uint32_t j : fin) {
+                if (j == s) continue;
+                num = sch::mul(num, fr_small((int64_t)t - xs[j]));
+                den = sch::mul(den, fr_small(xs[s] - xs[j]));
+            }
+            const sch::Fr l = sch::mul(num, sch::inverse(den));
+            out[(size_t)t * (M + 1) + s] = sch::mul(scale, l);
+            if (inf_col >= 0) {
+                sch::Fr xm = sch::kOne;
+                for (uint32_t e = 0; e < M; ++e) xm = sch::mul(xm, fr_small(xs[s]));
+                inf_w = sch::sub(inf_w, sch::mul(xm, l));
+            }
+        }
+        if (inf_col >= 0) out[(size_t)t * (M + 1) + inf_col] = sch::mul(scale, inf_w);
+    }
+}
+
 static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
     p->device = g_device;
@@ -222,6 +262,7 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     std::vector<uint32_t> slot_table, slot_exp;
     std::vector<FinProd> fin(p->K);
     std::vector<Combo> combos;
+    std::vector<sch::Fr> Wall;
     for (uint32_t k = 0; k < p->K; ++k) {
         Product pr;
         std::memcpy(&pr.coeff, d->coeffs + 4 * k, 32);
@@ -247,11 +288,15 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
         fin[k].M = pr.M;
         fin[k].pad = 0;
         fin[k].partial_off = pr.partial_off;
-        fin[k].coeff = to_dev(pr.coeff);
         {
             sch::Fr sc = pr.coeff; // coeff * 2^(5(M-1)) in Montgomery form = Montgomery form doubled 5(M-1) times
-            for (uint32_t d = 0; d < 5 * (pr.M - 1); ++d) sc = sch::add(sc, sc);
-            fin[k].coeff_scaled = to_dev(sc);
+            for (uint32_t dbl = 0; dbl < 5 * (pr.M - 1); ++dbl) sc = sch::add(sc, sc);
+            std::vector<sch::Fr> w;
+            fin[k].w_off = Wall.size();
+            build_node_matrix(pr.M, p->D, pr.coeff, w);
+            Wall.insert(Wall.end(), w.begin(), w.end());
+            build_node_matrix(pr.M, p->D, sc, w);
+            Wall.insert(Wall.end(), w.begin(), w.end());
         }
         for (uint32_t t = 0; t <= pr.M; ++t) {
             Combo c;
@@ -294,6 +339,8 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     HIP_TRY(hipMalloc(&p->d_partials, std::max<uint64_t>(partial_elems, 1) * 32));
     HIP_TRY(hipMalloc(&p->d_finprods, std::max<size_t>(p->K, 1) * sizeof(FinProd)));
     if (p->K) HIP_TRY(hipMemcpyAsync(p->d_finprods, fin.data(), p->K * sizeof(FinProd), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipMalloc(&p->d_W, std::max<size_t>(Wall.size(), 1) * 32));
+    if (!Wall.empty()) HIP_TRY(hipMemcpyAsync(p->d_W, Wall.data(), Wall.size() * 32, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMalloc(&p->d_scratch, (size_t)2 * std::max<uint32_t>(p->K, 1) * p->D * 32));
     HIP_TRY(hipMalloc(&p->d_out, (size_t)p->D * 32));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_out), (size_t)p->D * 32, hipHostMallocMapped | hipHostMallocCoherent));
@@ -478,7 +525,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
             if (!bound[u]) HIP_TRY(bind_table(u));
     }
     p->seq += 1;
-    HIP_TRY(scd::launch_finalize(p->d_finprods, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide,
+    HIP_TRY(scd::launch_finalize(p->d_finprods, p->d_W, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide,
                                  publish_to_host ? p->h_out_dev : nullptr, publish_to_host ? p->h_flag_dev : nullptr, p->seq, scaled,
                                  p->stream));
     HIP_TRY(hipEventRecord(p->ev1, p->stream));

@@ -15,6 +15,16 @@ struct FrHost {
     uint64_t l[4];
 };
 
+// Evaluation nodes of a product's round polynomial, in the order the kernels use them: 0, 1, inf, -1, 2, -2, 3, ...
+// A product with M multiplicands is evaluated at the first M+1 of them.  "inf" is the leading coefficient
+// (the product of the slopes), whose operand -- the slope hi-lo -- is needed anyway; -1 and 2 are one lazy
+// add away from the table entries.  k_finalize maps the M+1 sums to the message's points 0..deg with a
+// host-computed (deg+1) x (M+1) matrix (exact Lagrange weights), so any node set gives the same canonical bits.
+constexpr int32_t kNodeInf = 0x7fffffff;
+__host__ __device__ constexpr int32_t node_value(int s) {
+    return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? kNodeInf : ((s - 3) % 2 == 0 ? -((s - 3) / 2 + 1) : ((s - 3) / 2 + 2));
+}
+
 // One distinct table of a product.  mode 0: `src` already holds this round's table (2*n_pairs entries).
 // mode 1: `src` holds the previous round's table (4*n_pairs entries); the kernel binds the previous
 // challenge on the fly, writes this round's table (2*n_pairs entries) to `dst`, and sums from registers.
@@ -35,8 +45,9 @@ struct FinProd {
     uint32_t M;           // multiplicands = degree of this product's round polynomial
     uint32_t pad;
     uint64_t partial_off; // offset (in field elements) of this product's partial sums
-    FrHost coeff;
-    FrHost coeff_scaled;  // coeff * 2^(5(M-1)): undoes the 2^-5 per product of the 2^261-radix kernels (fe.cuh)
+    uint64_t w_off;       // offset (in field elements) of this product's node->message matrices in d_W:
+                          //   [w_off, +D*(M+1))            c_k * W          (partials in the tables' R = 2^256 form)
+                          //   [w_off + D*(M+1), +D*(M+1))  c_k * 2^(5(M-1)) * W  (partials from the 2^261-radix kernels, fe.cuh)
 };
 
 // table pointers passed by value (kernel argument) for the latency-bound small-round kernels
@@ -72,7 +83,7 @@ hipError_t launch_fix_multi(const TablePtrs &tp, int n_tables, const FrHost &r, 
 hipError_t launch_sum_combos(const TablePtrs &tp, const Combo *d_combos, int n_combos, const uint32_t *d_slot_table,
                              const uint32_t *d_slot_exp, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
 // combine per-block partials of all products into the round polynomial (D evaluations)
-hipError_t launch_finalize(const FinProd *d_prods, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
+hipError_t launch_finalize(const FinProd *d_prods, const FrHost *d_W, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
                            FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
                            int scaled, hipStream_t stream);
 hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);

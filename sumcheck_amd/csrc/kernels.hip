@@ -41,6 +41,12 @@ __device__ __forceinline__ FrU fru_from_host(const FrHost &h) {
     return r;
 }
 
+// Montgomery form of a (small, signed) evaluation node
+__device__ __forceinline__ Fr node_constant(int32_t nv) {
+    if (nv == kNodeInf) return fr_zero();
+    return nv >= 0 ? fr_from_u32((uint32_t)nv) : fr_neg(fr_from_u32((uint32_t)(-nv)));
+}
+
 __device__ __forceinline__ Fr fr_shfl_down(const Fr &a, int off) {
     Fr r;
 #pragma unroll
@@ -104,11 +110,16 @@ __global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const F
             }
             const Fr step = fr_sub(hi, lo);
             const uint32_t e = A.slot[s].exp;
-            Fr cur = lo;
+            Fr curP = hi, curN = lo; // walking outwards from 1 and 0 along the line
 #pragma unroll
             for (int t = 0; t <= M; ++t) {
-                if (t == 1) cur = hi;
-                if (t >= 2) cur = fr_add(cur, step);
+                const int32_t nv = node_value(t);
+                Fr cur;
+                if (nv == 0) cur = lo;
+                else if (nv == 1) cur = hi;
+                else if (nv == kNodeInf) cur = step;
+                else if (nv < 0) { curN = fr_sub(curN, step); cur = curN; }
+                else { curP = fr_add(curP, step); cur = curP; }
                 uint32_t k = 0;
                 if (first) { prod[t] = cur; k = 1; }
                 for (; k < e; ++k) prod[t] = fr_mul(prod[t], cur);
@@ -165,13 +176,23 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
             }
             const Fe step = fe_sub(hi, lo); // limbs in (-2^29, 2^29)
             const uint32_t e = A.slot[s].exp;
-            Fe cur = lo;
+            Fe curP = hi, curN = lo;
 #pragma unroll
             for (int t = 0; t <= M; ++t) {
-                if (t == 1) cur = hi;
-                if (t >= 2) cur = fe_carry_pass(fe_add(cur, step));
+                const int32_t nv = node_value(t);
+                Fe cur;
+                if (nv == 0) cur = lo;
+                else if (nv == 1) cur = hi;
+                else if (nv == kNodeInf) cur = step;
+                else if (nv < 0) { // -1 = 2lo - hi is within the 2^30 limb bound as is; further out re-tighten first
+                    curN = (nv == -1) ? fe_sub(curN, step) : fe_sub(fe_carry_pass(curN), step);
+                    cur = curN;
+                } else {
+                    curP = (nv == 2) ? fe_add(curP, step) : fe_add(fe_carry_pass(curP), step);
+                    cur = curP;
+                }
                 uint32_t k = 0;
-                if (first) { prod[t] = cur; k = 1; }
+                if (first) { prod[t] = (nv == 0 || nv == 1) ? cur : fe_carry_pass(cur); k = 1; }
                 for (; k < e; ++k) prod[t] = fe_mul(cur, prod[t]);
             }
             first = false;
@@ -199,7 +220,8 @@ __global__ __launch_bounds__(kBlock) void k_sum_generic(const uint4 *const *__re
                                                         const uint64_t n_pairs, uint4 *__restrict__ partials) {
     __shared__ uint32_t sm[kBlock / 64][8];
     const uint32_t t = blockIdx.y;
-    const Fr tf = fr_from_u32(t);
+    const int32_t nv = node_value((int)t);
+    const Fr tf = node_constant(nv);
     Fr acc = fr_zero();
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_pairs; b += stride) {
@@ -208,8 +230,9 @@ __global__ __launch_bounds__(kBlock) void k_sum_generic(const uint4 *const *__re
             const uint4 *p = cur_tables[slot_table[s]] + 4 * b;
             const Fr lo = fr_load(p), hi = fr_load(p + 2);
             Fr val;
-            if (t == 0) val = lo;
-            else if (t == 1) val = hi;
+            if (nv == 0) val = lo;
+            else if (nv == 1) val = hi;
+            else if (nv == kNodeInf) val = fr_sub(hi, lo);
             else val = fr_add(lo, fr_mul(tf, fr_sub(hi, lo)));
             for (uint32_t k = 0; k < slot_exp[s]; ++k) prod = fr_mul(prod, val);
         }
@@ -266,7 +289,8 @@ __global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const
     __shared__ uint32_t sm[kBlock / 64][8];
     const Combo c = combos[blockIdx.y];
     const uint32_t t = c.t;
-    const Fr tf = fr_from_u32(t);
+    const int32_t nv = node_value((int)t);
+    const Fr tf = node_constant(nv);
     Fr acc = fr_zero();
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_pairs; b += stride) {
@@ -275,11 +299,11 @@ __global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const
         for (uint32_t s = 0; s < c.n_slots; ++s) {
             const uint4 *p = tp.src[slot_table[c.slot_off + s]] + 4 * b;
             Fr val;
-            if (t == 0) val = fr_load(p);
-            else if (t == 1) val = fr_load(p + 2);
+            if (nv == 0) val = fr_load(p);
+            else if (nv == 1) val = fr_load(p + 2);
             else {
                 const Fr lo = fr_load(p), hi = fr_load(p + 2);
-                val = fr_add(lo, fr_mul(fr_sub(hi, lo), tf));
+                val = (nv == kNodeInf) ? fr_sub(hi, lo) : fr_add(lo, fr_mul(fr_sub(hi, lo), tf));
             }
             uint32_t k = 0;
             if (first) { prod = val; k = 1; first = false; }
@@ -294,19 +318,19 @@ __global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const
 // ------------------------------------------------------------------------------------------------
 // Finalize: per-block partials of every product -> the round's ProverMsg (D = deg+1 evaluations).
 //   phase 1  S_k[t] = sum over blocks of partial_k[blk][t]                       (t <= M_k)
-//   phase 2  extend S_k to t = M_k+1 .. D-1 by forward differences (additions only)
-//   phase 3  out[t] = sum_k c_k * S_k[t]
+//   phase 2  P_k(t) for the message points t = 0..D-1 = sum_s (c_k W_k)[t][s] S_k[s]   (host-computed Lagrange weights)
+//   phase 3  out[t] = sum_k P_k(t)
 // One block of 256 threads; everything here is O(K*D) field operations.
 // ------------------------------------------------------------------------------------------------
 constexpr int kFinBlock = 1024; // 16 wavefronts: one per (product, point) combination for typical shapes
-__global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restrict__ prods, const int K, const int D, const int nblocks,
-                                                        const uint4 *__restrict__ partials, uint4 *__restrict__ scratch,
+__global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restrict__ prods, const uint4 *__restrict__ Wm, const int K, const int D,
+                                                        const int nblocks, const uint4 *__restrict__ partials, uint4 *__restrict__ scratch,
                                                         uint4 *__restrict__ out, uint64_t *__restrict__ out_wide,
                                                         uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag, const uint32_t seq,
                                                         const int scaled) {
     constexpr int kBlock = kFinBlock; // shadows the 256-thread constant inside this kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // phase 1: one wave per (k,t) combination; two independent accumulators keep two loads in flight per lane
+    // phase 1: one wave per (product, node) combination; two independent accumulators keep two loads in flight per lane
     for (int combo = wave; combo < K * D; combo += kBlock / 64) {
         const int k = combo / D, t = combo % D;
         const int M = (int)prods[k].M;
@@ -327,34 +351,22 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
         if (lane == 0) fr_store(scratch + 2 * (k * D + t), acc);
     }
     __syncthreads();
-    // phase 2: thread k extends product k (trailing forward differences, in place on a copy)
-    for (int k = threadIdx.x; k < K; k += kBlock) {
-        const int M = (int)prods[k].M;
-        if (M + 1 >= D) continue;
-        uint4 *S = scratch + 2 * (k * D);
-        uint4 *W = scratch + 2 * ((K + k) * D); // work area: M+1 trailing differences
-        for (int i = 0; i <= M; ++i) fr_store(W + 2 * i, fr_load(S + 2 * i));
-        for (int l = 1; l <= M; ++l)
-            for (int i = 0; i <= M - l; ++i) fr_store(W + 2 * i, fr_sub(fr_load(W + 2 * (i + 1)), fr_load(W + 2 * i)));
-        // W[M-l] = l-th difference ending at y_M; W[M] = y_M
-        for (int t = M + 1; t < D; ++t) {
-            for (int i = 1; i <= M; ++i) fr_store(W + 2 * i, fr_add(fr_load(W + 2 * i), fr_load(W + 2 * (i - 1))));
-            fr_store(S + 2 * t, fr_load(W + 2 * M));
-        }
-    }
-    __syncthreads();
-    // phase 3a: scale by the coefficient
+    // phase 2: thread (k, t): message point t of product k = sum_s (c_k W_k)[t][s] * S_k[s]
     for (int combo = threadIdx.x; combo < K * D; combo += kBlock) {
-        const int k = combo / D;
-        // products summed by k_prod_round_fe carry 2^(-5(M-1)); their coefficient is pre-multiplied by 2^(5(M-1))
-        const Fr c = fr_from_host((scaled && prods[k].M <= (uint32_t)kMaxFusedM) ? prods[k].coeff_scaled : prods[k].coeff);
-        fr_store(scratch + 2 * combo, fr_mul(c, fr_load(scratch + 2 * combo)));
+        const int k = combo / D, t = combo % D;
+        const int M = (int)prods[k].M;
+        // partials from the 2^261-radix kernels carry 2^(-5(M-1)); the second copy of the matrix undoes it
+        const uint64_t woff = prods[k].w_off + ((scaled && M <= kMaxFusedM) ? (uint64_t)D * (M + 1) : 0);
+        const uint4 *Wk = Wm + 2 * (woff + (uint64_t)t * (M + 1));
+        Fr acc = fr_zero();
+        for (int sN = 0; sN <= M; ++sN) acc = fr_add(acc, fr_mul(fr_load(Wk + 2 * sN), fr_load(scratch + 2 * (k * D + sN))));
+        fr_store(scratch + 2 * ((K + k) * D + t), acc);
     }
     __syncthreads();
     // phase 3b: sum over products
     for (int t = threadIdx.x; t < D; t += kBlock) {
         Fr acc = fr_zero();
-        for (int k = 0; k < K; ++k) acc = fr_add(acc, fr_load(scratch + 2 * (k * D + t)));
+        for (int k = 0; k < K; ++k) acc = fr_add(acc, fr_load(scratch + 2 * ((K + k) * D + t)));
         if (out) fr_store(out + 2 * t, acc);
         if (h_out) fr_store(h_out + 2 * t, acc); // host-mapped pinned memory: the message lands on the host without a copy
         if (out_wide) {
@@ -548,10 +560,10 @@ hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t 
     return hipGetLastError();
 }
 
-hipError_t launch_finalize(const FinProd *d_prods, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
+hipError_t launch_finalize(const FinProd *d_prods, const FrHost *d_W, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
                            FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
                            int scaled, hipStream_t stream) {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinBlock), 0, stream, d_prods, K, D, nblocks, (const uint4 *)d_partials,
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinBlock), 0, stream, d_prods, (const uint4 *)d_W, K, D, nblocks, (const uint4 *)d_partials,
                        (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq, scaled);
     return hipGetLastError();
 }
