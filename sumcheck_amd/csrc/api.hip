@@ -148,6 +148,7 @@ struct sc_prover {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     bool use_fe = true; // big rounds in carry-free arithmetic (fe.cuh); SC_FE=0 selects the saturated kernels
+    int kernel_variant = 2; // SC_KERNEL: 0 = lane-per-pair (k_prod_round[_fe]), 2 = tiled LDS-staged (k_round_tile)
     // reset support + per-product instrumentation
     bool borrow = false;
     std::vector<const uint4 *> origin; // borrowed table pointers (borrow mode)
@@ -256,6 +257,7 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     p->U = d->n_tables;
     p->randomness.reserve(p->nv);
     if (const char *e = std::getenv("SC_FE")) p->use_fe = std::atoi(e) != 0;
+    if (const char *e = std::getenv("SC_KERNEL")) p->kernel_variant = std::atoi(e);
 
     // products: distinct tables + multiplicities
     uint64_t partial_elems = 0;
@@ -432,7 +434,9 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     for (int d = 0; d < 5; ++d) r32v = sch::add(r32v, r32v);
     const FrHost r32 = to_dev(r32v);
     int scaled = 0;
-    const int grid = scd::grid_for_pairs(n_pairs);
+    const bool small_round = n_pairs <= scd::kSmallRoundPairs && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0;
+    const bool tiled = !small_round && !p->any_generic && p->kernel_variant == 2;
+    const int grid = tiled ? scd::grid_for_tiles(n_pairs) : scd::grid_for_pairs(n_pairs);
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
 
     auto bind_table = [&](uint32_t u) -> hipError_t { // stand-alone bind of table u (2*n_pairs outputs)
@@ -444,7 +448,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         return e;
     };
 
-    const bool small = n_pairs <= scd::kSmallRoundPairs && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0;
+    const bool small = small_round;
     if (small) {
         // latency-bound round: one launch binds every table, one launch sums every (product, point) combination
         TablePtrs tp;
@@ -503,7 +507,10 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
                     a.slot[s].dst = nullptr;
                 }
             }
-            if (p->use_fe) {
+            if (tiled) {
+                HIP_TRY(scd::launch_round_tile((int)pr.M, a, r32, n_pairs, partials, grid, p->stream));
+                scaled = 1;
+            } else if (p->use_fe) {
                 HIP_TRY(scd::launch_prod_round_fe((int)pr.M, a, r32, n_pairs, partials, grid, p->stream));
                 scaled = 1;
             } else {

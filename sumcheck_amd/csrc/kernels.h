@@ -72,6 +72,10 @@ hipError_t launch_prod_round(int M, const ProdArgs &args, const FrHost &r, uint6
 // the same in carry-free 29-bit-limb arithmetic; r32 = challenge * 2^5, partials carry 2^(-5(M-1))
 hipError_t launch_prod_round_fe(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
                                 hipStream_t stream);
+// tiled variant (LDS-staged, one wavefront per node): grid from grid_for_tiles, same partial layout and scaling as _fe
+int grid_for_tiles(uint64_t n_pairs);
+hipError_t launch_round_tile(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
+                             hipStream_t stream);
 // generic (any M): tables already bound; slot lists in device memory
 hipError_t launch_sum_generic(const uint4 *const *d_cur_tables, const uint32_t *d_slot_table, const uint32_t *d_slot_exp,
                               int n_slots, int M, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);

@@ -212,6 +212,107 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// K4, tiled: the fused bind + product-sum with fine-grained work items staged through LDS.
+//
+// k_prod_round / k_prod_round_fe give one lane a whole pair: 2 binds and M-1 products for each of M+1 nodes in one
+// dependent chain behind ~200 live VGPRs, so only 2-3 waves fit a SIMD and the VALU idles ~45 % of the time
+// (profiles: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = 0.40-0.50).  Here a block of 64*(M+1) threads walks tiles of 64
+// pairs in two phases:
+//   A  one lane per (table slot, entry): load (bind mode: two adjacent entries of the previous table, 64 contiguous
+//      bytes per lane, bind r, store the bound entry to HBM), convert to 29-bit limbs and park it in LDS
+//      (limb-planar: lane i writes dword i of every limb row -> conflict-free);
+//   B  one wavefront per evaluation node, one lane per pair: read (lo, hi) of every slot from LDS with ds_read_b64,
+//      form the node's operand (0: lo, 1: hi, inf: hi-lo, -1: 2lo-hi, 2: 2hi-lo, ... all lazy adds) and multiply the
+//      M factors; accumulate the lane's running sum for that node across tiles.
+// Each lane holds one accumulator and one operand set (~80 VGPRs -> 5-6 waves per SIMD) and the longest dependent
+// chain is M-1 products.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTilePairs = 64;
+
+template <int M>
+__global__ __launch_bounds__(64 * (M + 1)) void k_round_tile(const ProdArgs A, const FrHost r32_h, const uint64_t n_pairs,
+                                                             uint4 *__restrict__ partials) {
+    constexpr int kThreads = 64 * (M + 1);
+    constexpr int kEnt = 2 * kTilePairs; // entries per slot per tile
+    __shared__ int32_t lds[M * 9 * kEnt]; // [slot][limb][entry]
+    const FeU r = feu_from_host(r32_h);
+    const int tid = threadIdx.x;
+    const int node_idx = tid >> 6; // one wavefront per node
+    const int lane = tid & 63;
+    const int32_t nv = node_value(node_idx);
+    const int n_slots = A.n_slots;
+    Fe acc = fe_zero();
+    const uint64_t n_tiles = (n_pairs + kTilePairs - 1) / kTilePairs;
+    uint32_t iter = 0;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++iter) {
+        const uint64_t b0 = tile * kTilePairs;            // first pair of the tile
+        const uint64_t ent_left = 2 * (n_pairs - b0);     // valid entries in this tile (>= 2)
+        // ---- phase A: stage every slot's 128 entries -------------------------------------------------------
+        for (int item = tid; item < n_slots * kEnt; item += kThreads) {
+            const int s = item / kEnt, i = item % kEnt; // entry i of the tile = table entry 2*b0 + i
+            Fe v = fe_zero();
+            if ((uint64_t)i < ent_left) {
+                if (A.slot[s].mode == 0) {
+                    v = fe_from_fr(fr_load(A.slot[s].src + 2 * (2 * b0 + i)));
+                } else {
+                    const uint4 *p = A.slot[s].src + 4 * (2 * b0 + i); // previous-table entries 2e, 2e+1: 64 contiguous bytes
+                    const Fe e0 = fe_from_fr(fr_load(p)), e1 = fe_from_fr(fr_load(p + 2));
+                    const Fr c = fe_to_fr(fe_add(e0, fe_mul_u(fe_sub(e1, e0), r)));
+                    fr_store(A.slot[s].dst + 2 * (2 * b0 + i), c); // tables stay canonical in the reference layout
+                    v = fe_from_fr(c);
+                }
+            }
+            int32_t *row = lds + (s * 9) * kEnt + i;
+#pragma unroll
+            for (int l = 0; l < 9; ++l) row[l * kEnt] = v.l[l];
+        }
+        __syncthreads();
+        // ---- phase B: this wavefront's node, this lane's pair ------------------------------------------------
+        {
+            Fe prod;
+            bool first = true;
+            for (int s = 0; s < n_slots; ++s) {
+                Fe lo, hi;
+                const int32_t *row = lds + (s * 9) * kEnt + 2 * lane;
+#pragma unroll
+                for (int l = 0; l < 9; ++l) {
+                    const int2 w = *reinterpret_cast<const int2 *>(row + l * kEnt);
+                    lo.l[l] = w.x;
+                    hi.l[l] = w.y;
+                }
+                Fe val;
+                if (nv == 0) val = lo;
+                else if (nv == 1) val = hi;
+                else if (nv == kNodeInf) val = fe_sub(hi, lo);
+                else if (nv == -1) val = fe_sub(fe_add(lo, lo), hi);
+                else if (nv == 2) val = fe_sub(fe_add(hi, hi), lo);
+                else { // further out: walk along the line, re-tightening the limbs before every step
+                    const Fe step = fe_sub(hi, lo);
+                    if (nv > 0) {
+                        val = fe_sub(fe_add(hi, hi), lo);
+                        for (int32_t c = 2; c < nv; ++c) val = fe_add(fe_carry_pass(val), step);
+                    } else {
+                        val = fe_sub(fe_add(lo, lo), hi);
+                        for (int32_t c = -1; c > nv; --c) val = fe_sub(fe_carry_pass(val), step);
+                    }
+                }
+                uint32_t k = 0;
+                if (first) { prod = (nv == 0 || nv == 1) ? val : fe_carry_pass(val); k = 1; first = false; }
+                for (; k < A.slot[s].exp; ++k) prod = fe_mul(val, prod);
+            }
+            if (b0 + lane < n_pairs) acc = fe_carry_pass(fe_add(acc, prod));
+            if ((iter & 31u) == 31u) acc = fe_from_fr(fe_to_fr(acc));
+        }
+        __syncthreads(); // LDS is overwritten by the next tile
+    }
+    // wavefront reduction of this node's sums, one partial per block
+    Fr sum = fe_to_fr(acc);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum = fr_add(sum, fr_shfl_down(sum, off));
+    if (lane == 0) fr_store(partials + 2 * ((uint64_t)blockIdx.x * (M + 1) + node_idx), sum);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Generic product-sum (any number of multiplicands): grid.y = evaluation point t, tables already bound.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_sum_generic(const uint4 *const *__restrict__ cur_tables,
@@ -524,6 +625,35 @@ hipError_t launch_prod_round_fe(int M, const ProdArgs &args, const FrHost &r32, 
     case 6: return launch_prod_round_fe_t<6>(args, r32, n_pairs, d_partials, grid, stream);
     case 7: return launch_prod_round_fe_t<7>(args, r32, n_pairs, d_partials, grid, stream);
     case 8: return launch_prod_round_fe_t<8>(args, r32, n_pairs, d_partials, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int M>
+static hipError_t launch_round_tile_t(const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
+                                      hipStream_t stream) {
+    hipLaunchKernelGGL(k_round_tile<M>, dim3(grid), dim3(64 * (M + 1)), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
+    return hipGetLastError();
+}
+
+int grid_for_tiles(uint64_t n_pairs) {
+    uint64_t g = (n_pairs + kTilePairs - 1) / kTilePairs;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)kMaxGrid) g = kMaxGrid;
+    return (int)g;
+}
+
+hipError_t launch_round_tile(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
+                             hipStream_t stream) {
+    switch (M) {
+    case 1: return launch_round_tile_t<1>(args, r32, n_pairs, d_partials, grid, stream);
+    case 2: return launch_round_tile_t<2>(args, r32, n_pairs, d_partials, grid, stream);
+    case 3: return launch_round_tile_t<3>(args, r32, n_pairs, d_partials, grid, stream);
+    case 4: return launch_round_tile_t<4>(args, r32, n_pairs, d_partials, grid, stream);
+    case 5: return launch_round_tile_t<5>(args, r32, n_pairs, d_partials, grid, stream);
+    case 6: return launch_round_tile_t<6>(args, r32, n_pairs, d_partials, grid, stream);
+    case 7: return launch_round_tile_t<7>(args, r32, n_pairs, d_partials, grid, stream);
+    case 8: return launch_round_tile_t<8>(args, r32, n_pairs, d_partials, grid, stream);
     default: return hipErrorInvalidValue;
     }
 }
