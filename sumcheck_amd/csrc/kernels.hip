@@ -102,8 +102,10 @@ __global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const F
             } else {
                 const uint4 *p = A.slot[s].src + 8 * b; // entries 4b..4b+3 = 128 contiguous bytes
                 const Fr e0 = fr_load(p), e1 = fr_load(p + 2), e2 = fr_load(p + 4), e3 = fr_load(p + 6);
-                lo = fr_add(e0, fr_mul_u(fr_sub(e1, e0), r));
-                hi = fr_add(e2, fr_mul_u(fr_sub(e3, e2), r));
+                Fr ml, mh; // the two binds of a pair are independent: interleave their instruction streams
+                fr_mul2_comba_u(fr_sub(e1, e0), r, fr_sub(e3, e2), r, ml, mh);
+                lo = fr_add(e0, ml);
+                hi = fr_add(e2, mh);
                 uint4 *q = A.slot[s].dst + 4 * b;
                 fr_store(q, lo);
                 fr_store(q + 2, hi);
@@ -111,18 +113,26 @@ __global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const F
             const Fr step = fr_sub(hi, lo);
             const uint32_t e = A.slot[s].exp;
             Fr curP = hi, curN = lo; // walking outwards from 1 and 0 along the line
+            Fr cur[M + 1];
 #pragma unroll
             for (int t = 0; t <= M; ++t) {
                 const int32_t nv = node_value(t);
-                Fr cur;
-                if (nv == 0) cur = lo;
-                else if (nv == 1) cur = hi;
-                else if (nv == kNodeInf) cur = step;
-                else if (nv < 0) { curN = fr_sub(curN, step); cur = curN; }
-                else { curP = fr_add(curP, step); cur = curP; }
-                uint32_t k = 0;
-                if (first) { prod[t] = cur; k = 1; }
-                for (; k < e; ++k) prod[t] = fr_mul(prod[t], cur);
+                if (nv == 0) cur[t] = lo;
+                else if (nv == 1) cur[t] = hi;
+                else if (nv == kNodeInf) cur[t] = step;
+                else if (nv < 0) { curN = fr_sub(curN, step); cur[t] = curN; }
+                else { curP = fr_add(curP, step); cur[t] = curP; }
+            }
+            uint32_t k = 0;
+            if (first) {
+#pragma unroll
+                for (int t = 0; t <= M; ++t) prod[t] = cur[t];
+                k = 1;
+            }
+            for (; k < e; ++k) { // nodes in pairs: two independent Montgomery products per asm stream
+#pragma unroll
+                for (int t = 0; t + 1 <= M; t += 2) fr_mul2_comba(prod[t], cur[t], prod[t + 1], cur[t + 1], prod[t], prod[t + 1]);
+                if ((M + 1) % 2 == 1) prod[M] = fr_mul(prod[M], cur[M]);
             }
             first = false;
         }
@@ -543,6 +553,11 @@ __global__ __launch_bounds__(kBlock) void k_bench_modmul(const uint32_t reps, co
         for (uint32_t k = 0; k < reps; ++k) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) x[c] = fr_mul_comba(x[c], y);
+        }
+    } else if (variant == 4) {
+        for (uint32_t k = 0; k < reps; ++k) {
+            fr_mul2_comba(x[0], y, x[1], y, x[0], x[1]);
+            fr_mul2_comba(x[2], y, x[3], y, x[2], x[3]);
         }
     } else if (variant == 3) {
         FrU u;
