@@ -148,7 +148,7 @@ struct sc_prover {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     bool use_fe = true; // big rounds in carry-free arithmetic (fe.cuh); SC_FE=0 selects the saturated kernels
-    int kernel_variant = 2; // SC_KERNEL: 0 = lane-per-pair (k_prod_round[_fe]), 2 = tiled LDS-staged (k_round_tile)
+    int kernel_variant = 3; // SC_KERNEL: 0 = lane-per-pair (k_prod_round[_fe]), 2 = tiled LDS-staged (k_round_tile), 3 = product tree
     // reset support + per-product instrumentation
     bool borrow = false;
     std::vector<const uint4 *> origin; // borrowed table pointers (borrow mode)
@@ -487,10 +487,46 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         const Product &pr = p->prods[k];
         FrHost *partials = p->d_partials + pr.partial_off;
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[2 * k], p->stream));
-        if (pr.fused) {
+        if (pr.fused && p->kernel_variant == 3 && pr.M <= 4) {
+            // product tree: one argument slot per FACTOR.  The first factor touching a table this round binds and stores it;
+            // a repeat inside the same product re-binds from the old table without storing (mode 3).
+            ProdArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.n_slots = (int)pr.M;
+            if (const char *e = std::getenv("SC_DEBUG")) a.debug = std::atoi(e);
+            int f = 0;
+            for (size_t s = 0; s < pr.tables.size(); ++s) {
+                Table &t = p->tabs[pr.tables[s]];
+                const uint4 *old_src = t.cur;
+                bool stored_here = false;
+                for (uint32_t rep = 0; rep < pr.exps[s]; ++rep, ++f) {
+                    a.slot[f].exp = 1;
+                    if (bind && !bound[pr.tables[s]]) {
+                        a.slot[f].mode = 1;
+                        a.slot[f].src = old_src;
+                        a.slot[f].dst = t.buf[t.next];
+                        t.cur = t.buf[t.next];
+                        t.next ^= 1;
+                        bound[pr.tables[s]] = 1;
+                        stored_here = true;
+                    } else if (stored_here) {
+                        a.slot[f].mode = 3;
+                        a.slot[f].src = old_src;
+                        a.slot[f].dst = nullptr;
+                    } else {
+                        a.slot[f].mode = 0;
+                        a.slot[f].src = t.cur;
+                        a.slot[f].dst = nullptr;
+                    }
+                }
+            }
+            HIP_TRY(scd::launch_prod_tree((int)pr.M, a, r32, n_pairs, partials, grid, p->stream));
+            scaled = 1;
+        } else         if (pr.fused) {
             ProdArgs a;
             std::memset(&a, 0, sizeof(a));
             a.n_slots = (int)pr.tables.size();
+            if (const char *e = std::getenv("SC_DEBUG")) a.debug = std::atoi(e);
             for (size_t s = 0; s < pr.tables.size(); ++s) {
                 Table &t = p->tabs[pr.tables[s]];
                 a.slot[s].exp = pr.exps[s];

@@ -38,6 +38,7 @@ struct Slot {
 struct ProdArgs {
     Slot slot[kMaxFusedM];
     int n_slots;
+    int debug; // experiments only (SC_DEBUG): bit 0 = synthesise operands instead of loading, bit 1 = skip the products
 };
 
 // static per-product record for the finalize kernel (device memory)
@@ -72,6 +73,10 @@ hipError_t launch_prod_round(int M, const ProdArgs &args, const FrHost &r, uint6
 // the same in carry-free 29-bit-limb arithmetic; r32 = challenge * 2^5, partials carry 2^(-5(M-1))
 hipError_t launch_prod_round_fe(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
                                 hipStream_t stream);
+// production big-round kernel: args list exactly M factors (repeated tables listed repeatedly; modes 0 / 1 / 3), static
+// multiplication tree per M; same partial layout and 2^(-5(M-1)) scaling as launch_prod_round_fe
+hipError_t launch_prod_tree(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
+                            hipStream_t stream);
 // tiled variant (LDS-staged, one wavefront per node): grid from grid_for_tiles, same partial layout and scaling as _fe
 int grid_for_tiles(uint64_t n_pairs);
 hipError_t launch_round_tile(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,

@@ -97,8 +97,14 @@ __global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const F
             Fr lo, hi;
             if (A.slot[s].mode == 0) {
                 const uint4 *p = A.slot[s].src + 4 * b; // pair b = 64 contiguous bytes
-                lo = fr_load(p);
-                hi = fr_load(p + 2);
+                if (A.debug & 1) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { lo.v[i] = (uint32_t)b * 2654435761u + i + s; hi.v[i] = (uint32_t)(b >> 3) + 77u * i; }
+                    lo.v[7] &= 0x3fffffffu; hi.v[7] &= 0x3fffffffu;
+                } else {
+                    lo = fr_load(p);
+                    hi = fr_load(p + 2);
+                }
             } else {
                 const uint4 *p = A.slot[s].src + 8 * b; // entries 4b..4b+3 = 128 contiguous bytes
                 const Fr e0 = fr_load(p), e1 = fr_load(p + 2), e2 = fr_load(p + 4), e3 = fr_load(p + 6);
@@ -128,6 +134,11 @@ __global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const F
 #pragma unroll
                 for (int t = 0; t <= M; ++t) prod[t] = cur[t];
                 k = 1;
+            }
+            if (A.debug & 2) {
+#pragma unroll
+                for (int t = 0; t <= M; ++t) prod[t] = fr_add(prod[t], cur[t]);
+                k = e;
             }
             for (; k < e; ++k) { // nodes in pairs: two independent Montgomery products per asm stream
 #pragma unroll
@@ -169,8 +180,17 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
             Fe lo, hi;
             if (A.slot[s].mode == 0) {
                 const uint4 *p = A.slot[s].src + 4 * b;
-                lo = fe_from_fr(fr_load(p));
-                hi = fe_from_fr(fr_load(p + 2));
+                if (A.debug & 1) {
+                    Fr x, y;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { x.v[i] = (uint32_t)b * 2654435761u + i + s; y.v[i] = (uint32_t)(b >> 3) + 77u * i; }
+                    x.v[7] &= 0x3fffffffu; y.v[7] &= 0x3fffffffu;
+                    lo = fe_from_fr(x);
+                    hi = fe_from_fr(y);
+                } else {
+                    lo = fe_from_fr(fr_load(p));
+                    hi = fe_from_fr(fr_load(p + 2));
+                }
             } else {
                 const uint4 *p = A.slot[s].src + 8 * b;
                 const Fe e0 = fe_from_fr(fr_load(p)), e1 = fe_from_fr(fr_load(p + 2));
@@ -203,12 +223,140 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
                 }
                 uint32_t k = 0;
                 if (first) { prod[t] = (nv == 0 || nv == 1) ? cur : fe_carry_pass(cur); k = 1; }
+                if (A.debug & 2) { prod[t] = fe_carry_pass(fe_add(prod[t], cur)); k = e; }
                 for (; k < e; ++k) prod[t] = fe_mul(cur, prod[t]);
             }
             first = false;
         }
 #pragma unroll
         for (int t = 0; t <= M; ++t) acc[t] = fe_carry_pass(fe_add(acc[t], prod[t]));
+        if ((iter & 31u) == 31u) { // keep the top limb far from 2^31 on very long grid-stride loops
+#pragma unroll
+            for (int t = 0; t <= M; ++t) acc[t] = fe_from_fr(fe_to_fr(acc[t]));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t <= M; ++t) {
+        const Fr s = block_sum(fe_to_fr(acc[t]), sm);
+        if (threadIdx.x == 0) fr_store(partials + 2 * ((uint64_t)blockIdx.x * (M + 1) + t), s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4, product tree: the production big-round kernel.  `A` lists exactly M FACTORS (a table that occurs twice in the
+// product is listed twice), so the multiplication schedule is static per M:
+//   M = 2:  3 products  (nodes 0, 1, inf)
+//   M = 3:  q = f0 f1 at {0, 1, inf} (3), extended to -1 by additions, times f2 at {0, 1, inf, -1} (4)      =  7 (not 8)
+//   M = 4:  qa = f0 f1, qb = f2 f3 at {0, 1, inf} (6), both extended to {-1, 2}, qa qb at the five nodes (5) = 11 (not 15)
+//   M >= 5: node by node, M-1 products each.
+// A quadratic q with q0 = q(0), q1 = q(1), qi = leading coefficient has q(-1) = 2 qi - q1 + 2 q0 and
+// q(2) = 2 qi + 2 q1 - q0: three lazy limb-wise additions and one carry pass in the 29-bit representation.
+// Slot modes: 0 read this round's table; 1 bind the previous table, store, use; 3 bind without storing (a repeated
+// factor whose table the same lane has already stored).
+// ------------------------------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ void tree_nodes(const Fe (&lo)[M], const Fe (&hi)[M], Fe (&P)[M + 1]) {
+    if constexpr (M == 1) {
+        P[0] = lo[0];
+        P[1] = hi[0];
+    } else if constexpr (M == 2) {
+        P[0] = fe_mul(lo[0], lo[1]);
+        P[1] = fe_mul(hi[0], hi[1]);
+        P[2] = fe_mul(fe_sub(hi[0], lo[0]), fe_sub(hi[1], lo[1]));
+    } else if constexpr (M == 3) {
+        const Fe q0 = fe_mul(lo[0], lo[1]), q1 = fe_mul(hi[0], hi[1]), qi = fe_mul(fe_sub(hi[0], lo[0]), fe_sub(hi[1], lo[1]));
+        const Fe qm1 = fe_carry_pass(fe_sub(fe_add(fe_add(qi, qi), fe_add(q0, q0)), q1));
+        P[0] = fe_mul(lo[2], q0);
+        P[1] = fe_mul(hi[2], q1);
+        P[2] = fe_mul(fe_sub(hi[2], lo[2]), qi);
+        P[3] = fe_mul(fe_sub(fe_add(lo[2], lo[2]), hi[2]), qm1); // f2(-1) = 2 lo - hi
+    } else if constexpr (M == 4) {
+        const Fe a0 = fe_mul(lo[0], lo[1]), a1 = fe_mul(hi[0], hi[1]), ai = fe_mul(fe_sub(hi[0], lo[0]), fe_sub(hi[1], lo[1]));
+        const Fe b0 = fe_mul(lo[2], lo[3]), b1 = fe_mul(hi[2], hi[3]), bi = fe_mul(fe_sub(hi[2], lo[2]), fe_sub(hi[3], lo[3]));
+        const Fe a2i = fe_add(ai, ai), b2i = fe_add(bi, bi);
+        const Fe am1 = fe_carry_pass(fe_sub(fe_add(a2i, fe_add(a0, a0)), a1)), bm1 = fe_carry_pass(fe_sub(fe_add(b2i, fe_add(b0, b0)), b1));
+        const Fe a2 = fe_carry_pass(fe_sub(fe_add(a2i, fe_add(a1, a1)), a0)), b2 = fe_carry_pass(fe_sub(fe_add(b2i, fe_add(b1, b1)), b0));
+        P[0] = fe_mul(a0, b0);
+        P[1] = fe_mul(a1, b1);
+        P[2] = fe_mul(ai, bi);
+        P[3] = fe_mul(am1, bm1);
+        P[4] = fe_mul(a2, b2);
+    } else {
+#pragma unroll
+        for (int t = 0; t <= M; ++t) {
+            const int32_t nv = node_value(t);
+#pragma unroll
+            for (int f = 0; f < M; ++f) {
+                Fe val;
+                if (nv == 0) val = lo[f];
+                else if (nv == 1) val = hi[f];
+                else if (nv == kNodeInf) val = fe_sub(hi[f], lo[f]);
+                else if (nv == -1) val = fe_sub(fe_add(lo[f], lo[f]), hi[f]);
+                else if (nv == 2) val = fe_sub(fe_add(hi[f], hi[f]), lo[f]);
+                else {
+                    const Fe step = fe_sub(hi[f], lo[f]);
+                    if (nv > 0) {
+                        val = fe_sub(fe_add(hi[f], hi[f]), lo[f]);
+                        for (int32_t c = 2; c < nv; ++c) val = fe_add(fe_carry_pass(val), step);
+                    } else {
+                        val = fe_sub(fe_add(lo[f], lo[f]), hi[f]);
+                        for (int32_t c = -1; c > nv; --c) val = fe_sub(fe_carry_pass(val), step);
+                    }
+                }
+                P[t] = (f == 0) ? ((nv == 0 || nv == 1) ? val : fe_carry_pass(val)) : fe_mul(val, P[t]);
+            }
+        }
+    }
+}
+
+// compile-time loop over the factors (a plain loop is not reliably unrolled here, which would push lo[]/hi[] to scratch)
+template <int F, int M>
+struct LoadFactors {
+    static __device__ __forceinline__ void run(const ProdArgs &A, const uint64_t b, const FeU &r, Fe (&lo)[M], Fe (&hi)[M]) {
+        const uint32_t mode = A.slot[F].mode;
+        if (mode == 0) {
+            const uint4 *p = A.slot[F].src + 4 * b;
+            lo[F] = fe_from_fr(fr_load(p));
+            hi[F] = fe_from_fr(fr_load(p + 2));
+        } else {
+            const uint4 *p = A.slot[F].src + 8 * b; // entries 4b..4b+3 of the previous table: 128 contiguous bytes
+            const Fe e0 = fe_from_fr(fr_load(p)), e1 = fe_from_fr(fr_load(p + 2));
+            const Fe e2 = fe_from_fr(fr_load(p + 4)), e3 = fe_from_fr(fr_load(p + 6));
+            const Fr lc = fe_to_fr(fe_add(e0, fe_mul_u(fe_sub(e1, e0), r)));
+            const Fr hc = fe_to_fr(fe_add(e2, fe_mul_u(fe_sub(e3, e2), r)));
+            if (mode == 1) { // tables stay canonical in the reference layout
+                uint4 *q = A.slot[F].dst + 4 * b;
+                fr_store(q, lc);
+                fr_store(q + 2, hc);
+            }
+            lo[F] = fe_from_fr(lc);
+            hi[F] = fe_from_fr(hc);
+        }
+        LoadFactors<F + 1, M>::run(A, b, r, lo, hi);
+    }
+};
+template <int M>
+struct LoadFactors<M, M> {
+    static __device__ __forceinline__ void run(const ProdArgs &, const uint64_t, const FeU &, Fe (&)[M], Fe (&)[M]) {}
+};
+
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_prod_tree(const ProdArgs A, const FrHost r32_h, const uint64_t n_pairs,
+                                                      uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    const FeU r = feu_from_host(r32_h);
+    Fe acc[M + 1];
+#pragma unroll
+    for (int t = 0; t <= M; ++t) acc[t] = fe_zero();
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint32_t iter = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_pairs; b += stride, ++iter) {
+        Fe lo[M], hi[M];
+        LoadFactors<0, M>::run(A, b, r, lo, hi);
+        Fe P[M + 1];
+        tree_nodes<M>(lo, hi, P);
+#pragma unroll
+        for (int t = 0; t <= M; ++t) acc[t] = fe_carry_pass(fe_add(acc[t], P[t]));
         if ((iter & 31u) == 31u) { // keep the top limb far from 2^31 on very long grid-stride loops
 #pragma unroll
             for (int t = 0; t <= M; ++t) acc[t] = fe_from_fr(fe_to_fr(acc[t]));
@@ -554,6 +702,25 @@ __global__ __launch_bounds__(kBlock) void k_bench_modmul(const uint32_t reps, co
 #pragma unroll
             for (int c = 0; c < 4; ++c) x[c] = fr_mul_comba(x[c], y);
         }
+    } else if (variant == 5 || variant == 6) { // carry-free 29-bit-limb product, 4 (variant 5) or 2 (variant 6) chains
+        Fe fx[4], fy = fe_from_fr(y);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fx[c] = fe_from_fr(x[c]);
+        if (variant == 5) {
+            for (uint32_t k = 0; k < reps; ++k) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) fx[c] = fe_mul(fy, fx[c]);
+            }
+        } else {
+            for (uint32_t k = 0; k < reps; ++k) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) fx[c] = fe_mul(fy, fx[c]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) fx[c] = fe_mul(fy, fx[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[c] = fe_to_fr(fx[c]);
     } else if (variant == 4) {
         for (uint32_t k = 0; k < reps; ++k) {
             fr_mul2_comba(x[0], y, x[1], y, x[0], x[1]);
@@ -641,6 +808,24 @@ hipError_t launch_prod_round_fe(int M, const ProdArgs &args, const FrHost &r32, 
     case 7: return launch_prod_round_fe_t<7>(args, r32, n_pairs, d_partials, grid, stream);
     case 8: return launch_prod_round_fe_t<8>(args, r32, n_pairs, d_partials, grid, stream);
     default: return hipErrorInvalidValue;
+    }
+}
+
+template <int M>
+static hipError_t launch_prod_tree_t(const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
+                                     hipStream_t stream) {
+    hipLaunchKernelGGL(k_prod_tree<M>, dim3(grid), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_prod_tree(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
+                            hipStream_t stream) {
+    switch (M) {
+    case 1: return launch_prod_tree_t<1>(args, r32, n_pairs, d_partials, grid, stream);
+    case 2: return launch_prod_tree_t<2>(args, r32, n_pairs, d_partials, grid, stream);
+    case 3: return launch_prod_tree_t<3>(args, r32, n_pairs, d_partials, grid, stream);
+    case 4: return launch_prod_tree_t<4>(args, r32, n_pairs, d_partials, grid, stream);
+    default: return hipErrorInvalidValue; // 5..8 multiplicands run node by node in k_prod_round_fe
     }
 }
 
