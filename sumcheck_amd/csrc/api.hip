@@ -114,9 +114,11 @@ struct Product {
 };
 
 struct Table {
-    const uint4 *cur = nullptr; // this round's evaluations
+    const uint4 *cur = nullptr;       // this round's evaluations (main array)
+    const int32_t *cur_top = nullptr; // non-null: `cur` is in the internal F29 format and this is its limb-8 array
     uint4 *buf[2] = {nullptr, nullptr};
-    int next = 0;               // buffer the next bind writes to
+    int32_t *buf_top[2] = {nullptr, nullptr}; // limb-8 arrays of the two ping-pong buffers
+    int next = 0;                     // buffer the next bind writes to
 };
 
 struct sc_prover {
@@ -147,6 +149,7 @@ struct sc_prover {
     uint32_t *d_slot_table = nullptr, *d_slot_exp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool use_f29 = false; // bound tables of big rounds kept in the internal 9 x 29-bit format (all products <= 4 multiplicands)
     bool use_fe = true; // big rounds in carry-free arithmetic (fe.cuh); SC_FE=0 selects the saturated kernels
     int kernel_variant = 3; // SC_KERNEL: 0 = lane-per-pair (k_prod_round[_fe]), 2 = tiled LDS-staged (k_round_tile), 3 = product tree
     // reset support + per-product instrumentation
@@ -258,6 +261,10 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     p->randomness.reserve(p->nv);
     if (const char *e = std::getenv("SC_FE")) p->use_fe = std::atoi(e) != 0;
     if (const char *e = std::getenv("SC_KERNEL")) p->kernel_variant = std::atoi(e);
+    p->use_f29 = p->kernel_variant == 3;
+    if (const char *e = std::getenv("SC_F29")) p->use_f29 = p->use_f29 && std::atoi(e) != 0;
+    for (uint32_t k = 0; k < d->n_products; ++k)
+        if (d->prod_offsets[k + 1] - d->prod_offsets[k] > 4) p->use_f29 = false;
 
     // products: distinct tables + multiplicities
     uint64_t partial_elems = 0;
@@ -318,7 +325,7 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     const uint64_t n = 1ULL << p->nv;
     const uint64_t s0 = borrow ? std::max<uint64_t>(n >> 1, 1) : n;
     const uint64_t s1 = borrow ? std::max<uint64_t>(n >> 2, 1) : std::max<uint64_t>(n >> 1, 1);
-    const uint64_t per_table = (s0 + s1) * 32;
+    const uint64_t per_table = (s0 + s1) * 36; // 32 B main + 4 B limb-8 array per element (internal F29 format)
     HIP_TRY(hipMalloc(&p->arena, per_table * p->U));
     p->tabs.resize(p->U);
     p->borrow = borrow;
@@ -327,6 +334,8 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
         char *base = static_cast<char *>(p->arena) + per_table * u;
         t.buf[0] = reinterpret_cast<uint4 *>(base);
         t.buf[1] = reinterpret_cast<uint4 *>(base + s0 * 32);
+        t.buf_top[0] = reinterpret_cast<int32_t *>(base + (s0 + s1) * 32);
+        t.buf_top[1] = t.buf_top[0] + s0;
         if (borrow) {
             t.cur = reinterpret_cast<const uint4 *>(d->tables[u]);
             t.next = 0;
@@ -457,12 +466,14 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
             for (uint32_t u = 0; u < p->U; ++u) {
                 Table &t = p->tabs[u];
                 tp.src[u] = t.cur;
+                tp.src_top[u] = t.cur_top;
                 tp.dst[u] = t.buf[t.next];
             }
             HIP_TRY(scd::launch_fix_multi(tp, (int)p->U, rdev, 2 * n_pairs, p->stream));
             for (uint32_t u = 0; u < p->U; ++u) {
                 Table &t = p->tabs[u];
                 t.cur = t.buf[t.next];
+                t.cur_top = nullptr; // the latency-bound path keeps tables canonical in the reference layout
                 t.next ^= 1;
             }
         }
@@ -498,24 +509,31 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
             for (size_t s = 0; s < pr.tables.size(); ++s) {
                 Table &t = p->tabs[pr.tables[s]];
                 const uint4 *old_src = t.cur;
+                const int32_t *old_top = t.cur_top;
                 bool stored_here = false;
                 for (uint32_t rep = 0; rep < pr.exps[s]; ++rep, ++f) {
                     a.slot[f].exp = 1;
                     if (bind && !bound[pr.tables[s]]) {
                         a.slot[f].mode = 1;
                         a.slot[f].src = old_src;
+                        a.slot[f].src_top = old_top;
                         a.slot[f].dst = t.buf[t.next];
+                        a.slot[f].dst_top = p->use_f29 ? t.buf_top[t.next] : nullptr;
                         t.cur = t.buf[t.next];
+                        t.cur_top = a.slot[f].dst_top;
                         t.next ^= 1;
                         bound[pr.tables[s]] = 1;
                         stored_here = true;
                     } else if (stored_here) {
                         a.slot[f].mode = 3;
                         a.slot[f].src = old_src;
+                        a.slot[f].src_top = old_top;
                         a.slot[f].dst = nullptr;
+                        a.slot[f].dst_top = p->use_f29 ? t.buf_top[0] : nullptr; // only selects the tighten path
                     } else {
                         a.slot[f].mode = 0;
                         a.slot[f].src = t.cur;
+                        a.slot[f].src_top = t.cur_top;
                         a.slot[f].dst = nullptr;
                     }
                 }
@@ -637,8 +655,18 @@ extern "C" int sc_prover_state(sc_prover *p, uint64_t *randomness, uint32_t *n_r
         HIP_TRY(hipSetDevice(p->device));
         const uint32_t bound = p->round > 0 ? p->round - 1 : 0;
         const uint64_t n = 1ULL << (p->nv - bound);
-        for (uint32_t u = 0; u < p->U; ++u)
-            HIP_TRY(hipMemcpyAsync(tables_out + 4 * n * u, p->tabs[u].cur, n * 32, hipMemcpyDeviceToHost, p->stream));
+        void *tmp = nullptr; // tables in the internal F29 format are converted to the canonical reference layout first
+        for (uint32_t u = 0; u < p->U; ++u) {
+            const void *src = p->tabs[u].cur;
+            if (p->tabs[u].cur_top) {
+                if (!tmp) HIP_TRY(hipMalloc(&tmp, n * 32));
+                HIP_TRY(scd::launch_f29_to_sat(p->tabs[u].cur, p->tabs[u].cur_top, static_cast<uint4 *>(tmp), n, p->stream));
+                src = tmp;
+            }
+            HIP_TRY(hipMemcpyAsync(tables_out + 4 * n * u, src, n * 32, hipMemcpyDeviceToHost, p->stream));
+            if (tmp) HIP_TRY(hipStreamSynchronize(p->stream));
+        }
+        if (tmp) (void)hipFree(tmp);
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
     return SC_OK;
@@ -699,6 +727,7 @@ extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_nu
                 p->origin[u] = reinterpret_cast<const uint4 *>(tables_or_null[u]);
             }
             p->tabs[u].cur = p->origin[u];
+            p->tabs[u].cur_top = nullptr;
             p->tabs[u].next = 0;
         }
     } else {
@@ -709,6 +738,7 @@ extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_nu
             HIP_TRY(hipMemcpyAsync(p->tabs[u].buf[0], tables_or_null[u], n * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                    p->stream));
             p->tabs[u].cur = p->tabs[u].buf[0];
+            p->tabs[u].cur_top = nullptr;
             p->tabs[u].next = 1;
         }
         HIP_TRY(hipStreamSynchronize(p->stream));

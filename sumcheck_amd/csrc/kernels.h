@@ -33,6 +33,13 @@ struct Slot {
     uint4 *dst;
     uint32_t mode;
     uint32_t exp; // multiplicity of the table inside the product (e.g. [1,4,4] -> table 4 has exp 2)
+    // Internal table format "F29" (big rounds after the first bind): an element is nine signed 29-bit limbs, limbs
+    // 0..7 in the 32-byte main array (same stride as the reference layout) and limb 8 in a separate 4-byte array, so
+    // a bound table is stored after a carry pass instead of a full canonical reduction + repack, and loads need no
+    // unpacking.  src_top == nullptr: `src` is in the reference layout (canonical 8 x 32-bit).  dst is always F29
+    // when dst_top != nullptr.
+    const int32_t *src_top;
+    int32_t *dst_top;
 };
 
 struct ProdArgs {
@@ -55,6 +62,7 @@ struct FinProd {
 struct TablePtrs {
     const uint4 *src[kMaxSmallTables];
     uint4 *dst[kMaxSmallTables];
+    const int32_t *src_top[kMaxSmallTables]; // non-null: that source table is in the internal F29 format
 };
 // one (product, evaluation point) combination of the small-round sum kernel (device memory, static per prover)
 struct Combo {
@@ -97,6 +105,8 @@ hipError_t launch_finalize(const FinProd *d_prods, const FrHost *d_W, int K, int
                            int scaled, hipStream_t stream);
 hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);
 hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t n, hipStream_t stream);
+// F29 table -> canonical reference layout (state export)
+hipError_t launch_f29_to_sat(const uint4 *src, const int32_t *src_top, uint4 *dst, uint64_t n, hipStream_t stream);
 hipError_t launch_fr_elementwise(int op, const uint4 *a, const uint4 *b, const FrHost &u, uint4 *out, uint64_t n, hipStream_t stream);
 hipError_t launch_bench_modmul(uint64_t n_threads, uint32_t reps, uint32_t variant, uint64_t *d_sink, hipStream_t stream);
 

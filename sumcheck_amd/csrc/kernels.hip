@@ -314,23 +314,47 @@ template <int F, int M>
 struct LoadFactors {
     static __device__ __forceinline__ void run(const ProdArgs &A, const uint64_t b, const FeU &r, Fe (&lo)[M], Fe (&hi)[M]) {
         const uint32_t mode = A.slot[F].mode;
+        const int32_t *stop = A.slot[F].src_top; // non-null: the source table is in the internal F29 format
         if (mode == 0) {
             const uint4 *p = A.slot[F].src + 4 * b;
-            lo[F] = fe_from_fr(fr_load(p));
-            hi[F] = fe_from_fr(fr_load(p + 2));
+            if (stop) {
+                const int2 t = *reinterpret_cast<const int2 *>(stop + 2 * b);
+                lo[F] = fe_load_f29(p, t.x);
+                hi[F] = fe_load_f29(p + 2, t.y);
+            } else {
+                lo[F] = fe_from_fr(fr_load(p));
+                hi[F] = fe_from_fr(fr_load(p + 2));
+            }
         } else {
             const uint4 *p = A.slot[F].src + 8 * b; // entries 4b..4b+3 of the previous table: 128 contiguous bytes
-            const Fe e0 = fe_from_fr(fr_load(p)), e1 = fe_from_fr(fr_load(p + 2));
-            const Fe e2 = fe_from_fr(fr_load(p + 4)), e3 = fe_from_fr(fr_load(p + 6));
-            const Fr lc = fe_to_fr(fe_add(e0, fe_mul_u(fe_sub(e1, e0), r)));
-            const Fr hc = fe_to_fr(fe_add(e2, fe_mul_u(fe_sub(e3, e2), r)));
-            if (mode == 1) { // tables stay canonical in the reference layout
-                uint4 *q = A.slot[F].dst + 4 * b;
-                fr_store(q, lc);
-                fr_store(q + 2, hc);
+            Fe e0, e1, e2, e3;
+            if (stop) {
+                const int4 t = *reinterpret_cast<const int4 *>(stop + 4 * b);
+                e0 = fe_load_f29(p, t.x); e1 = fe_load_f29(p + 2, t.y); e2 = fe_load_f29(p + 4, t.z); e3 = fe_load_f29(p + 6, t.w);
+            } else {
+                e0 = fe_from_fr(fr_load(p)); e1 = fe_from_fr(fr_load(p + 2)); e2 = fe_from_fr(fr_load(p + 4)); e3 = fe_from_fr(fr_load(p + 6));
             }
-            lo[F] = fe_from_fr(lc);
-            hi[F] = fe_from_fr(hc);
+            const Fe l0 = fe_add(e0, fe_mul_u(fe_sub(e1, e0), r));
+            const Fe h0 = fe_add(e2, fe_mul_u(fe_sub(e3, e2), r));
+            if (A.slot[F].dst_top || (mode == 3 && stop)) { // internal F29 tables: a carry pass + one conditional subtraction
+                lo[F] = fe_tighten(l0);
+                hi[F] = fe_tighten(h0);
+                if (mode == 1) {
+                    uint4 *q = A.slot[F].dst + 4 * b;
+                    fe_store_f29(q, lo[F]);
+                    fe_store_f29(q + 2, hi[F]);
+                    *reinterpret_cast<int2 *>(A.slot[F].dst_top + 2 * b) = make_int2(lo[F].l[8], hi[F].l[8]);
+                }
+            } else { // tables stay canonical in the reference layout
+                const Fr lc = fe_to_fr(l0), hc = fe_to_fr(h0);
+                if (mode == 1) {
+                    uint4 *q = A.slot[F].dst + 4 * b;
+                    fr_store(q, lc);
+                    fr_store(q + 2, hc);
+                }
+                lo[F] = fe_from_fr(lc);
+                hi[F] = fe_from_fr(hc);
+            }
         }
         LoadFactors<F + 1, M>::run(A, b, r, lo, hi);
     }
@@ -534,12 +558,28 @@ __global__ __launch_bounds__(kBlock) void k_fix_multi(const TablePtrs tp, const 
     const FrU r = fru_from_host(r_h);
     const uint4 *__restrict__ src = tp.src[blockIdx.y];
     uint4 *__restrict__ dst = tp.dst[blockIdx.y];
+    const int32_t *__restrict__ stop = tp.src_top[blockIdx.y];
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_out; b += stride) {
         const uint4 *p = src + 4 * b;
-        const Fr lo = fr_load(p), hi = fr_load(p + 2);
+        Fr lo, hi;
+        if (stop) { // first latency-bound round after the big rounds: the table arrives in F29, leaves canonical
+            const int2 t = *reinterpret_cast<const int2 *>(stop + 2 * b);
+            lo = fe_to_fr(fe_load_f29(p, t.x));
+            hi = fe_to_fr(fe_load_f29(p + 2, t.y));
+        } else {
+            lo = fr_load(p);
+            hi = fr_load(p + 2);
+        }
         fr_store(dst + 2 * b, fr_add(lo, fr_mul_u(fr_sub(hi, lo), r)));
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_f29_to_sat(const uint4 *__restrict__ src, const int32_t *__restrict__ stop, uint4 *__restrict__ dst,
+                                                       const uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        fr_store(dst + 2 * i, fe_to_fr(fe_load_f29(src + 2 * i, stop[i])));
 }
 
 __global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const Combo *__restrict__ combos,
@@ -919,6 +959,11 @@ hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint6
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     const uint64_t key = z ^ (z >> 31);
     hipLaunchKernelGGL(k_synth, dim3(grid_for_pairs(n)), dim3(kBlock), 0, stream, key, first, n, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_f29_to_sat(const uint4 *src, const int32_t *src_top, uint4 *dst, uint64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_f29_to_sat, dim3(grid_for_pairs(n)), dim3(kBlock), 0, stream, src, src_top, dst, n);
     return hipGetLastError();
 }
 
