@@ -1,0 +1,52 @@
+"""GPU parity of the alternative kernel variants (selected by environment at prover creation): the production path is the
+product-tree kernel over internal F29 tables; the saturated Comba kernel, the node-by-node carry-free kernel, the tiled
+LDS-staged kernel and the F29-off mode are kept as cross-checks and must produce the same bits."""
+import os
+
+import numpy as np
+import pytest
+
+import sumcheck_amd as sc
+from oracle import cref
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("env", [
+    {"SC_KERNEL": "3", "SC_F29": "1"},   # production
+    {"SC_KERNEL": "3", "SC_F29": "0"},   # product tree, canonical tables
+    {"SC_KERNEL": "0", "SC_FE": "1"},    # node-by-node, carry-free arithmetic
+    {"SC_KERNEL": "0", "SC_FE": "0"},    # node-by-node, saturated Comba (inline asm)
+    {"SC_KERNEL": "2"},                  # tiled, LDS-staged
+])
+@pytest.mark.parametrize("nv,nt,shapes", [
+    (19, 10, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]),       # BASELINE config-3 shape, three big rounds
+    (18, 5, [[2, 3, 0, 1], [1, 4, 4], [3, 2, 1], [0, 0]]),  # shared tables, repeated factors
+    (18, 6, [[0, 1, 2, 3, 4], [5, 5], [2]]),                # five multiplicands: outside the tree, no F29
+])
+def test_variant_matches_oracle(env, nv, nt, shapes, monkeypatch):
+    for k in ("SC_KERNEL", "SC_F29", "SC_FE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    tabs = [cref.synth_table(4242 + nv, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(4242 + nv, 1000, len(shapes))
+    d = H.desc_from(nv, shapes, tabs, coefs)
+    want, wrand = cref.ml_prove(d, threads=cref.max_threads())
+    poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs)
+    proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly)
+    assert np.array_equal(np.stack([m.evaluations for m in proof]), want)
+    assert np.array_equal(state.randomness, wrand)
+    # interactive flow with a mid-proof state export while the tables are in the internal format (round 2)
+    st = sc.IPForMLSumcheck.prover_init(poly)
+    op = cref.Prover(d, threads=cref.max_threads())
+    chal = cref.synth_table(99, 1, nv)
+    v = None
+    for i in range(3):
+        got = sc.IPForMLSumcheck.prove_round(st, v).evaluations
+        assert np.array_equal(got, op.prove_round(None if v is None else v.randomness))
+        v = sc.VerifierMsg(chal[i])
+    _, otabs, _ = op.state()
+    for u, t in enumerate(st.flattened_ml_extensions):
+        assert np.array_equal(t.evaluations, otabs[u])
