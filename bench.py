@@ -116,7 +116,8 @@ def main():
     coefs = ct.cpu().numpy().view(np.uint64)
     torch.cuda.synchronize()
 
-    if world == 1:
+    force_sharded = os.environ.get("SC_BENCH_FORCE_SHARDED") == "1"  # exercise the N>1 code path on one GPU (tests)
+    if world == 1 and not force_sharded:
         mles = [sc.DenseMultilinearExtension(nv_local, t) for t in tables]
         poly = sc.ListOfProductsOfPolynomials(nv_local)
         for kk, sh in enumerate(shapes):
@@ -197,7 +198,7 @@ def main():
                          "all_kernels_GBps": all_kernels_gbps, "all_kernels_ms_per_step": rounds_ms.value / args.steps,
                          "per_product_ms_per_step": [m / args.steps for m in ms]},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not force_sharded:
             try:
                 out["cpu_baseline"] = cpu_baseline(shapes, U)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
