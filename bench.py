@@ -167,18 +167,21 @@ def main():
     if rank == 0:
         ops = field_ops(nv_total, shapes, U)
         value = ops * args.steps / elapsed
-        # dominant kernel: k_prod_round<4> (product 0: 4 of the 10 tables, 15 of the 26 sum multiplications per point)
+        # dominant kernel: k_prod_tree<4> (product 0: 4 of the 10 tables).  It is launched once per BIG round (more than 2^16
+        # pairs; later rounds are latency-bound and run through k_fix_multi / k_sum_combos).  Algorithmic bytes of those launches:
+        # round 1 reads the product's tables once; round i >= 2 reads T_{i-1} and writes T_i (32-byte elements).
         dom = int(np.argmax(list(ms)))
         u_dom = len(set(shapes[dom]))
-        bytes_per_prove_dom = algorithmic_bytes(nv_local, u_dom)
+        big_rounds = max(nv_local - 17, 1) if nv_local > 17 else 0
+        big_bytes = 32 * u_dom * ((1 << nv_local) + sum((1 << (nv_local - i + 2)) + (1 << (nv_local - i + 1)) for i in range(2, big_rounds + 1)))
         launches = int(ln[dom])
         avg_ms = ms[dom] / max(launches, 1)
-        bytes_per_launch = bytes_per_prove_dom * args.steps / max(launches, 1)
+        bytes_per_launch = big_bytes * args.steps / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None  # measured off-line with rocprofv3 PMC passes (tools/profile.sh), per launch of the same kernel
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")))
-            if tj.get("kernel", "").endswith(f"k_prod_round<{len(shapes[dom])}>") and nv_local == 24:
+            if tj.get("kernel", "").endswith(f"k_prod_tree<{len(shapes[dom])}>") and nv_local == 24:
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             pass
@@ -193,7 +196,7 @@ def main():
                        "nv": nv_total, "nv_per_gpu": nv_local, "tables": U, "degree": max(len(s) for s in shapes),
                        "field_ops_per_step": ops, "sharding": f"high-bit x{world}" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": f"k_prod_round<{len(shapes[dom])}> (product {dom})",
+                         "traffic": traffic, "kernel": f"k_prod_tree<{len(shapes[dom])}> (product {dom}, big rounds)",
                          "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "all_kernels_GBps": all_kernels_gbps, "all_kernels_ms_per_step": rounds_ms.value / args.steps,
                          "per_product_ms_per_step": [m / args.steps for m in ms]},

@@ -156,6 +156,7 @@ struct sc_prover {
     bool borrow = false;
     std::vector<const uint4 *> origin; // borrowed table pointers (borrow mode)
     bool timing = false, timing_pending = false;
+    bool prod_timed = false; // the pending round recorded per-product events (big rounds only)
     std::vector<hipEvent_t> prod_ev;   // 2 per product
     std::vector<double> prod_ms;       // accumulated device time of each product's kernel
     std::vector<uint64_t> prod_launches;
@@ -407,7 +408,7 @@ static int collect_timing(sc_prover *p) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
     p->rounds_ms += ms;
-    for (uint32_t k = 0; k < p->K; ++k) {
+    for (uint32_t k = 0; k < p->K && p->prod_timed; ++k) { // big rounds only: one fused kernel launch per product
         HIP_TRY(hipEventElapsedTime(&ms, p->prod_ev[2 * k], p->prod_ev[2 * k + 1]));
         p->prod_ms[k] += ms;
         p->prod_launches[k] += 1;
@@ -478,14 +479,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
             }
         }
         for (uint32_t u = 0; u < p->U; ++u) tp.src[u] = p->tabs[u].cur;
-        if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[0], p->stream));
         HIP_TRY(scd::launch_sum_combos(tp, p->d_combos, p->n_combos, p->d_slot_table, p->d_slot_exp, n_pairs, p->d_partials, grid, p->stream));
-        if (p->timing) {
-            for (uint32_t k = 0; k < p->K; ++k) { // the single launch is attributed to product 0; the others record an empty span
-                if (k > 0) HIP_TRY(hipEventRecord(p->prod_ev[2 * k], p->stream));
-                HIP_TRY(hipEventRecord(p->prod_ev[2 * k + 1], p->stream));
-            }
-        }
         bind = false;
     }
     if (bind && p->any_generic) { // generic products read bound tables: bind everything up front
@@ -592,6 +586,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     HIP_TRY(hipEventRecord(p->ev1, p->stream));
     p->timed = true;
     p->timing_pending = p->timing;
+    p->prod_timed = p->timing && !small;
     return SC_OK;
 }
 

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Copy the rocprofv3 summaries of gpurun_out/prof_<tag>/ into profiles/ and derive the HBM traffic per launch of the
+dominant kernel.  Usage: python tools/collect_profiles.py <tag> [kernel substring, default k_prod_tree<4>]"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+kern = sys.argv[2] if len(sys.argv) > 2 else "k_prod_tree<4>"
+base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+out = os.path.join(ROOT, "profiles")
+shutil.copy(os.path.join(base, "stats", "bench_kernel_stats.csv"), os.path.join(out, f"{tag}_rocprofv3_kernel_stats.csv"))
+shutil.copy(os.path.join(base, "stats", "bench_kernel_trace.csv"), os.path.join(out, f"{tag}_rocprofv3_kernel_trace.csv"))
+counters = {}
+for name, f in (("FETCH_SIZE", "pmc_fetch/bench_counter_collection.csv"), ("WRITE_SIZE", "pmc_write/bench_counter_collection.csv")):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(os.path.join(base, f))):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"])
+    counters[name] = {k: {"calls": n, "sum_KB": v, "per_call_KB": v / n} for k, (n, v) in agg.items()}
+key = next(k for k in counters["FETCH_SIZE"] if kern in k)
+f, w = counters["FETCH_SIZE"][key], counters["WRITE_SIZE"][key]
+n_tables = int(kern.split("<")[1].split(">")[0])
+summary = {
+    "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --output-format csv) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+    "corrections": "FETCH_SIZE x2 (MI355X_MICROARCH.md: gfx950 counts 64 B per 128-B request for 16 B/lane coalesced reads; checked on the "
+                   "round-1 launch: 4 x 2^24 x 32 B = 2097152 KB read, counter 1048848 KB); WRITE_SIZE x1 (calibrated on k_synth: 10 x 2^24 x 32 B "
+                   "written, counter 5242880 KB)",
+    "kernel": key,
+    "launches": f["calls"],
+    "traffic_bytes_per_launch": (2 * f["sum_KB"] + w["sum_KB"]) * 1024 / f["calls"],
+    "algorithmic_bytes_per_launch_big_rounds_only": None,
+    "counters": counters,
+}
+json.dump(summary, open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+shutil.copy(os.path.join(out, f"{tag}_hbm_traffic.json"), os.path.join(out, "hbm_traffic_latest.json"))
+print(key, "launches", f["calls"], "traffic/launch", summary["traffic_bytes_per_launch"])
