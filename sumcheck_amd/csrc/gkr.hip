@@ -14,6 +14,9 @@
 // arithmetic is exact, hence the result is the same canonical table whatever the summation order.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -378,40 +381,53 @@ extern "C" int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_val
 
 // One sumcheck phase: product 1*(A*B) over two device tables (start_phase{1,2}_sumcheck, mod.rs:45-54,66-82), dim rounds
 // of prove_round / feed / sample (mod.rs:111-119,126-133).
-static int run_phase(sch::Blake2b512Rng &rng, const Fr *dA, const Fr *dB, uint32_t dim, uint64_t *out_msgs, sch::Fr *challenges) {
-    const uint32_t offs[2] = {0, 2}, idx[2] = {0, 1};
+// One sumcheck phase: product 1*(A*B) over two device tables (start_phase{1,2}_sumcheck, mod.rs:45-54,66-82), dim rounds
+// of prove_round / feed / sample (mod.rs:111-119,126-133).  The handle (stream, ping-pong buffers, pinned result page) is
+// created for phase one and rewound onto phase two's tables, so the second phase allocates nothing.
+static int run_phase(sch::Blake2b512Rng &rng, sc_prover **handle, const Fr *dA, const Fr *dB, uint32_t dim, uint64_t *out_msgs,
+                     sch::Fr *challenges) {
     const uint64_t *tabs[2] = {reinterpret_cast<const uint64_t *>(dA), reinterpret_cast<const uint64_t *>(dB)};
-    sc_poly_desc d;
-    std::memset(&d, 0, sizeof(d));
-    d.num_vars = dim;
-    d.max_multiplicands = 2;
-    d.n_products = 1;
-    d.coeffs = sch::kOne.l; // F::one()
-    d.prod_offsets = offs;
-    d.prod_indices = idx;
-    d.n_tables = 2;
-    d.tables = tabs;
-    d.flags = SC_TABLES_ON_DEVICE | SC_TABLES_BORROW; // the inputs are this call's own scratch: no second copy
-    sc_prover *p = nullptr;
-    int rc = sc_prover_init(&d, &p);
+    int rc;
+    if (*handle == nullptr) {
+        const uint32_t offs[2] = {0, 2}, idx[2] = {0, 1};
+        sc_poly_desc d;
+        std::memset(&d, 0, sizeof(d));
+        d.num_vars = dim;
+        d.max_multiplicands = 2;
+        d.n_products = 1;
+        d.coeffs = sch::kOne.l; // F::one()
+        d.prod_offsets = offs;
+        d.prod_indices = idx;
+        d.n_tables = 2;
+        d.tables = tabs;
+        d.flags = SC_TABLES_ON_DEVICE | SC_TABLES_BORROW; // the inputs are this call's own scratch: no second copy
+        rc = sc_prover_init(&d, handle);
+    } else {
+        rc = sc_prover_reset(*handle, tabs, SC_TABLES_ON_DEVICE);
+    }
     if (rc) return rc;
     sch::Fr vm = sch::zero();
     bool have = false;
     for (uint32_t i = 0; i < dim; ++i) {
         uint64_t *pm = out_msgs + (size_t)i * 12;
-        rc = sc_prove_round(p, have ? vm.l : nullptr, pm);
-        if (rc) {
-            sc_prover_free(p);
-            return rc;
-        }
+        rc = sc_prove_round(*handle, have ? vm.l : nullptr, pm);
+        if (rc) return rc;
         rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(pm), 3);
         vm = rng.sample_fr();
         have = true;
         challenges[i] = vm;
     }
-    sc_prover_free(p);
     return SC_OK;
 }
+
+namespace {
+struct ProverGuard {
+    sc_prover *p = nullptr;
+    ~ProverGuard() {
+        if (p) sc_prover_free(p);
+    }
+};
+} // namespace
 
 extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim, const uint64_t *f2,
                             const uint64_t *f3, const uint64_t *g, uint64_t *out_proof, uint64_t *out_uv_or_null) {
@@ -423,6 +439,15 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
         if (dim < 21 && (f1_idx[i] >> (3 * dim)) != 0) return sc_internal_fail(SC_ERR_BAD_ARG, "f1 index %llu out of range", (unsigned long long)i);
     hipStream_t s = nullptr;
     DevBuf mem;
+    const bool trace = std::getenv("SC_GKR_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gkr] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const uint64_t N = 1ULL << dim;
     uint64_t *d_idx = nullptr, *d_idx_s = nullptr, *d_gi = nullptr;
     Fr *d_vals = nullptr, *d_vals_s = nullptr, *d_f2 = nullptr, *d_f3 = nullptr, *d_hg = nullptr, *d_gv = nullptr, *d_f1gu = nullptr, *d_f3s = nullptr;
@@ -443,24 +468,42 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
         G_TRY(hipMemcpyAsync(d_idx, f1_idx, nnz * 8, hipMemcpyHostToDevice, s));
         G_TRY(hipMemcpyAsync(d_vals, f1_vals, nnz * 32, hipMemcpyHostToDevice, s));
     }
+    lap("alloc");
     G_TRY(hipMemcpyAsync(d_f2, f2, N * 32, hipMemcpyHostToDevice, s));
     G_TRY(hipMemcpyAsync(d_f3, f3, N * 32, hipMemcpyHostToDevice, s));
+    lap("h2d");
     if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 3 * dim, d_idx_s, d_vals_s, s))) return rc;
+    lap("sort f1");
     uint64_t n1 = 0;
     if ((rc = phase_one_device(mem, d_idx_s, d_vals_s, nnz, dim, d_f3, reinterpret_cast<const sch::Fr *>(g), d_hg, d_gi, d_gv, d_n1, &n1, s))) return rc; // mod.rs:106
     G_TRY(hipStreamSynchronize(s));
+    lap("phase one init");
     std::vector<sch::Fr> u(dim), v(dim);
-    if ((rc = run_phase(rng->rng, d_hg, d_f2, dim, out_proof, u.data()))) return rc; // mod.rs:107-119
+    ProverGuard pg;
+    if ((rc = run_phase(rng->rng, &pg.p, d_hg, d_f2, dim, out_proof, u.data()))) return rc; // mod.rs:107-119
+    lap("phase one sumcheck");
     if ((rc = phase_two_device(mem, d_gi, d_gv, n1, dim, u.data(), d_f1gu, s))) return rc; // mod.rs:121
+    lap("phase two init");
     // f2.evaluate(&u) (mod.rs:122): bind all dim variables on the device
     sch::Fr f2_u;
     G_TRY(hipStreamSynchronize(s));
-    rc = sc_fix_variables(reinterpret_cast<const uint64_t *>(d_f2), dim, u[0].l, dim, reinterpret_cast<uint64_t *>(d_hg), SC_TABLES_ON_DEVICE);
-    if (rc) return rc;
-    G_TRY(hipMemcpy(&f2_u, d_hg, 32, hipMemcpyDeviceToHost));
+    { // bind all dim variables of f2, ping-ponging between two buffers that are free at this point (h_g is spent, f3*f2(u) not yet built)
+        const uint4 *cur = reinterpret_cast<const uint4 *>(d_f2);
+        uint4 *pp[2] = {reinterpret_cast<uint4 *>(d_hg), reinterpret_cast<uint4 *>(d_f3s)};
+        uint64_t m = N;
+        for (uint32_t i = 0; i < dim; ++i) {
+            m >>= 1;
+            G_TRY(scd::launch_fix(cur, pp[i & 1], hostfr(u[i]), m, s));
+            cur = pp[i & 1];
+        }
+        G_TRY(hipMemcpyAsync(&f2_u, cur, 32, hipMemcpyDeviceToHost, s));
+        G_TRY(hipStreamSynchronize(s));
+    }
     G_TRY(scd::launch_scale(reinterpret_cast<const uint4 *>(d_f3), reinterpret_cast<uint4 *>(d_f3s), hostfr(f2_u), N, s)); // mod.rs:71-75
     G_TRY(hipStreamSynchronize(s));
-    if ((rc = run_phase(rng->rng, d_f1gu, d_f3s, dim, out_proof + (size_t)dim * 12, v.data()))) return rc; // mod.rs:122-133
+    lap("f2(u), scale f3");
+    if ((rc = run_phase(rng->rng, &pg.p, d_f1gu, d_f3s, dim, out_proof + (size_t)dim * 12, v.data()))) return rc; // mod.rs:122-133
+    lap("phase two sumcheck");
     if (out_uv_or_null) {
         std::memcpy(out_uv_or_null, u.data(), (size_t)dim * 32);
         std::memcpy(out_uv_or_null + (size_t)dim * 4, v.data(), (size_t)dim * 32);
