@@ -336,9 +336,13 @@ struct LoadFactors {
             }
             const Fe l0 = fe_add(e0, fe_mul_u(fe_sub(e1, e0), r));
             const Fe h0 = fe_add(e2, fe_mul_u(fe_sub(e3, e2), r));
-            if (A.slot[F].dst_top || (mode == 3 && stop)) { // internal F29 tables: a carry pass + one conditional subtraction
-                lo[F] = fe_tighten(l0);
-                hi[F] = fe_tighten(h0);
+            if (A.slot[F].dst_top || (mode == 3 && stop)) {
+                // internal F29 tables: ONE parallel carry pass, no modular reduction.  The value grows by < p + 2^252 per bind
+                // (|r*(e1-e0)| image in (-2^251, p + 2^251)), i.e. stays below (rounds+1) p < 2^261 for any nv <= 40, which every
+                // consumer tolerates: fe_mul bounds depend on limb sizes only (limbs 0..7 are re-tightened here, the top limb
+                // stays below 2^28), and fe_to_fr reduces any |v| < 2^260 exactly.
+                lo[F] = fe_carry_pass(l0);
+                hi[F] = fe_carry_pass(h0);
                 if (mode == 1) {
                     uint4 *q = A.slot[F].dst + 4 * b;
                     fe_store_f29(q, lo[F]);
@@ -379,8 +383,13 @@ __global__ __launch_bounds__(kBlock) void k_prod_tree(const ProdArgs A, const Fr
         LoadFactors<0, M>::run(A, b, r, lo, hi);
         Fe P[M + 1];
         tree_nodes<M>(lo, hi, P);
+        if (iter & 1u) { // limbs: tightened + two products' limbs < 3 * 2^29 < 2^31, so a carry pass every other iteration suffices
 #pragma unroll
-        for (int t = 0; t <= M; ++t) acc[t] = fe_carry_pass(fe_add(acc[t], P[t]));
+            for (int t = 0; t <= M; ++t) acc[t] = fe_carry_pass(fe_add(acc[t], P[t]));
+        } else {
+#pragma unroll
+            for (int t = 0; t <= M; ++t) acc[t] = fe_add(acc[t], P[t]);
+        }
         if ((iter & 31u) == 31u) { // keep the top limb far from 2^31 on very long grid-stride loops
 #pragma unroll
             for (int t = 0; t <= M; ++t) acc[t] = fe_from_fr(fe_to_fr(acc[t]));
