@@ -109,18 +109,29 @@ __device__ __forceinline__ Fe fe_carry_pass(const Fe &a) {
 }
 
 // ---- internal table format F29 -----------------------------------------------------------------------------------
-// main[e] = limbs 0..7 of element e (two uint4), top[e] = limb 8.
-__device__ __forceinline__ Fe fe_load_f29(const uint4 *main, int32_t top) {
-    const uint4 a = main[0], b = main[1];
+// An element is nine 29-bit limbs.  Limb 8 lives in a linear int32 array top[entry].  Limbs 0..7 live in the "main" array in
+// a chunk-planar layout chosen so that every store instruction of the bind kernel is contiguous across the wavefront:
+// entries are grouped in blocks of 64 pairs (128 entries, 4 KiB); inside a block, plane k = 2*(entry & 1) + half holds the
+// 16-byte chunk (limbs 4*half .. 4*half+3) of that entry for the 64 pairs side by side:
+//     byte offset(entry e, half) = (e >> 7) * 4096 + (2 * (e & 1) + half) * 1024 + ((e >> 1) & 63) * 16.
+// The writer lane of pair q stores plane k at column q & 63: 64 lanes x 16 B = 1 KiB contiguous per instruction (the
+// reference layout's lane-private 64-byte stores cost 12 % of the mixed read/write HBM rate, profiles/r1_mem_bench.txt).
+// The next round's lane b reads pairs 2b and 2b+1: 16 bytes at a 32-byte lane stride, which streams as fast as contiguous.
+// Tables in this format always hold a multiple of 128 entries (big rounds only).
+__device__ __forceinline__ uint64_t f29_chunk(uint64_t entry, int half) { // index in uint4 units
+    return (entry >> 7) * 256 + (uint64_t)(2 * (int)(entry & 1) + half) * 64 + ((entry >> 1) & 63);
+}
+__device__ __forceinline__ Fe fe_load_f29(const uint4 *main, uint64_t entry, int32_t top) {
+    const uint4 a = main[f29_chunk(entry, 0)], b = main[f29_chunk(entry, 1)];
     Fe r;
     r.l[0] = (int32_t)a.x; r.l[1] = (int32_t)a.y; r.l[2] = (int32_t)a.z; r.l[3] = (int32_t)a.w;
     r.l[4] = (int32_t)b.x; r.l[5] = (int32_t)b.y; r.l[6] = (int32_t)b.z; r.l[7] = (int32_t)b.w;
     r.l[8] = top;
     return r;
 }
-__device__ __forceinline__ void fe_store_f29(uint4 *main, const Fe &v) {
-    main[0] = make_uint4((uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
-    main[1] = make_uint4((uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
+__device__ __forceinline__ void fe_store_f29(uint4 *main, uint64_t entry, const Fe &v) {
+    main[f29_chunk(entry, 0)] = make_uint4((uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
+    main[f29_chunk(entry, 1)] = make_uint4((uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
 }
 // Bound value -> storable form: the value of e0 + r*(e1-e0) lies in (-2^251, 2p + 2^252); one conditional subtraction
 // of p decided by the top limb keeps stored values in (-2^251, p + 2^233) for ever (no growth from round to round),

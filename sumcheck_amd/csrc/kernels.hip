@@ -319,8 +319,8 @@ struct LoadFactors {
             const uint4 *p = A.slot[F].src + 4 * b;
             if (stop) {
                 const int2 t = *reinterpret_cast<const int2 *>(stop + 2 * b);
-                lo[F] = fe_load_f29(p, t.x);
-                hi[F] = fe_load_f29(p + 2, t.y);
+                lo[F] = fe_load_f29(A.slot[F].src, 2 * b, t.x);
+                hi[F] = fe_load_f29(A.slot[F].src, 2 * b + 1, t.y);
             } else {
                 lo[F] = fe_from_fr(fr_load(p));
                 hi[F] = fe_from_fr(fr_load(p + 2));
@@ -330,7 +330,9 @@ struct LoadFactors {
             Fe e0, e1, e2, e3;
             if (stop) {
                 const int4 t = *reinterpret_cast<const int4 *>(stop + 4 * b);
-                e0 = fe_load_f29(p, t.x); e1 = fe_load_f29(p + 2, t.y); e2 = fe_load_f29(p + 4, t.z); e3 = fe_load_f29(p + 6, t.w);
+                const uint4 *m = A.slot[F].src;
+                e0 = fe_load_f29(m, 4 * b, t.x); e1 = fe_load_f29(m, 4 * b + 1, t.y);
+                e2 = fe_load_f29(m, 4 * b + 2, t.z); e3 = fe_load_f29(m, 4 * b + 3, t.w);
             } else {
                 e0 = fe_from_fr(fr_load(p)); e1 = fe_from_fr(fr_load(p + 2)); e2 = fe_from_fr(fr_load(p + 4)); e3 = fe_from_fr(fr_load(p + 6));
             }
@@ -344,9 +346,8 @@ struct LoadFactors {
                 lo[F] = fe_carry_pass(l0);
                 hi[F] = fe_carry_pass(h0);
                 if (mode == 1) {
-                    uint4 *q = A.slot[F].dst + 4 * b;
-                    fe_store_f29(q, lo[F]);
-                    fe_store_f29(q + 2, hi[F]);
+                    fe_store_f29(A.slot[F].dst, 2 * b, lo[F]);
+                    fe_store_f29(A.slot[F].dst, 2 * b + 1, hi[F]);
                     *reinterpret_cast<int2 *>(A.slot[F].dst_top + 2 * b) = make_int2(lo[F].l[8], hi[F].l[8]);
                 }
             } else { // tables stay canonical in the reference layout
@@ -574,8 +575,8 @@ __global__ __launch_bounds__(kBlock) void k_fix_multi(const TablePtrs tp, const 
         Fr lo, hi;
         if (stop) { // first latency-bound round after the big rounds: the table arrives in F29, leaves canonical
             const int2 t = *reinterpret_cast<const int2 *>(stop + 2 * b);
-            lo = fe_to_fr(fe_load_f29(p, t.x));
-            hi = fe_to_fr(fe_load_f29(p + 2, t.y));
+            lo = fe_to_fr(fe_load_f29(src, 2 * b, t.x));
+            hi = fe_to_fr(fe_load_f29(src, 2 * b + 1, t.y));
         } else {
             lo = fr_load(p);
             hi = fr_load(p + 2);
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(kBlock) void k_f29_to_sat(const uint4 *__restrict__
                                                        const uint64_t n) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
-        fr_store(dst + 2 * i, fe_to_fr(fe_load_f29(src + 2 * i, stop[i])));
+        fr_store(dst + 2 * i, fe_to_fr(fe_load_f29(src, i, stop[i])));
 }
 
 __global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const Combo *__restrict__ combos,
