@@ -149,6 +149,12 @@ struct sc_prover {
     uint32_t *d_slot_table = nullptr, *d_slot_exp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // products over pairwise disjoint tables may run concurrently (SC_STREAMS=1): one side stream per product, forked after
+    // the round's start event and joined before finalize
+    bool par_products = false;
+    std::vector<hipStream_t> pstreams;
+    std::vector<hipEvent_t> pjoin;
+    hipEvent_t ev_fork = nullptr;
     bool use_f29 = false; // bound tables of big rounds kept in the internal 9 x 29-bit format (all products <= 4 multiplicands)
     bool use_fe = true; // big rounds in carry-free arithmetic (fe.cuh); SC_FE=0 selects the saturated kernels
     int kernel_variant = 3; // SC_KERNEL: 0 = lane-per-pair (k_prod_round[_fe]), 2 = tiled LDS-staged (k_round_tile), 3 = product tree
@@ -183,6 +189,9 @@ static void prover_destroy(sc_prover *p) {
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     for (hipEvent_t e : p->prod_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->pjoin) (void)hipEventDestroy(e);
+    for (hipStream_t st : p->pstreams) (void)hipStreamDestroy(st);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     delete p;
 }
@@ -373,6 +382,27 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
         HIP_TRY(hipMalloc(&p->d_cur_tables, p->U * sizeof(void *)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_cur_tables), p->U * sizeof(void *), hipHostMallocDefault));
     }
+    if (const char *e = std::getenv("SC_STREAMS")) {
+        if (std::atoi(e) != 0 && p->K > 1) {
+            std::vector<int> owner(p->U, -1);
+            bool disjoint = true;
+            for (uint32_t k = 0; k < p->K; ++k)
+                for (uint32_t t : p->prods[k].tables) {
+                    if (owner[t] >= 0 && owner[t] != (int)k) disjoint = false;
+                    owner[t] = (int)k;
+                }
+            if (disjoint) {
+                p->par_products = true;
+                p->pstreams.resize(p->K);
+                p->pjoin.resize(p->K);
+                for (uint32_t k = 0; k < p->K; ++k) {
+                    HIP_TRY(hipStreamCreateWithFlags(&p->pstreams[k], hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&p->pjoin[k], hipEventDisableTiming));
+                }
+                HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+            }
+        }
+    }
     HIP_TRY(hipStreamSynchronize(p->stream)); // inputs are copied: the caller may drop them now (prover.rs:55-59)
     return SC_OK;
 }
@@ -488,9 +518,16 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     }
     std::vector<uint8_t> bound(p->U, 0);
     bool ptrs_uploaded = false;
+    hipStream_t main_stream = p->stream;
+    const bool fork = p->par_products && !small;
+    if (fork) HIP_TRY(hipEventRecord(p->ev_fork, main_stream));
     for (uint32_t k = 0; k < p->K && !small; ++k) {
         const Product &pr = p->prods[k];
         FrHost *partials = p->d_partials + pr.partial_off;
+        if (fork) {
+            p->stream = p->pstreams[k];
+            HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_fork, 0));
+        }
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[2 * k], p->stream));
         if (pr.fused && p->kernel_variant == 3 && pr.M <= 4) {
             // product tree: one argument slot per FACTOR.  The first factor touching a table this round binds and stores it;
@@ -574,6 +611,11 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
                                             (int)pr.tables.size(), (int)pr.M, n_pairs, partials, grid, p->stream));
         }
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[2 * k + 1], p->stream));
+        if (fork) {
+            HIP_TRY(hipEventRecord(p->pjoin[k], p->stream));
+            p->stream = main_stream;
+            HIP_TRY(hipStreamWaitEvent(main_stream, p->pjoin[k], 0));
+        }
     }
     if (bind) { // tables that no product refers to still follow the state machine
         for (uint32_t u = 0; u < p->U; ++u)

@@ -19,6 +19,8 @@
 #include "fe.cuh"
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace scd {
 
 __device__ __forceinline__ Fr fr_from_host(const FrHost &h) {
@@ -825,10 +827,18 @@ __global__ __launch_bounds__(kBlock) void k_fr_elementwise(const int op, const u
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+static int grid_cap() { // SC_GRID: experiment knob, at most kMaxGrid (the partial buffers are sized for that)
+    static const int cap = [] {
+        const char *e = std::getenv("SC_GRID");
+        const int v = e ? std::atoi(e) : kMaxGrid;
+        return v >= 1 && v <= kMaxGrid ? v : kMaxGrid;
+    }();
+    return cap;
+}
 int grid_for_pairs(uint64_t n_pairs) {
     uint64_t g = (n_pairs + kBlock - 1) / kBlock;
     if (g < 1) g = 1;
-    if (g > (uint64_t)kMaxGrid) g = kMaxGrid;
+    if (g > (uint64_t)grid_cap()) g = grid_cap();
     return (int)g;
 }
 
