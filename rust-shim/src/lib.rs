@@ -139,14 +139,51 @@ pub fn prove_round<F: Limbs4>(state: &mut HipProverState<F>, v_msg: &Option<F>) 
     out.into_iter().map(F::from_limbs).collect()
 }
 
-/// `MLSumcheck::prove` (reference `src/ml_sumcheck/mod.rs:42-45`): the whole Fiat-Shamir loop in one FFI call.
+struct Flattened {
+    coeffs: Vec<[u64; 4]>,
+    offsets: Vec<u32>,
+    indices: Vec<u32>,
+    tables: Vec<*const u64>,
+}
+impl Flattened {
+    fn desc(&self, num_vars: usize, max_multiplicands: usize) -> sc_poly_desc {
+        sc_poly_desc {
+            num_vars: num_vars as u32,
+            max_multiplicands: max_multiplicands as u32,
+            n_products: self.coeffs.len() as u32,
+            coeffs: self.coeffs.as_ptr() as *const u64,
+            prod_offsets: self.offsets.as_ptr(),
+            prod_indices: self.indices.as_ptr(),
+            n_tables: self.tables.len() as u32,
+            tables: self.tables.as_ptr(),
+            flags: 0,
+        }
+    }
+}
+fn flatten<F: Limbs4>(polynomial: &ListOfProductsOfPolynomials<F>) -> Flattened {
+    let coeffs = polynomial.products.iter().map(|(c, _)| unsafe { *(c.limbs() as *const [u64; 4]) }).collect();
+    let mut offsets = vec![0u32];
+    let mut indices = Vec::new();
+    for (_, idx) in &polynomial.products {
+        indices.extend(idx.iter().map(|&i| i as u32));
+        offsets.push(indices.len() as u32);
+    }
+    let tables = polynomial.flattened_ml_extensions.iter().map(|m| m.evaluations.as_ptr() as *const u64).collect();
+    Flattened { coeffs, offsets, indices, tables }
+}
+
+/// `MLSumcheck::prove` (reference `src/ml_sumcheck/mod.rs:42-45`): the whole Fiat-Shamir loop in one FFI call
+/// (`sc_ml_prove` with a fresh `Blake2b512Rng::setup()` transcript inside the library).
 pub fn ml_prove<F: Limbs4>(polynomial: &ListOfProductsOfPolynomials<F>) -> Vec<Vec<F>> {
-    // same flattening as prover_init; omitted here for brevity: build `desc` as above, then
-    //   sc_ml_prove(&desc, null, proof.as_mut_ptr(), null)
-    // and chunk `proof` into num_variables messages of max_multiplicands + 1 elements.
-    let mut state = prover_init(polynomial);
-    let _ = &mut state;
-    unimplemented!("see INTEGRATION.md: identical marshalling to prover_init followed by sc_ml_prove")
+    let flat = flatten(polynomial);
+    let desc = flat.desc(polynomial.num_variables, polynomial.max_multiplicands);
+    let d = polynomial.max_multiplicands + 1;
+    let mut proof = vec![[0u64; 4]; polynomial.num_variables.max(1) * d];
+    let rc = unsafe { sc_ml_prove(&desc, core::ptr::null_mut(), proof.as_mut_ptr() as *mut u64, core::ptr::null_mut()) };
+    if rc != SC_OK {
+        panic_like_reference(rc)
+    }
+    proof.chunks(d).take(polynomial.num_variables).map(|m| m.iter().map(|l| F::from_limbs(*l)).collect()).collect()
 }
 
 #[allow(dead_code)]

@@ -328,3 +328,26 @@ def test_gkr_config5_dim20():
                                       sc.DenseMultilinearExtension(dim, f2), sc.DenseMultilinearExtension(dim, f3), g)
     assert np.array_equal(np.stack([m.evaluations for m in proof.phase1_sumcheck_msgs]), want[0])
     assert np.array_equal(np.stack([m.evaluations for m in proof.phase2_sumcheck_msgs]), want[1])
+
+
+def test_config4_shard_shape_nv25():
+    """BASELINE config 4 is nv=28 over 8 GPUs: every GPU holds an nv=25 shard of the 3 tables (3 GiB).  One such shard as a
+    stand-alone instance, checked through the size-independent relations (the sharded protocol itself is covered by the gloo
+    and logical-shard tests)."""
+    nv, shapes, nt = 25, [[0, 1, 2]], 3
+    poly, mles, coefs = _device_poly(nv, shapes, nt, 0x5C20241008 + 4)
+    proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly, borrow=True)
+    sub = sc.MLSumcheck.verify(poly.info(), sc.MLSumcheck.extract_sum(proof), proof)
+    assert np.array_equal(state.randomness, sub.point)
+    assert np.array_equal(poly.evaluate(sub.point), sub.expected_evaluation)
+    # round 1 against the oracle on the low 2^16-entry slices is not meaningful (sums differ); instead pin round 1 by
+    # linearity: P(0) + P(1) of the whole instance equals the sum of the two half-instances' claims (high bit 0 / 1)
+    import torch
+    halves = []
+    for h in range(2):
+        ph = sc.ListOfProductsOfPolynomials(nv - 1)
+        n = 1 << (nv - 1)
+        ph.add_product([sc.DenseMultilinearExtension(nv - 1, m.evaluations[h * n:(h + 1) * n]) for m in mles], coefs[0])
+        pr = sc.MLSumcheck.prove(ph)
+        halves.append(field.to_int(sc.MLSumcheck.extract_sum(pr)))
+    assert (halves[0] + halves[1]) % field.P == field.to_int(sc.MLSumcheck.extract_sum(proof))
