@@ -362,7 +362,7 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     if (p->K) HIP_TRY(hipMemcpyAsync(p->d_finprods, fin.data(), p->K * sizeof(FinProd), hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMalloc(&p->d_W, std::max<size_t>(Wall.size(), 1) * 32));
     if (!Wall.empty()) HIP_TRY(hipMemcpyAsync(p->d_W, Wall.data(), Wall.size() * 32, hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipMalloc(&p->d_scratch, (size_t)2 * std::max<uint32_t>(p->K, 1) * p->D * 32));
+    HIP_TRY(hipMalloc(&p->d_scratch, (size_t)(2 + p->D) * std::max<uint32_t>(p->K, 1) * p->D * 32));
     HIP_TRY(hipMalloc(&p->d_out, (size_t)p->D * 32));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_out), (size_t)p->D * 32, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_flag), 64, hipHostMallocMapped | hipHostMallocCoherent));

@@ -662,16 +662,25 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
         if (lane == 0) fr_store(scratch + 2 * (k * D + t), acc);
     }
     __syncthreads();
-    // phase 2: thread (k, t): message point t of product k = sum_s (c_k W_k)[t][s] * S_k[s]
-    for (int combo = threadIdx.x; combo < K * D; combo += kBlock) {
-        const int k = combo / D, t = combo % D;
+    // phase 2: message point t of product k = sum_s (c_k W_k)[t][s] * S_k[s].  One thread per (k, t, s) does the single
+    // Montgomery product (a lone lane needs ~1 us per product, so the M+1 products of a point must not be chained) ...
+    for (int idx = threadIdx.x; idx < K * D * D; idx += kBlock) {
+        const int k = idx / (D * D), t = (idx / D) % D, sN = idx % D;
         const int M = (int)prods[k].M;
+        if (sN > M) continue;
         // partials from the 2^261-radix kernels carry 2^(-5(M-1)); the second copy of the matrix undoes it
         const uint64_t woff = prods[k].w_off + ((scaled && M <= kMaxFusedM) ? (uint64_t)D * (M + 1) : 0);
         const uint4 *Wk = Wm + 2 * (woff + (uint64_t)t * (M + 1));
+        fr_store(scratch + 2 * ((2 * K) * D + idx), fr_mul(fr_load(Wk + 2 * sN), fr_load(scratch + 2 * (k * D + sN))));
+    }
+    __syncthreads();
+    // ... and one thread per (k, t) adds them up
+    for (int combo = threadIdx.x; combo < K * D; combo += kBlock) {
+        const int k = combo / D;
+        const int M = (int)prods[k].M;
         Fr acc = fr_zero();
-        for (int sN = 0; sN <= M; ++sN) acc = fr_add(acc, fr_mul(fr_load(Wk + 2 * sN), fr_load(scratch + 2 * (k * D + sN))));
-        fr_store(scratch + 2 * ((K + k) * D + t), acc);
+        for (int sN = 0; sN <= M; ++sN) acc = fr_add(acc, fr_load(scratch + 2 * ((2 * K) * D + combo * D + sN)));
+        fr_store(scratch + 2 * ((K + k) * D + combo % D), acc);
     }
     __syncthreads();
     // phase 3b: sum over products
