@@ -145,22 +145,39 @@ __global__ __launch_bounds__(kBlock) void k_scatter_dense(const uint64_t *__rest
                                     hipGetErrorString(e_), __FILE__, __LINE__);                                          \
     } while (0)
 
-struct DevBuf { // owns device allocations for the lifetime of one API call
-    std::vector<void *> ptrs;
+struct DevBuf { // device scratch for the lifetime of one API call: one arena (hipFree is synchronous and slow: ~20 separate
+                // buffers cost more than the kernels), bump-allocated, with a plain hipMalloc fallback if the estimate is short
+    char *arena = nullptr;
+    size_t cap = 0, used = 0;
+    std::vector<void *> extra;
     ~DevBuf() {
-        for (void *p : ptrs) (void)hipFree(p);
+        if (arena) (void)hipFree(arena);
+        for (void *p : extra) (void)hipFree(p);
+    }
+    hipError_t reserve(size_t bytes) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&arena), bytes);
+        if (e == hipSuccess) cap = bytes;
+        else (void)hipGetLastError();
+        return hipSuccess; // on failure fall back to per-buffer allocations
     }
     template <typename T>
     hipError_t alloc(T **out, size_t n) {
+        const size_t bytes = ((n ? n : 1) * sizeof(T) + 255) & ~size_t(255);
+        if (used + bytes <= cap) {
+            *out = reinterpret_cast<T *>(arena + used);
+            used += bytes;
+            return hipSuccess;
+        }
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
+        hipError_t e = hipMalloc(&p, bytes);
         if (e == hipSuccess) {
-            ptrs.push_back(p);
+            extra.push_back(p);
             *out = static_cast<T *>(p);
         }
         return e;
     }
 };
+inline size_t gkr_scratch_estimate(uint64_t nnz, uint64_t N) { return (size_t)704 * (nnz + 1) + (size_t)352 * N + ((size_t)64 << 20); }
 
 inline int grid_for(uint64_t n) { return scd::grid_for_pairs(n); }
 inline FrHost hostfr(const sch::Fr &a) {
@@ -320,6 +337,7 @@ extern "C" int sc_gkr_phase_one(const uint64_t *f1_idx, const uint64_t *f1_vals,
     hipStream_t s = nullptr;
     DevBuf mem;
     const uint64_t N = 1ULL << dim;
+    (void)mem.reserve(gkr_scratch_estimate(nnz, N));
     uint64_t *d_idx = nullptr, *d_idx_s = nullptr, *d_gi = nullptr;
     Fr *d_vals = nullptr, *d_vals_s = nullptr, *d_f3 = nullptr, *d_hg = nullptr, *d_gv = nullptr;
     unsigned int *d_n1 = nullptr;
@@ -361,6 +379,7 @@ extern "C" int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_val
     hipStream_t s = nullptr;
     DevBuf mem;
     const uint64_t N = 1ULL << dim;
+    (void)mem.reserve(gkr_scratch_estimate(nnz, N));
     uint64_t *d_idx = nullptr, *d_idx_s = nullptr;
     Fr *d_vals = nullptr, *d_vals_s = nullptr, *d_out = nullptr;
     G_TRY(mem.alloc(&d_idx, nnz));
@@ -439,6 +458,7 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
         if (dim < 21 && (f1_idx[i] >> (3 * dim)) != 0) return sc_internal_fail(SC_ERR_BAD_ARG, "f1 index %llu out of range", (unsigned long long)i);
     hipStream_t s = nullptr;
     DevBuf mem;
+    (void)mem.reserve(gkr_scratch_estimate(nnz, 1ULL << dim));
     const bool trace = std::getenv("SC_GKR_TRACE") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
