@@ -116,6 +116,7 @@ def main():
     coefs = ct.cpu().numpy().view(np.uint64)
     torch.cuda.synchronize()
 
+    ncomm = None
     force_sharded = os.environ.get("SC_BENCH_FORCE_SHARDED") == "1"  # exercise the N>1 code path on one GPU (tests)
     if world == 1 and not force_sharded:
         mles = [sc.DenseMultilinearExtension(nv_local, t) for t in tables]
@@ -134,8 +135,18 @@ def main():
         comm = sharded.DistComm()
         tail_factory = lambda nvt, tabs: sharded.HipShardEngine(nvt, shapes, coefs, [tabs[u] for u in range(tabs.shape[0])], dev, borrow=False)
 
+        ncomm = None
+        if os.environ.get("SC_BENCH_PYTHON_ROUNDS") != "1":
+            try:  # per-round all-reduce inside the library (RCCL on the prover's stream); the Python loop is the fallback
+                ncomm = sharded.NativeComm(dev)
+            except Exception as e:
+                log(f"[bench] in-library RCCL rounds unavailable ({e}); using the torch.distributed round loop")
+                ncomm = None
+
         def step():
             engine.reset()
+            if ncomm is not None:
+                return sharded.prove_sharded_native(engine, ncomm, comm, nv_total, max(len(s) for s in shapes), tail_factory)[0]
             return sharded.prove_sharded([engine], comm, nv_total, max(len(s) for s in shapes), tail_factory)[0]
 
     def barrier():
@@ -194,7 +205,9 @@ def main():
             "config": {"workload": f"MLSumcheck prove, ListOfProducts {shapes} over {U} tables, nv={nv_total}"
                                    f" ({nv_local} per GPU shard), BLS12-381 Fr, tables HBM-resident",
                        "nv": nv_total, "nv_per_gpu": nv_local, "tables": U, "degree": max(len(s) for s in shapes),
-                       "field_ops_per_step": ops, "sharding": f"high-bit x{world}" if world > 1 else "none"},
+                       "field_ops_per_step": ops, "sharding": f"high-bit x{world}" if world > 1 else "none",
+                       "round_loop": ("library+rccl" if (world > 1 or force_sharded) and ncomm is not None else
+                                      ("torch.distributed" if (world > 1 or force_sharded) else "library"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "kernel": f"k_prod_tree<{len(shapes[dom])}> (product {dom}, big rounds)",
                          "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,

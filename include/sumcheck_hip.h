@@ -108,6 +108,19 @@ SC_API int sc_wide_reduce(const uint64_t *wide, uint32_t n_elems, uint64_t *out)
  * device), asynchronous on the handle's stream.  After this the handle is exhausted. */
 SC_API int sc_prover_bind_final(sc_prover *p, const uint64_t *r, uint64_t *d_out);
 
+/* Sharded rounds inside the library: one RCCL all-reduce (sum, uint64) of the widened round polynomial per round on the
+ * handle's stream.  RCCL is bound at run time (dlopen).  Rank 0 creates the 128-byte unique id and ships it to the other
+ * ranks by any means (bench.py: torch.distributed broadcast); every rank then calls sc_comm_init on its own device.
+ * sc_ml_prove_sharded_rounds runs the first n_rounds rounds of MLSumcheck::prove_as_subprotocol (mod.rs:54-64) for the
+ * GLOBAL instance of nv_total variables on this rank's shard (handle at round 0): out_proof n_rounds x (deg+1) x 4,
+ * out_randomness n_rounds x 4, identical on every rank. */
+typedef struct sc_comm sc_comm;
+SC_API int sc_comm_unique_id(uint8_t *out128);
+SC_API int sc_comm_init(const uint8_t *id128, int rank, int nranks, sc_comm **out);
+SC_API void sc_comm_free(sc_comm *comm);
+SC_API int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *rng, uint32_t nv_total, uint32_t n_rounds, uint64_t *out_proof,
+                                      uint64_t *out_randomness);
+
 /* ---- DenseMultilinearExtension::fix_variables (ark-poly; prover.rs:88, gkr mod.rs:122) ------ */
 /* in: 2^nv x 4 limbs, point: k x 4 limbs (binds variables 0..k-1, LSB first), out: 2^(nv-k) x 4.
  * flags: SC_TABLES_ON_DEVICE => `in` and `out` are device pointers. */

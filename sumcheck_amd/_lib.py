@@ -59,6 +59,10 @@ SIGNATURES = {
     "sc_prove_round_partial": (C.c_int, [_V, _V, _V]),
     "sc_wide_reduce": (C.c_int, [_V, C.c_uint32, _V]),
     "sc_prover_bind_final": (C.c_int, [_V, _V, _V]),
+    "sc_comm_unique_id": (C.c_int, [_V]),
+    "sc_comm_init": (C.c_int, [_V, C.c_int, C.c_int, C.POINTER(_V)]),
+    "sc_comm_free": (None, [_V]),
+    "sc_ml_prove_sharded_rounds": (C.c_int, [_V, _V, _V, C.c_uint32, C.c_uint32, _V, _V]),
     "sc_fix_variables": (C.c_int, [_V, C.c_uint32, _V, C.c_uint32, _V, C.c_uint32]),
     "sc_rng_setup": (_V, []),
     "sc_rng_free": (None, [_V]),

@@ -3,6 +3,9 @@
 // runs around prove_round (reference src/ml_sumcheck/mod.rs:50-70).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and enums only: the entry points are bound with dlsym
+
 #include <algorithm>
 #include <chrono>
 #include <cstdarg>
@@ -141,6 +144,9 @@ struct sc_prover {
     FrHost *h_out_dev = nullptr;  // device-side aliases of the two
     uint32_t *h_flag_dev = nullptr;
     uint32_t seq = 0;
+    uint64_t *d_wide = nullptr;      // sharded rounds inside the library: all-reduce buffer (D x 8 lanes) ...
+    uint64_t *h_wide = nullptr;      // ... and its host-mapped landing page
+    uint64_t *h_wide_dev = nullptr;
     Combo *d_combos = nullptr;    // (product, point) combinations for the small-round kernel
     int n_combos = 0;
     bool any_generic = false;
@@ -181,6 +187,8 @@ static void prover_destroy(sc_prover *p) {
     if (p->d_out) (void)hipFree(p->d_out);
     if (p->h_out) (void)hipHostFree(p->h_out);
     if (p->h_flag) (void)hipHostFree(p->h_flag);
+    if (p->d_wide) (void)hipFree(p->d_wide);
+    if (p->h_wide) (void)hipHostFree(p->h_wide);
     if (p->d_combos) (void)hipFree(p->d_combos);
     if (p->d_cur_tables) (void)hipFree(p->d_cur_tables);
     if (p->h_cur_tables) (void)hipHostFree(p->h_cur_tables);
@@ -988,6 +996,126 @@ extern "C" int sc_ml_verify(uint32_t num_vars, uint32_t max_multiplicands, const
     }
     if (num_vars) std::memcpy(out_point, rs.data(), (size_t)num_vars * 32);
     std::memcpy(out_expected, expected.l, 32);
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sharded rounds inside the library: one RCCL all-reduce per round on the handle's stream.
+// RCCL is bound at run time (dlopen of librccl.so.1: inside a PyTorch process that resolves to the copy torch already
+// mapped), so the library itself has no link-time dependency on it.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct NcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+} // namespace
+static NcclApi g_nccl;
+static int nccl_load() {
+    if (g_nccl.lib) return SC_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(SC_ERR_HIP, "cannot load librccl: %s", dlerror());
+    g_nccl.GetUniqueId = reinterpret_cast<decltype(&ncclGetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    g_nccl.CommInitRank = reinterpret_cast<decltype(&ncclCommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    g_nccl.AllReduce = reinterpret_cast<decltype(&ncclAllReduce)>(dlsym(h, "ncclAllReduce"));
+    g_nccl.CommDestroy = reinterpret_cast<decltype(&ncclCommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_nccl.GetErrorString = reinterpret_cast<decltype(&ncclGetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!g_nccl.GetUniqueId || !g_nccl.CommInitRank || !g_nccl.AllReduce || !g_nccl.CommDestroy) return fail(SC_ERR_HIP, "librccl lacks the NCCL entry points");
+    g_nccl.lib = h;
+    return SC_OK;
+}
+struct sc_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+#define NCCL_TRY(expr)                                                                                             \
+    do {                                                                                                           \
+        int r_ = (int)(expr);                                                                                         \
+        if (r_ != 0) return fail(SC_ERR_HIP, "%s failed: %s", #expr, g_nccl.GetErrorString ? g_nccl.GetErrorString((ncclResult_t)r_) : "?"); \
+    } while (0)
+
+extern "C" int sc_comm_unique_id(uint8_t *out128) {
+    if (!out128) return fail(SC_ERR_BAD_ARG, "null argument");
+    int rc = nccl_load();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    NCCL_TRY(g_nccl.GetUniqueId(reinterpret_cast<ncclUniqueId *>(out128)));
+    return SC_OK;
+}
+extern "C" int sc_comm_init(const uint8_t *id128, int rank, int nranks, sc_comm **out) {
+    if (!id128 || !out || rank < 0 || rank >= nranks) return fail(SC_ERR_BAD_ARG, "bad argument");
+    int rc = nccl_load();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(g_device));
+    sc_comm *c = new (std::nothrow) sc_comm();
+    if (!c) return fail(SC_ERR_OOM, "host allocation failed");
+    ncclUniqueId id;
+    std::memcpy(&id, id128, 128);
+    int r = (int)g_nccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (r != 0) {
+        delete c;
+        return fail(SC_ERR_HIP, "ncclCommInitRank failed: %s", g_nccl.GetErrorString ? g_nccl.GetErrorString((ncclResult_t)r) : "?");
+    }
+    c->rank = rank;
+    c->nranks = nranks;
+    *out = c;
+    return SC_OK;
+}
+extern "C" void sc_comm_free(sc_comm *c) {
+    if (!c) return;
+    if (c->comm && g_nccl.CommDestroy) (void)g_nccl.CommDestroy(c->comm);
+    delete c;
+}
+
+// The first n_rounds rounds of MLSumcheck::prove_as_subprotocol (reference src/ml_sumcheck/mod.rs:54-64) on this rank's shard:
+// per round the shard's kernels, one ncclAllReduce(sum, uint64) of the (deg+1) x 8 zero-extended limbs on the same stream, a
+// tiny publish kernel, then -- on every rank identically -- fold, feed, sample.  The handle is left after round n_rounds (its
+// tables have two entries when n_rounds == its num_vars); *last_challenge is the challenge to bind next.
+extern "C" int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *rng, uint32_t nv_total, uint32_t n_rounds, uint64_t *out_proof,
+                                          uint64_t *out_randomness) {
+    if (!p || !comm || !rng || !out_proof || !out_randomness) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (p->round != 0 || n_rounds > p->nv) return fail(SC_ERR_BAD_ARG, "handle must be at round 0 and hold at least n_rounds variables");
+    HIP_TRY(hipSetDevice(p->device));
+    const int n_words = (int)p->D * 8;
+    if (!p->d_wide) {
+        HIP_TRY(hipMalloc(&p->d_wide, (size_t)n_words * 8));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_wide), (size_t)n_words * 8, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_wide_dev), p->h_wide, 0));
+    }
+    rng->rng.feed_poly_info(p->max_mult, nv_total); // mod.rs:54: the GLOBAL instance's info
+    sch::Fr vm = sch::zero();
+    bool have = false;
+    std::vector<uint64_t> evals((size_t)p->D * 4);
+    for (uint32_t i = 0; i < n_rounds; ++i) {
+        int rc = launch_round(p, have ? vm.l : nullptr, p->d_wide, false);
+        if (rc) return rc;
+        NCCL_TRY(g_nccl.AllReduce(p->d_wide, p->d_wide, (size_t)n_words, ncclUint64, ncclSum, comm->comm, p->stream));
+        p->seq += 1;
+        const uint32_t want = p->seq;
+        HIP_TRY(scd::launch_publish_words(p->d_wide, p->h_wide_dev, n_words, p->h_flag_dev, want, p->stream));
+        uint64_t spins = 0;
+        bool seen = false;
+        const auto t_start = std::chrono::steady_clock::now();
+        while (!(seen = (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) == want))) {
+            if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) break;
+        }
+        if (!seen) {
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            if (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) != want) return fail(SC_ERR_HIP, "sharded round finished without publishing");
+        }
+        rc = sc_wide_reduce(p->h_wide, p->D, evals.data());
+        if (rc) return rc;
+        std::memcpy(out_proof + (size_t)i * p->D * 4, evals.data(), (size_t)p->D * 32);
+        rng->rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(evals.data()), p->D); // mod.rs:61
+        vm = rng->rng.sample_fr();                                                          // mod.rs:63
+        have = true;
+        std::memcpy(out_randomness + (size_t)i * 4, vm.l, 32);
+    }
     return SC_OK;
 }
 

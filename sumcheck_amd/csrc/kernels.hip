@@ -991,6 +991,19 @@ hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint6
     return hipGetLastError();
 }
 
+// copy a few words to host-mapped memory and raise the sequence flag (after an all-reduce on the same stream)
+__global__ void k_publish_words(const uint64_t *__restrict__ src, uint64_t *__restrict__ h_dst, const int n, uint32_t *__restrict__ h_flag,
+                                const uint32_t seq) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) h_dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_publish_words(const uint64_t *d_src, uint64_t *h_dst_mapped, int n, uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream) {
+    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, stream, d_src, h_dst_mapped, n, h_flag_mapped, seq);
+    return hipGetLastError();
+}
+
 hipError_t launch_f29_to_sat(const uint4 *src, const int32_t *src_top, uint4 *dst, uint64_t n, hipStream_t stream) {
     hipLaunchKernelGGL(k_f29_to_sat, dim3(grid_for_pairs(n)), dim3(kBlock), 0, stream, src, src_top, dst, n);
     return hipGetLastError();

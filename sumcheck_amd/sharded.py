@@ -174,6 +174,72 @@ def prove_sharded(engines: Sequence, comm: DistComm, nv_total: int, max_multipli
     return proof, rand
 
 
+class NativeComm:
+    """An RCCL communicator owned by libsumcheck_hip.so (sc_comm): the per-round all-reduce then runs inside the library on
+    the prover's stream, with no Python between rounds.  The 128-byte unique id travels over torch.distributed."""
+
+    def __init__(self, device):
+        import torch
+        import torch.distributed as dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        idb = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            check(lib().sc_comm_unique_id(C.cast(idb, C.c_void_p)))
+        t = torch.tensor(list(bytes(idb)), dtype=torch.uint8, device=device)
+        if self.world > 1:
+            dist.broadcast(t, src=0)
+        idb = (C.c_uint8 * 128)(*t.cpu().tolist())
+        self._h = C.c_void_p()
+        check(lib().sc_set_device(torch.device(device).index or 0))
+        check(lib().sc_comm_init(C.cast(idb, C.c_void_p), self.rank, self.world, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().sc_comm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prove_sharded_native(engine: HipShardEngine, ncomm: NativeComm, comm: DistComm, nv_total: int, max_multiplicands: int, tail_factory,
+                         fs_rng: Optional[Blake2b512Rng] = None):
+    """prove_sharded with the local rounds (all but the last log2 G) inside the library: sc_ml_prove_sharded_rounds.  One shard
+    per process.  The tail (bind_final + all_gather + log2 G rounds on a G-entry table) is the same code as prove_sharded."""
+    import torch
+    G = comm.world
+    k = _log2(G)
+    nv_local = nv_total - k
+    assert nv_local == engine.nv and nv_local >= 1
+    rng = fs_rng or Blake2b512Rng.setup()
+    D = max_multiplicands + 1
+    proof = np.empty((nv_total, D, 4), dtype=np.uint64)
+    rand = np.empty((nv_total, 4), dtype=np.uint64)
+    lp = np.empty((nv_local, D, 4), dtype=np.uint64)
+    lr = np.empty((nv_local, 4), dtype=np.uint64)
+    check(lib().sc_ml_prove_sharded_rounds(engine._h, ncomm._h, rng._h, nv_total, nv_local, C.c_void_p(lp.ctypes.data), C.c_void_p(lr.ctypes.data)))
+    proof[:nv_local] = lp
+    rand[:nv_local] = lr
+    if k > 0:
+        local = engine.bind_final(lr[-1]).unsqueeze(0)              # (1, U, 4)
+        allsh = comm.all_gather(local)                                # (world, 1, U, 4)
+        U = local.shape[1]
+        tables = allsh.reshape(G, U, 4).permute(1, 0, 2).contiguous()
+        tail = tail_factory(k, tables)
+        rt = None
+        for j in range(k):
+            evals = wide_reduce(tail.round_partial(rt).cpu().numpy().view(np.uint64))
+            proof[nv_local + j] = evals
+            rng.feed(ProverMsg(evals))
+            rt = rng.sample_fr()
+            rand[nv_local + j] = rt
+    return proof, rand
+
+
 def prove_logical_shards(nv: int, shapes, tables: Sequence[np.ndarray], coeffs: np.ndarray, G: int, device):
     """Single-process, single-GPU run of the sharded protocol with G logical shards (tests / debugging)."""
     k = _log2(G)

@@ -351,3 +351,23 @@ def test_config4_shard_shape_nv25():
         pr = sc.MLSumcheck.prove(ph)
         halves.append(field.to_int(sc.MLSumcheck.extract_sum(pr)))
     assert (halves[0] + halves[1]) % field.P == field.to_int(sc.MLSumcheck.extract_sum(proof))
+
+
+def test_sharded_rounds_inside_the_library_world1():
+    """sc_ml_prove_sharded_rounds with a one-rank RCCL communicator: the all-reduce, publish and fold path of the multi-GPU
+    run, compared with the unsharded oracle proof (one rank => no tail)."""
+    import torch
+    from sumcheck_amd import sharded
+    dev = _torch_dev()
+    nv, shapes, nt = 18, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10
+    tabs = [cref.synth_table(66, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(66, 1000, len(shapes))
+    d = H.desc_from(nv, shapes, tabs, coefs)
+    want, wrand = cref.ml_prove(d, threads=cref.max_threads())
+    engine = sharded.HipShardEngine(nv, shapes, coefs, tabs, dev, borrow=True)
+    ncomm = sharded.NativeComm(dev)
+    for _ in range(2):  # twice: the handle is rewound, buffers are reused
+        engine.reset()
+        got, rand = sharded.prove_sharded_native(engine, ncomm, sharded.DistComm(), nv, 4, None)
+        assert np.array_equal(got, want) and np.array_equal(rand, wrand)
+    ncomm.close()
