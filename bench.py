@@ -221,6 +221,10 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "field-ops/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         else:
             out["cpu_baseline"] = None
+        try:  # RCCL prints its NCCL_DEBUG=VERSION banner through C stdio: push it out first so the JSON line is the last line
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
