@@ -157,6 +157,10 @@ def main():
 
     for _ in range(args.warmup):
         proof = step()
+    try:  # every rank: flush RCCL's NCCL_DEBUG=VERSION banner (C stdio) now, long before rank 0 prints the JSON line
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
     _lib.check(sc.lib().sc_prover_set_timing(handle, 1))  # per-kernel HIP events on the launch stream, timed region only
     barrier()
     t0 = time.perf_counter()
