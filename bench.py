@@ -117,6 +117,7 @@ def main():
     torch.cuda.synchronize()
 
     ncomm = None
+    state_box = {"ncomm": None}
     force_sharded = os.environ.get("SC_BENCH_FORCE_SHARDED") == "1"  # exercise the N>1 code path on one GPU (tests)
     if world == 1 and not force_sharded:
         mles = [sc.DenseMultilinearExtension(nv_local, t) for t in tables]
@@ -143,10 +144,17 @@ def main():
                 log(f"[bench] in-library RCCL rounds unavailable ({e}); using the torch.distributed round loop")
                 ncomm = None
 
+        state_box = {"ncomm": ncomm}
+
         def step():
             engine.reset()
-            if ncomm is not None:
-                return sharded.prove_sharded_native(engine, ncomm, comm, nv_total, max(len(s) for s in shapes), tail_factory)[0]
+            if state_box["ncomm"] is not None:
+                try:
+                    return sharded.prove_sharded_native(engine, state_box["ncomm"], comm, nv_total, max(len(s) for s in shapes), tail_factory)[0]
+                except Exception as e:  # same on every rank (collective failure): drop to the torch.distributed loop for good
+                    log(f"[bench] in-library RCCL rounds failed ({e}); falling back to the torch.distributed round loop")
+                    state_box["ncomm"] = None
+                    engine.reset()
             return sharded.prove_sharded([engine], comm, nv_total, max(len(s) for s in shapes), tail_factory)[0]
 
     def barrier():
@@ -210,7 +218,7 @@ def main():
                                    f" ({nv_local} per GPU shard), BLS12-381 Fr, tables HBM-resident",
                        "nv": nv_total, "nv_per_gpu": nv_local, "tables": U, "degree": max(len(s) for s in shapes),
                        "field_ops_per_step": ops, "sharding": f"high-bit x{world}" if world > 1 else "none",
-                       "round_loop": ("library+rccl" if (world > 1 or force_sharded) and ncomm is not None else
+                       "round_loop": ("library+rccl" if (world > 1 or force_sharded) and state_box["ncomm"] is not None else
                                       ("torch.distributed" if (world > 1 or force_sharded) else "library"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "kernel": f"k_prod_tree<{len(shapes[dom])}> (product {dom}, big rounds)",
