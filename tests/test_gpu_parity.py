@@ -111,6 +111,7 @@ SHAPES = [
     (13, 9, [[0, 1, 2, 3, 4, 5, 6, 7, 8], [0, 0, 0, 0, 0, 0, 0, 0, 0, 0]]),      # generic path (>8 multiplicands)
     (17, 3, [[0, 1, 2]]),                                                        # several grid-stride iterations
     (3, 2, [[0], [1], [0, 1]]),
+    (9, 36, [[3 * i, 3 * i + 1, 3 * i + 2] for i in range(11)] + [[33, 34], [35]]),  # > 32 tables: no small-round kernels
 ]
 
 
