@@ -113,13 +113,17 @@ __device__ __forceinline__ Fe fe_carry_pass(const Fe &a) {
 // a chunk-planar layout chosen so that every store instruction of the bind kernel is contiguous across the wavefront:
 // entries are grouped in blocks of 64 pairs (128 entries, 4 KiB); inside a block, plane k = 2*(entry & 1) + half holds the
 // 16-byte chunk (limbs 4*half .. 4*half+3) of that entry for the 64 pairs side by side:
-//     byte offset(entry e, half) = (e >> 7) * 4096 + (2 * (e & 1) + half) * 1024 + ((e >> 1) & 63) * 16.
-// The writer lane of pair q stores plane k at column q & 63: 64 lanes x 16 B = 1 KiB contiguous per instruction (the
-// reference layout's lane-private 64-byte stores cost 12 % of the mixed read/write HBM rate, profiles/r1_mem_bench.txt).
-// The next round's lane b reads pairs 2b and 2b+1: 16 bytes at a 32-byte lane stride, which streams as fast as contiguous.
+//     byte offset(entry e, half) = (e >> 7) * 4096 + (2 * (e & 1) + half) * 1024 + col(q) * 16,  q = e >> 1 (the pair),
+//     col(q) = ((q & 63) >> 1) | ((q & 1) << 5)   -- even pairs of the block in columns 0..31, odd pairs in 32..63.
+// The writer lane of pair q stores plane k at column col(q): the 64 lanes of a wavefront cover one contiguous 1 KiB row per
+// instruction (the reference layout's lane-private 64-byte stores cost 12 % of the mixed read/write HBM rate,
+// profiles/r1_mem_bench.txt).  The next round's lane b reads pairs 2b and 2b+1, i.e. for each of them 32 consecutive columns
+// per half-wavefront: every load instruction is two contiguous 512-byte runs.
 // Tables in this format always hold a multiple of 128 entries (big rounds only).
 __device__ __forceinline__ uint64_t f29_chunk(uint64_t entry, int half) { // index in uint4 units
-    return (entry >> 7) * 256 + (uint64_t)(2 * (int)(entry & 1) + half) * 64 + ((entry >> 1) & 63);
+    const uint64_t q = entry >> 1; // pair
+    const uint64_t col = ((q & 63) >> 1) | ((q & 1) << 5); // even pairs in columns 0..31, odd pairs in 32..63
+    return (entry >> 7) * 256 + (uint64_t)(2 * (int)(entry & 1) + half) * 64 + col;
 }
 __device__ __forceinline__ Fe fe_load_f29(const uint4 *main, uint64_t entry, int32_t top) {
     const uint4 a = main[f29_chunk(entry, 0)], b = main[f29_chunk(entry, 1)];
