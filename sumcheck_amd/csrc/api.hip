@@ -546,7 +546,6 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
             ProdArgs a;
             std::memset(&a, 0, sizeof(a));
             a.n_slots = (int)pr.M;
-            if (const char *e = std::getenv("SC_DEBUG")) a.debug = std::atoi(e);
             int f = 0;
             for (size_t s = 0; s < pr.tables.size(); ++s) {
                 Table &t = p->tabs[pr.tables[s]];
@@ -586,7 +585,6 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
             ProdArgs a;
             std::memset(&a, 0, sizeof(a));
             a.n_slots = (int)pr.tables.size();
-            if (const char *e = std::getenv("SC_DEBUG")) a.debug = std::atoi(e);
             for (size_t s = 0; s < pr.tables.size(); ++s) {
                 Table &t = p->tabs[pr.tables[s]];
                 a.slot[s].exp = pr.exps[s];

@@ -11,6 +11,10 @@
 //   * p mod 2^32 = 1, so m*p0 + t0 = 2^32*[t0 != 0]: the first reduction column is a compare.
 // The top limb of p is < 2^31 ("spare bit"): a+b never overflows 256 bits and the CIOS running value
 // stays < 2p, so the interleaved form needs no 10th limb.
+//
+// fr_mul is the generated Comba/FIPS product (fr_mul_gen.inc, tools/gen_mac.py); fr_mul_cios is kept as
+// the readable restatement it is tested against.  The big-round kernels do not use this file's product:
+// they compute in the carry-free 9 x 29-bit representation of fe.cuh and only convert at the edges.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -45,7 +45,6 @@ struct Slot {
 struct ProdArgs {
     Slot slot[kMaxFusedM];
     int n_slots;
-    int debug; // experiments only (SC_DEBUG): bit 0 = synthesise operands instead of loading, bit 1 = skip the products
 };
 
 // static per-product record for the finalize kernel (device memory)

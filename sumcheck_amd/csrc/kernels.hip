@@ -15,6 +15,16 @@
 //   per-point evaluation at all deg+1 points).
 //   Per-lane accumulators -> wave64 shuffle reduction -> LDS across the 4 waves -> one partial per
 //   block -> k_finalize.
+//
+// Kernels, by role:
+//   k_prod_tree<M>     production big-round kernel (M <= 4): fe.cuh carry-free arithmetic, evaluation
+//                      nodes 0,1,inf,-1,2,.. , static product tree, F29 internal table format.
+//   k_prod_round<M>    saturated 8 x u32 Comba arithmetic, consecutive-integer nodes (SC_KERNEL=0/1;
+//                      also the path for M in 5..8).
+//   k_prod_round_fe<M> fe.cuh arithmetic without the tree (SC_KERNEL=2) -- kept as a parity cross-check.
+//   k_sum_generic/k_fix  any M, any aliasing pattern; used beyond kMaxFusedM and for > 32 tables.
+//   k_fix_multi + k_sum_combos   latency-oriented pair for rounds with <= 2^16 pairs.
+//   k_finalize         partial sums -> round message (Lagrange matrix, c_k, sum over products).
 #include "fr.cuh"
 #include "fe.cuh"
 #include "kernels.h"
@@ -99,14 +109,8 @@ __global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const F
             Fr lo, hi;
             if (A.slot[s].mode == 0) {
                 const uint4 *p = A.slot[s].src + 4 * b; // pair b = 64 contiguous bytes
-                if (A.debug & 1) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { lo.v[i] = (uint32_t)b * 2654435761u + i + s; hi.v[i] = (uint32_t)(b >> 3) + 77u * i; }
-                    lo.v[7] &= 0x3fffffffu; hi.v[7] &= 0x3fffffffu;
-                } else {
-                    lo = fr_load(p);
-                    hi = fr_load(p + 2);
-                }
+                lo = fr_load(p);
+                hi = fr_load(p + 2);
             } else {
                 const uint4 *p = A.slot[s].src + 8 * b; // entries 4b..4b+3 = 128 contiguous bytes
                 const Fr e0 = fr_load(p), e1 = fr_load(p + 2), e2 = fr_load(p + 4), e3 = fr_load(p + 6);
@@ -136,11 +140,6 @@ __global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const F
 #pragma unroll
                 for (int t = 0; t <= M; ++t) prod[t] = cur[t];
                 k = 1;
-            }
-            if (A.debug & 2) {
-#pragma unroll
-                for (int t = 0; t <= M; ++t) prod[t] = fr_add(prod[t], cur[t]);
-                k = e;
             }
             for (; k < e; ++k) { // nodes in pairs: two independent Montgomery products per asm stream
 #pragma unroll
@@ -182,17 +181,8 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
             Fe lo, hi;
             if (A.slot[s].mode == 0) {
                 const uint4 *p = A.slot[s].src + 4 * b;
-                if (A.debug & 1) {
-                    Fr x, y;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { x.v[i] = (uint32_t)b * 2654435761u + i + s; y.v[i] = (uint32_t)(b >> 3) + 77u * i; }
-                    x.v[7] &= 0x3fffffffu; y.v[7] &= 0x3fffffffu;
-                    lo = fe_from_fr(x);
-                    hi = fe_from_fr(y);
-                } else {
-                    lo = fe_from_fr(fr_load(p));
-                    hi = fe_from_fr(fr_load(p + 2));
-                }
+                lo = fe_from_fr(fr_load(p));
+                hi = fe_from_fr(fr_load(p + 2));
             } else {
                 const uint4 *p = A.slot[s].src + 8 * b;
                 const Fe e0 = fe_from_fr(fr_load(p)), e1 = fe_from_fr(fr_load(p + 2));
@@ -225,7 +215,6 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
                 }
                 uint32_t k = 0;
                 if (first) { prod[t] = (nv == 0 || nv == 1) ? cur : fe_carry_pass(cur); k = 1; }
-                if (A.debug & 2) { prod[t] = fe_carry_pass(fe_add(prod[t], cur)); k = e; }
                 for (; k < e; ++k) prod[t] = fe_mul(cur, prod[t]);
             }
             first = false;
