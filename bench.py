@@ -194,11 +194,15 @@ def main():
     if rank == 0:
         ops = field_ops(nv_total, shapes, U)
         value = ops * args.steps / elapsed
-        # dominant kernel: k_prod_tree<4> (product 0: 4 of the 10 tables).  It is launched once per BIG round (more than 2^16
+        # dominant kernel: k_round_tree (all products; or k_prod_tree<4>, product 0, with SC_MERGE=0).  It is launched once per BIG round (more than 2^16
         # pairs; later rounds are latency-bound and run through k_fix_multi / k_sum_combos).  Algorithmic bytes of those launches:
         # round 1 reads the product's tables once; round i >= 2 reads T_{i-1} and writes T_i (32-byte elements).
+        # With every product at <= 4 multiplicands the library runs a big round as ONE launch, k_round_tree, over all products:
+        # its event pair is reported under product 0 and the other products report no launches.
         dom = int(np.argmax(list(ms)))
-        u_dom = len(set(shapes[dom]))
+        merged = K > 1 and ln[0] > 0 and all(ln[k] == 0 for k in range(1, K))
+        u_dom = U if merged else len(set(shapes[dom]))
+        kname = "k_round_tree" if merged else f"k_prod_tree<{len(shapes[dom])}>"
         big_rounds = max(nv_local - 17, 1) if nv_local > 17 else 0
         big_bytes = 32 * u_dom * ((1 << nv_local) + sum((1 << (nv_local - i + 2)) + (1 << (nv_local - i + 1)) for i in range(2, big_rounds + 1)))
         launches = int(ln[dom])
@@ -208,7 +212,7 @@ def main():
         traffic = None  # measured off-line with rocprofv3 PMC passes (tools/profile.sh), per launch of the same kernel
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")))
-            if tj.get("kernel", "").endswith(f"k_prod_tree<{len(shapes[dom])}>") and nv_local == 24:
+            if tj.get("kernel", "").endswith(kname) and nv_local == 24:
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             pass
@@ -225,7 +229,7 @@ def main():
                        "round_loop": ("library+rccl" if (world > 1 or force_sharded) and state_box["ncomm"] is not None else
                                       ("torch.distributed" if (world > 1 or force_sharded) else "library"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": f"k_prod_tree<{len(shapes[dom])}> (product {dom}, big rounds)",
+                         "traffic": traffic, "kernel": f"{kname} ({'all products, one launch per big round' if merged else f'product {dom}, big rounds'})",
                          "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "all_kernels_GBps": all_kernels_gbps, "all_kernels_ms_per_step": rounds_ms.value / args.steps,
                          "per_product_ms_per_step": [m / args.steps for m in ms]},

@@ -169,11 +169,14 @@ SC_API int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_
  * stream `stream` starting at element `first`, written to device memory d_out (n x 4 limbs). */
 SC_API int sc_synth_table_device(uint64_t seed, uint64_t stream, uint64_t first, uint64_t n, uint64_t *d_out);
 /* Device-side timing of the handle's last sc_prove_round: milliseconds between HIP events recorded
- * on the handle's stream around the round's kernels (excludes the D2H of the evaluations). */
+ * on the handle's stream around the round's kernels (excludes the D2H of the evaluations).  The events
+ * are only recorded while sc_prover_set_timing(p, 1) is in effect (they cost a few microseconds per round). */
 SC_API int sc_prover_last_round_ms(sc_prover *p, float *ms);
 /* Per-product instrumentation: with timing on, every product kernel launch is bracketed by HIP events on the
  * handle's stream; sc_prover_get_timing returns the accumulated device milliseconds and launch counts per
- * product (K entries each) and the accumulated per-round span (all kernels of a round incl. finalize). */
+ * product (K entries each) and the accumulated per-round span (all kernels of a round incl. finalize).
+ * When a round runs as one launch over all its products (every product has <= 4 multiplicands: k_round_tree),
+ * that launch is reported under product 0 and the other products report no launches. */
 SC_API int sc_prover_set_timing(sc_prover *p, int on);
 SC_API int sc_prover_get_timing(sc_prover *p, double *ms_per_product, uint64_t *launches_per_product, double *rounds_ms);
 /* Rewind a handle to round 0 without reallocating (repeated proofs over resident tables).  Borrowing handle:

@@ -7,6 +7,7 @@
 #include <rccl/rccl.h> // types and enums only: the entry points are bound with dlsym
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -161,6 +162,8 @@ struct sc_prover {
     std::vector<hipStream_t> pstreams;
     std::vector<hipEvent_t> pjoin;
     hipEvent_t ev_fork = nullptr;
+    bool merge_rounds = false; // big rounds run as ONE launch over all products (k_round_tree); SC_MERGE=0 disables
+    int rotate = 1;            // product rotation inside that launch (SC_ROTATE, see RoundArgs)
     bool use_f29 = false; // bound tables of big rounds kept in the internal 9 x 29-bit format (all products <= 4 multiplicands)
     bool use_fe = true; // big rounds in carry-free arithmetic (fe.cuh); SC_FE=0 selects the saturated kernels
     int kernel_variant = 3; // SC_KERNEL: 0 = lane-per-pair (k_prod_round[_fe]), 2 = tiled LDS-staged (k_round_tile), 3 = product tree
@@ -168,6 +171,7 @@ struct sc_prover {
     bool borrow = false;
     std::vector<const uint4 *> origin; // borrowed table pointers (borrow mode)
     bool timing = false, timing_pending = false;
+    bool prod_merged = false; // ... as one event pair around the merged launch (attributed to product 0)
     bool prod_timed = false; // the pending round recorded per-product events (big rounds only)
     std::vector<hipEvent_t> prod_ev;   // 2 per product
     std::vector<double> prod_ms;       // accumulated device time of each product's kernel
@@ -286,6 +290,11 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     // with more tables than the small-round kernels take, the big-round kernels also run the short rounds, whose tables are
     // smaller than one 128-entry block of the chunk-planar layout
     if (d->n_tables > (uint32_t)scd::kMaxSmallTables) p->use_f29 = false;
+    p->merge_rounds = p->kernel_variant == 3 && d->n_products > 0 && d->n_products <= (uint32_t)scd::kMaxRoundProds;
+    for (uint32_t k = 0; k < d->n_products; ++k)
+        if (d->prod_offsets[k + 1] - d->prod_offsets[k] > 4) p->merge_rounds = false;
+    if (const char *e = std::getenv("SC_MERGE")) p->merge_rounds = p->merge_rounds && std::atoi(e) != 0;
+    if (const char *e = std::getenv("SC_ROTATE")) p->rotate = std::atoi(e);
 
     // products: distinct tables + multiplicities
     uint64_t partial_elems = 0;
@@ -449,7 +458,7 @@ static int collect_timing(sc_prover *p) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
     p->rounds_ms += ms;
-    for (uint32_t k = 0; k < p->K && p->prod_timed; ++k) { // big rounds only: one fused kernel launch per product
+    for (uint32_t k = 0; k < (p->prod_merged ? 1u : p->K) && p->prod_timed; ++k) { // big rounds only: one fused kernel launch per product
         HIP_TRY(hipEventElapsedTime(&ms, p->prod_ev[2 * k], p->prod_ev[2 * k + 1]));
         p->prod_ms[k] += ms;
         p->prod_launches[k] += 1;
@@ -487,8 +496,31 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     int scaled = 0;
     const bool small_round = n_pairs <= scd::kSmallRoundPairs && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0;
     const bool tiled = !small_round && !p->any_generic && p->kernel_variant == 2;
-    const int grid = tiled ? scd::grid_for_tiles(n_pairs) : scd::grid_for_pairs(n_pairs);
-    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    scd::BindConst rc; // (only the big rounds of the tree kernels pay for it)
+    std::memset(&rc, 0, sizeof(rc)); // tree kernels: rows (r * 2^(29 i + 58)) mod p as plain 29-bit limbs (fe.cuh, fe_mul_bind)
+    if (bind && !small_round && p->kernel_variant == 3) {
+        static const std::array<sch::Fr, 9> pow2 = [] { // Montgomery form of 2^(29 i + 58)
+            std::array<sch::Fr, 9> t;
+            sch::Fr c = sch::kOne;
+            for (int d = 0; d < 58; ++d) c = sch::add(c, c);
+            for (int i = 0; i < 9; ++i) {
+                t[i] = c;
+                for (int d = 0; d < 29; ++d) c = sch::add(c, c);
+            }
+            return t;
+        }();
+        for (int i = 0; i < 9; ++i) {
+            const sch::Fr x = sch::to_canonical(sch::mul(r, pow2[i]));
+            for (int k = 0; k < 9; ++k) {
+                const int bit = 29 * k, w = bit >> 6, sh = bit & 63;
+                uint64_t v = x.l[w] >> sh;
+                if (sh > 35 && w < 3) v |= x.l[w + 1] << (64 - sh);
+                rc.R[i][k] = (int32_t)(v & 0x1fffffffULL);
+            }
+        }
+    }
+    int grid = tiled ? scd::grid_for_tiles(n_pairs) : scd::grid_for_pairs(n_pairs);
+    if (p->timing) HIP_TRY(hipEventRecord(p->ev0, p->stream));
 
     auto bind_table = [&](uint32_t u) -> hipError_t { // stand-alone bind of table u (2*n_pairs outputs)
         Table &t = p->tabs[u];
@@ -532,7 +564,59 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     hipStream_t main_stream = p->stream;
     const bool fork = p->par_products && !small;
     if (fork) HIP_TRY(hipEventRecord(p->ev_fork, main_stream));
-    for (uint32_t k = 0; k < p->K && !small; ++k) {
+    const bool merged = !small && !fork && p->merge_rounds && !p->any_generic;
+    if (merged) {
+        grid = std::min(grid, scd::kRoundTreeGrid);
+        // One launch for the round.  The first factor touching a table binds and stores it (mode 1); every later factor on
+        // that table -- in the same or in another product -- re-binds from the old buffer without storing (mode 3), so no
+        // product reads what another one writes in this launch.
+        scd::RoundArgs ra;
+        std::memset(&ra, 0, sizeof(ra));
+        ra.n_prod = (int)p->K;
+        ra.rotate = p->rotate;
+        std::vector<const uint4 *> old_src(p->U);
+        std::vector<const int32_t *> old_top(p->U);
+        for (uint32_t u = 0; u < p->U; ++u) {
+            old_src[u] = p->tabs[u].cur;
+            old_top[u] = p->tabs[u].cur_top;
+        }
+        for (uint32_t k = 0; k < p->K; ++k) {
+            const Product &pr = p->prods[k];
+            scd::TreeProd &tp = ra.prod[k];
+            tp.M = pr.M;
+            tp.partial_off = pr.partial_off;
+            int f = 0;
+            for (size_t s = 0; s < pr.tables.size(); ++s) {
+                const uint32_t u = pr.tables[s];
+                Table &t = p->tabs[u];
+                for (uint32_t rep = 0; rep < pr.exps[s]; ++rep, ++f) {
+                    scd::Slot &sl = tp.slot[f];
+                    sl.exp = 1;
+                    sl.src = old_src[u];
+                    sl.src_top = old_top[u];
+                    if (!bind) {
+                        sl.mode = 0;
+                    } else if (!bound[u]) {
+                        sl.mode = 1;
+                        sl.dst = t.buf[t.next];
+                        sl.dst_top = p->use_f29 ? t.buf_top[t.next] : nullptr;
+                        t.cur = t.buf[t.next];
+                        t.cur_top = sl.dst_top;
+                        t.next ^= 1;
+                        bound[u] = 1;
+                    } else {
+                        sl.mode = 3;
+                        sl.dst_top = p->use_f29 ? t.buf_top[0] : nullptr; // only selects the carry-pass path
+                    }
+                }
+            }
+        }
+        if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[0], p->stream));
+        HIP_TRY(scd::launch_round_tree(ra, rc, n_pairs, p->d_partials, grid, p->stream));
+        if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[1], p->stream));
+        scaled = 1;
+    }
+    for (uint32_t k = 0; k < p->K && !small && !merged; ++k) {
         const Product &pr = p->prods[k];
         FrHost *partials = p->d_partials + pr.partial_off;
         if (fork) {
@@ -579,7 +663,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
                     }
                 }
             }
-            HIP_TRY(scd::launch_prod_tree((int)pr.M, a, r32, n_pairs, partials, grid, p->stream));
+            HIP_TRY(scd::launch_prod_tree((int)pr.M, a, rc, n_pairs, partials, grid, p->stream));
             scaled = 1;
         } else         if (pr.fused) {
             ProdArgs a;
@@ -634,17 +718,24 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     HIP_TRY(scd::launch_finalize(p->d_finprods, p->d_W, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide,
                                  publish_to_host ? p->h_out_dev : nullptr, publish_to_host ? p->h_flag_dev : nullptr, p->seq, scaled,
                                  p->stream));
-    HIP_TRY(hipEventRecord(p->ev1, p->stream));
-    p->timed = true;
+    if (p->timing) HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    p->timed = p->timing;
     p->timing_pending = p->timing;
     p->prod_timed = p->timing && !small;
+    p->prod_merged = merged;
     return SC_OK;
 }
+
+static int await_round(sc_prover *p, uint64_t *out_evals);
 
 extern "C" int sc_prove_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals) {
     if (!p || !out_evals) return fail(SC_ERR_BAD_ARG, "null argument");
     int rc = launch_round(p, r_or_null, nullptr, true);
     if (rc) return rc;
+    return await_round(p, out_evals);
+}
+
+static int await_round(sc_prover *p, uint64_t *out_evals) {
     // The message is written by k_finalize straight into host-mapped pinned memory, followed by a system-scope release of
     // the sequence flag: poll it instead of paying a DMA copy plus an interrupt-driven stream synchronise every round.
     const uint32_t want = p->seq;
@@ -720,7 +811,7 @@ extern "C" int sc_prover_state(sc_prover *p, uint64_t *randomness, uint32_t *n_r
 
 extern "C" int sc_prover_last_round_ms(sc_prover *p, float *ms) {
     if (!p || !ms) return fail(SC_ERR_BAD_ARG, "null argument");
-    if (!p->timed) return fail(SC_ERR_BAD_ARG, "no round has been launched");
+    if (!p->timed) return fail(SC_ERR_BAD_ARG, "no timed round: enable sc_prover_set_timing before the round");
     HIP_TRY(hipEventSynchronize(p->ev1));
     HIP_TRY(hipEventElapsedTime(ms, p->ev0, p->ev1));
     return SC_OK;
@@ -908,14 +999,29 @@ extern "C" int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *o
     const uint32_t D = p->D;
     sch::Fr vm = sch::zero();
     bool have = false;
+    static const bool trace = std::getenv("SC_HOST_TRACE") != nullptr; // stderr: where the host's share of a proof goes
+    using clk = std::chrono::steady_clock;
+    double t_launch = 0, t_wait = 0, t_fs = 0;
     for (uint32_t i = 0; i < p->nv; ++i) {
         uint64_t *pm = out_proof + (size_t)i * D * 4;
-        int rc = sc_prove_round(p, have ? vm.l : nullptr, pm);
+        const auto t0 = clk::now();
+        int rc = launch_round(p, have ? vm.l : nullptr, nullptr, true);
         if (rc) return rc;
+        const auto t1 = clk::now();
+        rc = await_round(p, pm);
+        if (rc) return rc;
+        const auto t2 = clk::now();
         rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(pm), D); // mod.rs:61
         vm = rng.sample_fr();                                           // mod.rs:63
         have = true;
+        if (trace) {
+            const auto t3 = clk::now();
+            t_launch += std::chrono::duration<double, std::micro>(t1 - t0).count();
+            t_wait += std::chrono::duration<double, std::micro>(t2 - t1).count();
+            t_fs += std::chrono::duration<double, std::micro>(t3 - t2).count();
+        }
     }
+    if (trace) std::fprintf(stderr, "[sc] proof host time: launch %.1f us, wait %.1f us, transcript %.1f us (%u rounds)\n", t_launch, t_wait, t_fs, p->nv);
     p->randomness.push_back(vm); // mod.rs:65-67: recorded, never bound
     return SC_OK;
 }

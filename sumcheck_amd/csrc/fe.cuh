@@ -182,6 +182,74 @@ __device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {
 __device__ __forceinline__ Fe fe_mul(const Fe &a, const Fe &b) { return fe_mul_t<Fe>(a, b); }
 __device__ __forceinline__ Fe fe_mul_u(const Fe &a, const FeU &u) { return fe_mul_t<FeU>(a, u); }
 
+// d * r (mod p) for the round's fixed challenge r, d the lazy difference of two table entries (|limbs| < 2^29 + 16).
+// C.R[i] = (r * 2^(29 i + 58)) mod p, so S = sum_i d_i * R_i is congruent to d * r * 2^58 and already NINE columns wide: no high
+// half to fold.  Two Montgomery steps (m0, m1; p_0 = 1, -p^-1 = -1 mod 2^29) divide by 2^58:
+//   T = (S + m0 p + m1 p 2^29) / 2^58,   |T| < 2^230 + p (1 + 2^-29),
+// 81 + 16 = 97 multiply-adds instead of the 153 of a general product.  Result limbs 0..7 in [0, 2^29), limb 8 signed, |.| < 2^24.
+// The 81 constants do not fit the SGPR file next to everything else, so the block parks them in LDS, column-major
+// (RT[12 k + i] = R[i][k], kBindLds ints), and every column's nine constants come back with three broadcast ds_read_b128 that
+// serve BOTH products of a table's pair (entries 2b and 2b+1 are bound by the same r).
+constexpr int kBindLds = 9 * 12;
+__device__ __forceinline__ void bind_consts_to_lds(const BindConst &C, int32_t (&RT)[kBindLds]) {
+    for (int i = threadIdx.x; i < kBindLds; i += blockDim.x) {
+        const int k = i / 12, row = i % 12;
+        RT[i] = row < 9 ? C.R[row][k] : 0;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ Fe fe_mul_bind(const Fe &d, const int32_t (&RT)[kBindLds]) {
+    uint32_t off = 0;
+    asm volatile("" : "+v"(off)); // keep the constant loads inside the pair loop (hoisted, they would pin 81 VGPRs)
+    const int32_t *q = RT + off;
+    int64_t acc = 0;
+    int32_t m0 = 0, m1 = 0;
+    Fe r;
+    // one column ahead: column k+1's constants are in flight while column k multiplies; the compiler barriers keep the 27
+    // loads from being issued up front (72 more live VGPRs)
+    int4 n0 = *reinterpret_cast<const int4 *>(q), n1 = *reinterpret_cast<const int4 *>(q + 4);
+    int32_t n2 = q[8];
+#pragma unroll
+    for (int k = 0; k <= 9; ++k) {
+        if (k < 9) {
+            const int32_t c[9] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2};
+            asm volatile("" : "+v"(acc)::"memory"); // orders column k-1's multiply-adds before column k+1's loads
+            if (k < 8) {
+                n0 = *reinterpret_cast<const int4 *>(q + 12 * (k + 1));
+                n1 = *reinterpret_cast<const int4 *>(q + 12 * (k + 1) + 4);
+                n2 = q[12 * (k + 1) + 8];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc += (int64_t)d.l[i] * (int64_t)c[i];
+        }
+        if (k >= 1 && k < 9) acc += (int64_t)m0 * (int64_t)fe_p_limb(k);
+        if (k >= 2) acc += (int64_t)m1 * (int64_t)fe_p_limb(k - 1);
+        if (k == 0) {
+            m0 = (int32_t)((0u - (uint32_t)acc) & (uint32_t)kFeMask);
+            acc += m0;
+        } else if (k == 1) {
+            m1 = (int32_t)((0u - (uint32_t)acc) & (uint32_t)kFeMask);
+            acc += m1;
+        } else {
+            r.l[k - 2] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask);
+        }
+        acc >>= 29;
+    }
+    r.l[8] = (int32_t)acc;
+    return r;
+}
+
+// Compiler fence on three elements: they are computed before, and stay in registers across, this point.  (Without it the
+// half-products of factors 0,1 are sunk below the loads and binds of factors 2,3 and all four lines are live at once.)
+__device__ __forceinline__ void fe_pin3(Fe &a, Fe &b, Fe &c) {
+    asm volatile(""
+                 : "+v"(a.l[0]), "+v"(a.l[1]), "+v"(a.l[2]), "+v"(a.l[3]), "+v"(a.l[4]), "+v"(a.l[5]), "+v"(a.l[6]), "+v"(a.l[7]), "+v"(a.l[8]),
+                   "+v"(b.l[0]), "+v"(b.l[1]), "+v"(b.l[2]), "+v"(b.l[3]), "+v"(b.l[4]), "+v"(b.l[5]), "+v"(b.l[6]), "+v"(b.l[7]), "+v"(b.l[8]),
+                   "+v"(c.l[0]), "+v"(c.l[1]), "+v"(c.l[2]), "+v"(c.l[3]), "+v"(c.l[4]), "+v"(c.l[5]), "+v"(c.l[6]), "+v"(c.l[7]), "+v"(c.l[8])
+                 :
+                 : "memory");
+}
+
 // Exact canonical conversion: any value with |v| < 2^260 -> the representative in [0, p) as 8 x u32.
 __device__ __forceinline__ Fr fe_to_fr(const Fe &a) {
     // 1. normalise, estimate the quotient by p from the top limb (= floor(v / 2^232))

@@ -25,6 +25,12 @@ __host__ __device__ constexpr int32_t node_value(int s) {
     return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? kNodeInf : ((s - 3) % 2 == 0 ? -((s - 3) / 2 + 1) : ((s - 3) / 2 + 2));
 }
 
+// The round's challenge, prepared by the host for the bind of the tree kernels (fe.cuh: fe_mul_bind): row i holds the nine
+// 29-bit limbs of (r * 2^(29 i + 58)) mod p as a plain integer, r the challenge's standard (non-Montgomery) value.
+struct BindConst {
+    int32_t R[9][9];
+};
+
 // One distinct table of a product.  mode 0: `src` already holds this round's table (2*n_pairs entries).
 // mode 1: `src` holds the previous round's table (4*n_pairs entries); the kernel binds the previous
 // challenge on the fly, writes this round's table (2*n_pairs entries) to `dst`, and sums from registers.
@@ -45,6 +51,24 @@ struct Slot {
 struct ProdArgs {
     Slot slot[kMaxFusedM];
     int n_slots;
+};
+
+// One launch for a whole round (every product has <= 4 multiplicands): each block walks all the round's products over its
+// own share of the pairs, so a round is one kernel with no launch gaps and the multiplier-bound products (M = 3, 4) of
+// some blocks overlap the HBM-bound ones (M = 1, 2) of others.  Partials keep the per-product layout k_finalize reads.
+constexpr int kMaxRoundProds = 12;
+constexpr int kRoundTreeGrid = 768; // k_round_tree holds 3 blocks per CU (156 VGPRs, 46 KB LDS): one full wave of blocks on 256 CUs
+struct TreeProd {
+    Slot slot[4];
+    uint32_t M;
+    uint32_t pad;
+    uint64_t partial_off; // in field elements, as in FinProd
+};
+struct RoundArgs {
+    TreeProd prod[kMaxRoundProds];
+    int n_prod;
+    int rotate; // 0: every block walks the products in order; 1: start product rotated by blockIdx % 8 (dispatch slot = XCD);
+                // 2: rotated by blockIdx
 };
 
 // static per-product record for the finalize kernel (device memory)
@@ -82,8 +106,10 @@ hipError_t launch_prod_round_fe(int M, const ProdArgs &args, const FrHost &r32, 
                                 hipStream_t stream);
 // production big-round kernel: args list exactly M factors (repeated tables listed repeatedly; modes 0 / 1 / 3), static
 // multiplication tree per M; same partial layout and 2^(-5(M-1)) scaling as launch_prod_round_fe
-hipError_t launch_prod_tree(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
+hipError_t launch_prod_tree(int M, const ProdArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid,
                             hipStream_t stream);
+// all products of a round in one launch (see RoundArgs); d_partials is the base of the partial-sum array
+hipError_t launch_round_tree(const RoundArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
 // tiled variant (LDS-staged, one wavefront per node): grid from grid_for_tiles, same partial layout and scaling as _fe
 int grid_for_tiles(uint64_t n_pairs);
 hipError_t launch_round_tile(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,

@@ -300,97 +300,185 @@ __device__ __forceinline__ void tree_nodes(const Fe (&lo)[M], const Fe (&hi)[M],
     }
 }
 
-// compile-time loop over the factors (a plain loop is not reliably unrolled here, which would push lo[]/hi[] to scratch)
-template <int F, int M>
-struct LoadFactors {
-    static __device__ __forceinline__ void run(const ProdArgs &A, const uint64_t b, const FeU &r, Fe (&lo)[M], Fe (&hi)[M]) {
-        const uint32_t mode = A.slot[F].mode;
-        const int32_t *stop = A.slot[F].src_top; // non-null: the source table is in the internal F29 format
+// factor F of the product at pair b: its line's two end points (lo, hi), binding / storing as the slot's mode says
+template <int F>
+struct LoadFactor {
+    static __device__ __forceinline__ void run(const Slot *S, const uint64_t b, const int32_t (&r)[kBindLds], Fe &lo_out, Fe &hi_out) {
+        const Slot &sl = S[F];
+        const uint32_t mode = sl.mode;
+        const int32_t *stop = sl.src_top; // non-null: the source table is in the internal F29 format
         if (mode == 0) {
-            const uint4 *p = A.slot[F].src + 4 * b;
+            const uint4 *p = sl.src + 4 * b;
             if (stop) {
                 const int2 t = *reinterpret_cast<const int2 *>(stop + 2 * b);
-                lo[F] = fe_load_f29(A.slot[F].src, 2 * b, t.x);
-                hi[F] = fe_load_f29(A.slot[F].src, 2 * b + 1, t.y);
+                lo_out = fe_load_f29(sl.src, 2 * b, t.x);
+                hi_out = fe_load_f29(sl.src, 2 * b + 1, t.y);
             } else {
-                lo[F] = fe_from_fr(fr_load(p));
-                hi[F] = fe_from_fr(fr_load(p + 2));
+                lo_out = fe_from_fr(fr_load(p));
+                hi_out = fe_from_fr(fr_load(p + 2));
             }
         } else {
-            const uint4 *p = A.slot[F].src + 8 * b; // entries 4b..4b+3 of the previous table: 128 contiguous bytes
+            const uint4 *p = sl.src + 8 * b; // entries 4b..4b+3 of the previous table: 128 contiguous bytes
             Fe e0, e1, e2, e3;
             if (stop) {
                 const int4 t = *reinterpret_cast<const int4 *>(stop + 4 * b);
-                const uint4 *m = A.slot[F].src;
+                const uint4 *m = sl.src;
                 e0 = fe_load_f29(m, 4 * b, t.x); e1 = fe_load_f29(m, 4 * b + 1, t.y);
                 e2 = fe_load_f29(m, 4 * b + 2, t.z); e3 = fe_load_f29(m, 4 * b + 3, t.w);
             } else {
                 e0 = fe_from_fr(fr_load(p)); e1 = fe_from_fr(fr_load(p + 2)); e2 = fe_from_fr(fr_load(p + 4)); e3 = fe_from_fr(fr_load(p + 6));
             }
-            const Fe l0 = fe_add(e0, fe_mul_u(fe_sub(e1, e0), r));
-            const Fe h0 = fe_add(e2, fe_mul_u(fe_sub(e3, e2), r));
-            if (A.slot[F].dst_top || (mode == 3 && stop)) {
-                // internal F29 tables: ONE parallel carry pass, no modular reduction.  The value grows by < p + 2^252 per bind
-                // (|r*(e1-e0)| image in (-2^251, p + 2^251)), i.e. stays below (rounds+1) p < 2^261 for any nv <= 40, which every
-                // consumer tolerates: fe_mul bounds depend on limb sizes only (limbs 0..7 are re-tightened here, the top limb
-                // stays below 2^28), and fe_to_fr reduces any |v| < 2^260 exactly.
-                lo[F] = fe_carry_pass(l0);
-                hi[F] = fe_carry_pass(h0);
+            const Fe l0 = fe_add(e0, fe_mul_bind(fe_sub(e1, e0), r));
+            asm volatile("" : "+v"(e3.l[8]) : "v"(l0.l[8])); // one product at a time: interleaving the two doubles the live constants
+            const Fe h0 = fe_add(e2, fe_mul_bind(fe_sub(e3, e2), r));
+            if (sl.dst_top || (mode == 3 && stop)) {
+                // internal F29 tables: ONE parallel carry pass, no modular reduction.  The value grows by < p + 2^231 per bind
+                // (fe_mul_bind: r*(e1-e0) comes back in (-2^230, p + 2^230)), i.e. stays below (rounds+1) p < 2^261 for any
+                // nv <= 40, which every consumer tolerates: the multipliers' bounds depend on limb sizes only (limbs 0..7 are
+                // re-tightened here, the top limb stays below 2^28), and fe_to_fr reduces any |v| < 2^260 exactly.
+                lo_out = fe_carry_pass(l0);
+                hi_out = fe_carry_pass(h0);
                 if (mode == 1) {
-                    fe_store_f29(A.slot[F].dst, 2 * b, lo[F]);
-                    fe_store_f29(A.slot[F].dst, 2 * b + 1, hi[F]);
-                    *reinterpret_cast<int2 *>(A.slot[F].dst_top + 2 * b) = make_int2(lo[F].l[8], hi[F].l[8]);
+                    fe_store_f29(sl.dst, 2 * b, lo_out);
+                    fe_store_f29(sl.dst, 2 * b + 1, hi_out);
+                    *reinterpret_cast<int2 *>(sl.dst_top + 2 * b) = make_int2(lo_out.l[8], hi_out.l[8]);
                 }
             } else { // tables stay canonical in the reference layout
                 const Fr lc = fe_to_fr(l0), hc = fe_to_fr(h0);
                 if (mode == 1) {
-                    uint4 *q = A.slot[F].dst + 4 * b;
+                    uint4 *q = sl.dst + 4 * b;
                     fr_store(q, lc);
                     fr_store(q + 2, hc);
                 }
-                lo[F] = fe_from_fr(lc);
-                hi[F] = fe_from_fr(hc);
+                lo_out = fe_from_fr(lc);
+                hi_out = fe_from_fr(hc);
             }
         }
-        LoadFactors<F + 1, M>::run(A, b, r, lo, hi);
     }
 };
-template <int M>
-struct LoadFactors<M, M> {
-    static __device__ __forceinline__ void run(const ProdArgs &, const uint64_t, const FeU &, Fe (&)[M], Fe (&)[M]) {}
-};
 
+// one product's pass of a block over its share of the pairs: row = this block's M+1 partial sums of that product
 template <int M>
-__global__ __launch_bounds__(kBlock) void k_prod_tree(const ProdArgs A, const FrHost r32_h, const uint64_t n_pairs,
-                                                      uint4 *__restrict__ partials) {
-    __shared__ uint32_t sm[kBlock / 64][8];
-    const FeU r = feu_from_host(r32_h);
-    Fe acc[M + 1];
+__device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBindLds], const uint64_t n_pairs, uint4 *__restrict__ row, uint32_t (*sm)[8],
+                                          int32_t *lacc) {
+    // The M+1 running sums live in LDS (limb-planar, one column per thread: lacc[(9 t + limb) * kBlock + tid], conflict-free and
+    // private to the thread, so no barrier): 45 VGPRs less for M = 4, one more resident block per CU.
+    int32_t *my = lacc + threadIdx.x;
 #pragma unroll
-    for (int t = 0; t <= M; ++t) acc[t] = fe_zero();
+    for (int i = 0; i < 9 * (M + 1); ++i) my[i * kBlock] = 0;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     uint32_t iter = 0;
     for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_pairs; b += stride, ++iter) {
-        Fe lo[M], hi[M];
-        LoadFactors<0, M>::run(A, b, r, lo, hi);
+        // Factors are loaded (and bound) in the order the tree consumes them, so at most two lines are live next to the
+        // half-products: a0/a1/ai of factors 0,1 are formed before factors 2,3 are touched.
         Fe P[M + 1];
-        tree_nodes<M>(lo, hi, P);
-        if (iter & 1u) { // limbs: tightened + two products' limbs < 3 * 2^29 < 2^31, so a carry pass every other iteration suffices
-#pragma unroll
-            for (int t = 0; t <= M; ++t) acc[t] = fe_carry_pass(fe_add(acc[t], P[t]));
+        if constexpr (M == 1) {
+            LoadFactor<0>::run(S, b, r, P[0], P[1]);
+        } else if constexpr (M == 2) {
+            Fe l0, h0, l1, h1;
+            LoadFactor<0>::run(S, b, r, l0, h0);
+            LoadFactor<1>::run(S, b, r, l1, h1);
+            P[0] = fe_mul(l0, l1);
+            P[1] = fe_mul(h0, h1);
+            P[2] = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
+        } else if constexpr (M == 3) {
+            Fe q0, q1, qi;
+            {
+                Fe l0, h0, l1, h1;
+                LoadFactor<0>::run(S, b, r, l0, h0);
+                LoadFactor<1>::run(S, b, r, l1, h1);
+                q0 = fe_mul(l0, l1);
+                q1 = fe_mul(h0, h1);
+                qi = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
+            }
+            fe_pin3(q0, q1, qi);
+            const Fe qm1 = fe_carry_pass(fe_sub(fe_add(fe_add(qi, qi), fe_add(q0, q0)), q1)); // q(-1) = 2 q(0) + 2 q(inf) - q(1)
+            Fe l2, h2;
+            LoadFactor<2>::run(S, b, r, l2, h2);
+            P[0] = fe_mul(l2, q0);
+            P[1] = fe_mul(h2, q1);
+            P[2] = fe_mul(fe_sub(h2, l2), qi);
+            P[3] = fe_mul(fe_sub(fe_add(l2, l2), h2), qm1); // f2(-1) = 2 lo - hi
         } else {
-#pragma unroll
-            for (int t = 0; t <= M; ++t) acc[t] = fe_add(acc[t], P[t]);
+            static_assert(M == 4, "the tree kernels take products of at most four multiplicands");
+            Fe a0, a1, ai, b0, b1, bi;
+            {
+                Fe l0, h0, l1, h1;
+                LoadFactor<0>::run(S, b, r, l0, h0);
+                LoadFactor<1>::run(S, b, r, l1, h1);
+                a0 = fe_mul(l0, l1);
+                a1 = fe_mul(h0, h1);
+                ai = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
+            }
+            fe_pin3(a0, a1, ai);
+            {
+                Fe l2, h2, l3, h3;
+                LoadFactor<2>::run(S, b, r, l2, h2);
+                LoadFactor<3>::run(S, b, r, l3, h3);
+                b0 = fe_mul(l2, l3);
+                b1 = fe_mul(h2, h3);
+                bi = fe_mul(fe_sub(h2, l2), fe_sub(h3, l3));
+            }
+            // a quadratic from its values at 0, 1 and its leading coefficient: q(-1) = 2 q(0) + 2 q(inf) - q(1), q(2) = 2 q(1) + 2 q(inf) - q(0)
+            const Fe a2i = fe_add(ai, ai), b2i = fe_add(bi, bi);
+            P[0] = fe_mul(a0, b0);
+            P[1] = fe_mul(a1, b1);
+            P[2] = fe_mul(ai, bi);
+            P[3] = fe_mul(fe_carry_pass(fe_sub(fe_add(a2i, fe_add(a0, a0)), a1)), fe_carry_pass(fe_sub(fe_add(b2i, fe_add(b0, b0)), b1)));
+            P[4] = fe_mul(fe_carry_pass(fe_sub(fe_add(a2i, fe_add(a1, a1)), a0)), fe_carry_pass(fe_sub(fe_add(b2i, fe_add(b1, b1)), b0)));
         }
-        if ((iter & 31u) == 31u) { // keep the top limb far from 2^31 on very long grid-stride loops
 #pragma unroll
-            for (int t = 0; t <= M; ++t) acc[t] = fe_from_fr(fe_to_fr(acc[t]));
+        for (int t = 0; t <= M; ++t) {
+            Fe a;
+#pragma unroll
+            for (int l = 0; l < 9; ++l) a.l[l] = my[(9 * t + l) * kBlock];
+            a = fe_add(a, P[t]);
+            // limbs: tightened + two products' limbs < 3 * 2^29 < 2^31, so a carry pass every other iteration suffices
+            if (iter & 1u) a = fe_carry_pass(a);
+            if ((iter & 31u) == 31u) a = fe_from_fr(fe_to_fr(a)); // keep the top limb far from 2^31 on very long grid-stride loops
+#pragma unroll
+            for (int l = 0; l < 9; ++l) my[(9 * t + l) * kBlock] = a.l[l];
         }
     }
 #pragma unroll
     for (int t = 0; t <= M; ++t) {
-        const Fr s = block_sum(fe_to_fr(acc[t]), sm);
-        if (threadIdx.x == 0) fr_store(partials + 2 * ((uint64_t)blockIdx.x * (M + 1) + t), s);
+        Fe a;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) a.l[l] = my[(9 * t + l) * kBlock];
+        const Fr s = block_sum(fe_to_fr(a), sm);
+        if (threadIdx.x == 0) fr_store(row + 2 * t, s);
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_prod_tree(const ProdArgs A, const BindConst r, const uint64_t n_pairs,
+                                                      uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    __shared__ int32_t rt[kBindLds];
+    __shared__ int32_t lacc[9 * (M + 1) * kBlock];
+    bind_consts_to_lds(r, rt);
+    tree_pass<M>(A.slot, rt, n_pairs, partials + 2 * ((uint64_t)blockIdx.x * (M + 1)), sm, lacc);
+}
+
+// every product of the round in one launch (RoundArgs in kernels.h)
+__global__ __launch_bounds__(kBlock) void k_round_tree(const RoundArgs R, const BindConst r, const uint64_t n_pairs,
+                                                       uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    __shared__ int32_t rt[kBindLds];
+    __shared__ int32_t lacc[9 * 5 * kBlock];
+    bind_consts_to_lds(r, rt);
+    const int n = R.n_prod;
+    int k = R.rotate == 1 ? (int)((blockIdx.x & 7u) % (uint32_t)n) : R.rotate == 2 ? (int)(blockIdx.x % (uint32_t)n) : 0;
+    for (int i = 0; i < n; ++i) {
+        const TreeProd &T = R.prod[k];
+        uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x * (T.M + 1));
+        switch (T.M) {
+        case 1: tree_pass<1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+        case 2: tree_pass<2>(T.slot, rt, n_pairs, row, sm, lacc); break;
+        case 3: tree_pass<3>(T.slot, rt, n_pairs, row, sm, lacc); break;
+        default: tree_pass<4>(T.slot, rt, n_pairs, row, sm, lacc); break;
+        }
+        if (++k == n) k = 0;
     }
 }
 
@@ -620,32 +708,39 @@ __global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const
 //   phase 1  S_k[t] = sum over blocks of partial_k[blk][t]                       (t <= M_k)
 //   phase 2  P_k(t) for the message points t = 0..D-1 = sum_s (c_k W_k)[t][s] S_k[s]   (host-computed Lagrange weights)
 //   phase 3  out[t] = sum_k P_k(t)
-// One block of 256 threads; everything here is O(K*D) field operations.
+// One block of 1024 threads; everything here is O(K*D) field operations and latency-bound, so the intermediate vectors
+// live in LDS when they fit (kLds; K*D*(D+2) elements) and phase 1 keeps eight partial loads in flight per lane.
 // ------------------------------------------------------------------------------------------------
 constexpr int kFinBlock = 1024; // 16 wavefronts: one per (product, point) combination for typical shapes
+constexpr size_t kFinLdsMax = 48 * 1024;
+template <bool kLds>
 __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restrict__ prods, const uint4 *__restrict__ Wm, const int K, const int D,
                                                         const int nblocks, const uint4 *__restrict__ partials, uint4 *__restrict__ scratch,
                                                         uint4 *__restrict__ out, uint64_t *__restrict__ out_wide,
                                                         uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag, const uint32_t seq,
                                                         const int scaled) {
     constexpr int kBlock = kFinBlock; // shadows the 256-thread constant inside this kernel
+    extern __shared__ uint4 fin_lds[];
+    if constexpr (kLds) scratch = fin_lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // phase 1: one wave per (product, node) combination; two independent accumulators keep two loads in flight per lane
+    // phase 1: one wave per (product, node) combination, eight independent loads in flight per lane
     for (int combo = wave; combo < K * D; combo += kBlock / 64) {
         const int k = combo / D, t = combo % D;
         const int M = (int)prods[k].M;
         if (t > M) continue;
         const uint4 *base = partials + 2 * prods[k].partial_off;
-        Fr acc = fr_zero(), acc2 = fr_zero();
-        int blk = lane;
-        for (; blk + 64 < nblocks; blk += 128) {
-            const Fr x = fr_load(base + 2 * ((uint64_t)blk * (M + 1) + t));
-            const Fr y = fr_load(base + 2 * ((uint64_t)(blk + 64) * (M + 1) + t));
-            acc = fr_add(acc, x);
-            acc2 = fr_add(acc2, y);
+        Fr acc = fr_zero();
+        for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {
+            Fr x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int blk = b0 + 64 * j;
+                x[j] = blk < nblocks ? fr_load(base + 2 * ((uint64_t)blk * (M + 1) + t)) : fr_zero();
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = fr_add(x[j], x[j + 4]);
+            acc = fr_add(acc, fr_add(fr_add(x[0], x[1]), fr_add(x[2], x[3])));
         }
-        if (blk < nblocks) acc = fr_add(acc, fr_load(base + 2 * ((uint64_t)blk * (M + 1) + t)));
-        acc = fr_add(acc, acc2);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) acc = fr_add(acc, fr_shfl_down(acc, off));
         if (lane == 0) fr_store(scratch + 2 * (k * D + t), acc);
@@ -870,13 +965,13 @@ hipError_t launch_prod_round_fe(int M, const ProdArgs &args, const FrHost &r32, 
 }
 
 template <int M>
-static hipError_t launch_prod_tree_t(const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
+static hipError_t launch_prod_tree_t(const ProdArgs &args, const BindConst &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
                                      hipStream_t stream) {
     hipLaunchKernelGGL(k_prod_tree<M>, dim3(grid), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
     return hipGetLastError();
 }
 
-hipError_t launch_prod_tree(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
+hipError_t launch_prod_tree(int M, const ProdArgs &args, const BindConst &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
                             hipStream_t stream) {
     switch (M) {
     case 1: return launch_prod_tree_t<1>(args, r32, n_pairs, d_partials, grid, stream);
@@ -885,6 +980,11 @@ hipError_t launch_prod_tree(int M, const ProdArgs &args, const FrHost &r32, uint
     case 4: return launch_prod_tree_t<4>(args, r32, n_pairs, d_partials, grid, stream);
     default: return hipErrorInvalidValue; // 5..8 multiplicands run node by node in k_prod_round_fe
     }
+}
+
+hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_round_tree, dim3(grid), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
+    return hipGetLastError();
 }
 
 template <int M>
@@ -951,8 +1051,15 @@ hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t 
 hipError_t launch_finalize(const FinProd *d_prods, const FrHost *d_W, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
                            FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
                            int scaled, hipStream_t stream) {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinBlock), 0, stream, d_prods, (const uint4 *)d_W, K, D, nblocks, (const uint4 *)d_partials,
-                       (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq, scaled);
+    const size_t lds = (size_t)K * D * (D + 2) * 32;
+    if (lds <= kFinLdsMax)
+        hipLaunchKernelGGL(k_finalize<true>, dim3(1), dim3(kFinBlock), lds, stream, d_prods, (const uint4 *)d_W, K, D, nblocks,
+                           (const uint4 *)d_partials, (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq,
+                           scaled);
+    else
+        hipLaunchKernelGGL(k_finalize<false>, dim3(1), dim3(kFinBlock), 0, stream, d_prods, (const uint4 *)d_W, K, D, nblocks,
+                           (const uint4 *)d_partials, (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq,
+                           scaled);
     return hipGetLastError();
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copy the rocprofv3 summaries of gpurun_out/prof_<tag>/ into profiles/ and derive the HBM traffic per launch of the
-dominant kernel.  Usage: python tools/collect_profiles.py <tag> [kernel substring, default k_prod_tree<4>]"""
+dominant kernel.  Usage: python tools/collect_profiles.py <tag> [kernel substring, default k_round_tree]"""
 import collections
 import csv
 import json
@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-kern = sys.argv[2] if len(sys.argv) > 2 else "k_prod_tree<4>"
+kern = sys.argv[2] if len(sys.argv) > 2 else "k_round_tree"
 base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 out = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(base, "stats", "bench_kernel_stats.csv"), os.path.join(out, f"{tag}_rocprofv3_kernel_stats.csv"))
@@ -25,11 +25,10 @@ for name, f in (("FETCH_SIZE", "pmc_fetch/bench_counter_collection.csv"), ("WRIT
     counters[name] = {k: {"calls": n, "sum_KB": v, "per_call_KB": v / n} for k, (n, v) in agg.items()}
 key = next(k for k in counters["FETCH_SIZE"] if kern in k)
 f, w = counters["FETCH_SIZE"][key], counters["WRITE_SIZE"][key]
-n_tables = int(kern.split("<")[1].split(">")[0])
 summary = {
     "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --output-format csv) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
     "corrections": "FETCH_SIZE x2 (MI355X_MICROARCH.md: gfx950 counts 64 B per 128-B request for 16 B/lane coalesced reads; checked on the "
-                   "round-1 launch: 4 x 2^24 x 32 B = 2097152 KB read, counter 1048848 KB); WRITE_SIZE x1 (calibrated on k_synth: 10 x 2^24 x 32 B "
+                   "round-1 launch of k_prod_tree<4>: 4 x 2^24 x 32 B = 2097152 KB read, counter 1048848 KB); WRITE_SIZE x1 (calibrated on k_synth: 10 x 2^24 x 32 B "
                    "written, counter 5242880 KB)",
     "kernel": key,
     "launches": f["calls"],

@@ -21,6 +21,7 @@ poly = sc.ListOfProductsOfPolynomials(nv)
 for k, sh in enumerate(shapes):
     poly.add_product([mles[i] for i in sh], coefs[k])
 st = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+st.set_timing(True)
 rng = sc.Blake2b512Rng.setup()
 for rep in range(3):
     st.reset()
