@@ -98,7 +98,8 @@ struct Combo {
 
 int grid_for_pairs(uint64_t n_pairs);
 
-// product k of one round: partials[blk*(M+1)+t] = sum over this block's pairs of prod_j line_j(t), t = 0..M
+// product k of one round: partials[t*grid+blk] = sum over this block's pairs of prod_j line_j(t), t = 0..M (node-major, so the
+// finalize kernel reads each node's partials as one contiguous run)
 hipError_t launch_prod_round(int M, const ProdArgs &args, const FrHost &r, uint64_t n_pairs, FrHost *d_partials, int grid,
                              hipStream_t stream);
 // the same in carry-free 29-bit-limb arithmetic; r32 = challenge * 2^5, partials carry 2^(-5(M-1))

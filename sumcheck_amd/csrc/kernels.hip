@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const F
 #pragma unroll
     for (int t = 0; t <= M; ++t) {
         const Fr s = block_sum(acc[t], sm);
-        if (threadIdx.x == 0) fr_store(partials + 2 * ((uint64_t)blockIdx.x * (M + 1) + t), s);
+        if (threadIdx.x == 0) fr_store(partials + 2 * ((uint64_t)t * gridDim.x + blockIdx.x), s);
     }
 }
 
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
 #pragma unroll
     for (int t = 0; t <= M; ++t) {
         const Fr s = block_sum(fe_to_fr(acc[t]), sm);
-        if (threadIdx.x == 0) fr_store(partials + 2 * ((uint64_t)blockIdx.x * (M + 1) + t), s);
+        if (threadIdx.x == 0) fr_store(partials + 2 * ((uint64_t)t * gridDim.x + blockIdx.x), s);
     }
 }
 
@@ -446,7 +446,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
 #pragma unroll
         for (int l = 0; l < 9; ++l) a.l[l] = my[(9 * t + l) * kBlock];
         const Fr s = block_sum(fe_to_fr(a), sm);
-        if (threadIdx.x == 0) fr_store(row + 2 * t, s);
+        if (threadIdx.x == 0) fr_store(row + 2 * ((uint64_t)t * gridDim.x), s);
     }
 }
 
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void k_prod_tree(const ProdArgs A, const Bi
     __shared__ int32_t rt[kBindLds];
     __shared__ int32_t lacc[9 * (M + 1) * kBlock];
     bind_consts_to_lds(r, rt);
-    tree_pass<M>(A.slot, rt, n_pairs, partials + 2 * ((uint64_t)blockIdx.x * (M + 1)), sm, lacc);
+    tree_pass<M>(A.slot, rt, n_pairs, partials + 2 * (uint64_t)blockIdx.x, sm, lacc);
 }
 
 // every product of the round in one launch (RoundArgs in kernels.h)
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void k_round_tree(const RoundArgs R, const 
     int k = R.rotate == 1 ? (int)((blockIdx.x & 7u) % (uint32_t)n) : R.rotate == 2 ? (int)(blockIdx.x % (uint32_t)n) : 0;
     for (int i = 0; i < n; ++i) {
         const TreeProd &T = R.prod[k];
-        uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x * (T.M + 1));
+        uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x);
         switch (T.M) {
         case 1: tree_pass<1>(T.slot, rt, n_pairs, row, sm, lacc); break;
         case 2: tree_pass<2>(T.slot, rt, n_pairs, row, sm, lacc); break;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64 * (M + 1)) void k_round_tile(const ProdArgs A, c
     Fr sum = fe_to_fr(acc);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum = fr_add(sum, fr_shfl_down(sum, off));
-    if (lane == 0) fr_store(partials + 2 * ((uint64_t)blockIdx.x * (M + 1) + node_idx), sum);
+    if (lane == 0) fr_store(partials + 2 * ((uint64_t)node_idx * gridDim.x + blockIdx.x), sum);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void k_sum_generic(const uint4 *const *__re
         acc = fr_add(acc, prod);
     }
     const Fr s = block_sum(acc, sm);
-    if (threadIdx.x == 0) fr_store(partials + 2 * ((uint64_t)blockIdx.x * (M + 1) + t), s);
+    if (threadIdx.x == 0) fr_store(partials + 2 * ((uint64_t)t * gridDim.x + blockIdx.x), s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const
         acc = fr_add(acc, prod);
     }
     const Fr s = block_sum(acc, sm);
-    if (threadIdx.x == 0) fr_store(partials + 2 * (c.partial_off + (uint64_t)blockIdx.x * (c.M + 1) + t), s);
+    if (threadIdx.x == 0) fr_store(partials + 2 * (c.partial_off + (uint64_t)t * gridDim.x + blockIdx.x), s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -734,8 +734,11 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
             Fr x[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                // clamped address + select: the eight loads are issued back to back (a predicated load would wait for its own data)
                 const int blk = b0 + 64 * j;
-                x[j] = blk < nblocks ? fr_load(base + 2 * ((uint64_t)blk * (M + 1) + t)) : fr_zero();
+                const Fr v = fr_load(base + 2 * ((uint64_t)t * nblocks + min(blk, nblocks - 1)));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[j].v[i] = blk < nblocks ? v.v[i] : 0u;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[j] = fr_add(x[j], x[j + 4]);
