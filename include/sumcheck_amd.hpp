@@ -314,22 +314,13 @@ struct MLSumcheck {
     }
 };
 
-// ListOfProductsOfPolynomials::evaluate (data_structures.rs:99-109); the products of the K*m scalars run through the library's
-// elementwise field kernel so that no second host-side field implementation is needed here
+// ListOfProductsOfPolynomials::evaluate (data_structures.rs:99-109): one library call, all tables folded on the GPU
 inline Fr evaluate(const ListOfProductsOfPolynomials &poly, const std::vector<Fr> &point) {
-    std::vector<Fr> vals;
-    for (const auto &t : poly.flattened_ml_extensions) vals.push_back(t->evaluate(point));
-    Fr acc = Fr::zero();
-    for (const auto &pr : poly.products) {
-        Fr term = pr.first;
-        for (size_t i : pr.second) {
-            Fr out;
-            check(sc_fr_elementwise(0, term.l, vals[i].l, out.l, 1));
-            term = out;
-        }
-        acc = acc + term;
-    }
-    return acc;
+    if (point.size() != poly.num_variables) throw Panic(SC_ERR_BAD_ARG, "wrong number of variables");
+    auto D = poly.desc();
+    Fr out;
+    check(sc_poly_evaluate(&D->d, point.empty() ? nullptr : point[0].l, out.l, nullptr));
+    return out;
 }
 
 struct SparseMultilinearExtension {

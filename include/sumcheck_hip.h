@@ -164,6 +164,13 @@ SC_API int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_vals, u
 SC_API int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim,
                  const uint64_t *f2, const uint64_t *f3, const uint64_t *g, uint64_t *out_proof, uint64_t *out_uv_or_null);
 
+/* ListOfProductsOfPolynomials::evaluate (src/ml_sumcheck/data_structures.rs:99-109): sum_k c_k prod_j T_j(point),
+ * the oracle query every reference test ends with (test.rs:71-74) and GKR's f2.evaluate(u) (gkr_round_sumcheck/
+ * mod.rs:122).  point: num_vars x 4 limbs, point[0] binds index bit 0.  The U table evaluations run on the device
+ * (tables host or device per desc->flags, never modified); out_table_values_or_null receives them (U x 4).
+ * num_vars == 0 is allowed here (a table is its single entry). */
+SC_API int sc_poly_evaluate(const sc_poly_desc *desc, const uint64_t *point, uint64_t *out_value, uint64_t *out_table_values_or_null);
+
 /* ---- synthetic inputs + instrumentation (bench / tests) ------------------------------------- */
 /* SplitMix64-keyed uniform field elements, generated on the device: n elements of
  * stream `stream` starting at element `first`, written to device memory d_out (n x 4 limbs). */

@@ -494,7 +494,11 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     for (int d = 0; d < 5; ++d) r32v = sch::add(r32v, r32v);
     const FrHost r32 = to_dev(r32v);
     int scaled = 0;
-    const bool small_round = n_pairs <= scd::kSmallRoundPairs && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0;
+    static const uint64_t small_pairs = [] { // SC_SMALL_LOG2: experiment knob for the big/small round boundary
+        const char *e = std::getenv("SC_SMALL_LOG2");
+        return e ? (1ULL << std::atoi(e)) : scd::kSmallRoundPairs;
+    }();
+    const bool small_round = n_pairs <= small_pairs && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0;
     const bool tiled = !small_round && !p->any_generic && p->kernel_variant == 2;
     scd::BindConst rc; // (only the big rounds of the tree kernels pay for it)
     std::memset(&rc, 0, sizeof(rc)); // tree kernels: rows (r * 2^(29 i + 58)) mod p as plain 29-bit limbs (fe.cuh, fe_mul_bind)
@@ -983,6 +987,120 @@ extern "C" int sc_fix_variables(const uint64_t *in, uint32_t nv, const uint64_t 
     FV_TRY(hipStreamSynchronize(s));
     cleanup();
 #undef FV_TRY
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ListOfProductsOfPolynomials::evaluate (data_structures.rs:99-109): sum_k c_k prod_j T_j(point).
+// The U table evaluations run on the device, three variables per pass (kernels.h: FoldArgs); the K + sum m_k
+// scalar products that combine them are host work.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct DevMem { // frees on scope exit
+    void *p = nullptr;
+    ~DevMem() {
+        if (p) (void)hipFree(p);
+    }
+};
+struct StreamGuard {
+    hipStream_t s = nullptr;
+    ~StreamGuard() {
+        if (s) (void)hipStreamDestroy(s);
+    }
+};
+} // namespace
+
+extern "C" int sc_poly_evaluate(const sc_poly_desc *d, const uint64_t *point, uint64_t *out_value, uint64_t *out_table_values_or_null) {
+    if (!d || !out_value || (d->num_vars && !point)) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (d->num_vars > 40) return fail(SC_ERR_BAD_ARG, "num_vars %u too large", d->num_vars);
+    if (d->n_tables == 0 || !d->tables) return fail(SC_ERR_BAD_ARG, "no tables");
+    if (d->n_products && (!d->coeffs || !d->prod_offsets || !d->prod_indices)) return fail(SC_ERR_BAD_ARG, "null product arrays");
+    for (uint32_t k = 0; k < d->n_products; ++k) {
+        if (d->prod_offsets[k + 1] <= d->prod_offsets[k]) return fail(SC_ERR_BAD_ARG, "product %u is empty", k);
+        for (uint32_t q = d->prod_offsets[k]; q < d->prod_offsets[k + 1]; ++q)
+            if (d->prod_indices[q] >= d->n_tables) return fail(SC_ERR_BAD_ARG, "product %u refers to table %u >= %u", k, d->prod_indices[q], d->n_tables);
+    }
+    for (uint32_t u = 0; u < d->n_tables; ++u)
+        if (!d->tables[u]) return fail(SC_ERR_BAD_ARG, "table %u is null", u);
+    const uint32_t nv = d->num_vars, U = d->n_tables;
+    std::vector<sch::Fr> pt(nv);
+    for (uint32_t i = 0; i < nv; ++i) {
+        std::memcpy(&pt[i], point + 4 * i, 32);
+        if (sch::geq_p(pt[i])) return fail(SC_ERR_BAD_ARG, "point[%u] is not a canonical field element", i);
+    }
+    if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    HIP_TRY(hipSetDevice(g_device));
+    StreamGuard sg;
+    HIP_TRY(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+    const bool on_device = d->flags & SC_TABLES_ON_DEVICE;
+    const uint64_t n = 1ULL << nv;
+    // passes: three variables at a time from the LSB end, the remainder (1 or 2) last, on a table that is tiny by then
+    std::vector<int> levels;
+    for (uint32_t left = nv; left > 0;) {
+        const int l = left >= 3 ? 3 : (int)left;
+        levels.push_back(l);
+        left -= l;
+    }
+    // device memory: staging for host tables, two ping-pong work areas (sizes after pass 1 and pass 2), the U results
+    DevMem stage, wa, wb, vals;
+    if (!on_device) HIP_TRY(hipMalloc(&stage.p, (size_t)U * n * 32));
+    const uint64_t na = levels.empty() ? 1 : n >> levels[0];
+    const uint64_t nb = levels.size() < 2 ? 1 : na >> levels[1];
+    HIP_TRY(hipMalloc(&wa.p, (size_t)U * na * 32));
+    HIP_TRY(hipMalloc(&wb.p, (size_t)U * nb * 32));
+    HIP_TRY(hipMalloc(&vals.p, (size_t)U * 32));
+    std::vector<const uint4 *> cur(U);
+    for (uint32_t u = 0; u < U; ++u) {
+        if (on_device) {
+            cur[u] = reinterpret_cast<const uint4 *>(d->tables[u]);
+        } else {
+            uint4 *dst = static_cast<uint4 *>(stage.p) + 2 * n * u;
+            HIP_TRY(hipMemcpyAsync(dst, d->tables[u], n * 32, hipMemcpyHostToDevice, sg.s));
+            cur[u] = dst;
+        }
+    }
+    uint64_t m = n;
+    uint32_t var = 0;
+    for (size_t ps = 0; ps < levels.size(); ++ps) {
+        const int L = levels[ps];
+        m >>= L;
+        const bool last = ps + 1 == levels.size();
+        uint4 *area = static_cast<uint4 *>((ps & 1) ? wb.p : wa.p);
+        for (uint32_t u0 = 0; u0 < U; u0 += (uint32_t)scd::kMaxSmallTables) {
+            const uint32_t cnt = std::min<uint32_t>(U - u0, (uint32_t)scd::kMaxSmallTables);
+            scd::FoldArgs fa;
+            std::memset(&fa, 0, sizeof(fa));
+            for (uint32_t j = 0; j < cnt; ++j) {
+                fa.src[j] = cur[u0 + j];
+                fa.dst[j] = last ? static_cast<uint4 *>(vals.p) + 2 * (u0 + j) : area + 2 * m * (u0 + j);
+            }
+            for (int l = 0; l < L; ++l) {
+                sch::Fr r32v = pt[var + l]; // r * 2^5 for the 2^261-radix arithmetic
+                for (int dbl = 0; dbl < 5; ++dbl) r32v = sch::add(r32v, r32v);
+                fa.r32[l] = to_dev(r32v);
+            }
+            HIP_TRY(scd::launch_fold_multi(fa, L, (int)cnt, m, sg.s));
+            for (uint32_t j = 0; j < cnt; ++j) cur[u0 + j] = fa.dst[j];
+        }
+        var += L;
+    }
+    std::vector<sch::Fr> tv(U);
+    if (levels.empty()) { // zero variables: a table is its single entry
+        for (uint32_t u = 0; u < U; ++u) HIP_TRY(hipMemcpyAsync(&tv[u], cur[u], 32, hipMemcpyDeviceToHost, sg.s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(tv.data(), vals.p, (size_t)U * 32, hipMemcpyDeviceToHost, sg.s));
+    }
+    HIP_TRY(hipStreamSynchronize(sg.s));
+    sch::Fr acc = sch::zero();
+    for (uint32_t k = 0; k < d->n_products; ++k) {
+        sch::Fr pr;
+        std::memcpy(&pr, d->coeffs + 4 * k, 32);
+        if (sch::geq_p(pr)) return fail(SC_ERR_BAD_ARG, "coefficient %u is not a canonical field element", k);
+        for (uint32_t q = d->prod_offsets[k]; q < d->prod_offsets[k + 1]; ++q) pr = sch::mul(pr, tv[d->prod_indices[q]]);
+        acc = sch::add(acc, pr);
+    }
+    std::memcpy(out_value, &acc, 32);
+    if (out_table_values_or_null) std::memcpy(out_table_values_or_null, tv.data(), (size_t)U * 32);
     return SC_OK;
 }
 

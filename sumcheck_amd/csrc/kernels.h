@@ -96,6 +96,17 @@ struct Combo {
     uint64_t partial_off;
 };
 
+// Evaluation at a point (ListOfProductsOfPolynomials::evaluate): every challenge is known up front, so one pass folds up to
+// three variables at once -- 8 entries in, 1 out -- and a table moves (1 + 1/8 + ...) x its size instead of 3 x.
+constexpr int kFoldMaxLevels = 3;
+struct FoldArgs {
+    const uint4 *src[kMaxSmallTables];
+    uint4 *dst[kMaxSmallTables];
+    FrHost r32[kFoldMaxLevels]; // challenges of this pass's variables (LSB first), each times 2^5 (fe.cuh radix)
+};
+// dst[y][i] = fold over `levels` variables of src[y][i << levels ...], i < n_out, y < n_tables (grid.y)
+hipError_t launch_fold_multi(const FoldArgs &args, int levels, int n_tables, uint64_t n_out, hipStream_t stream);
+
 int grid_for_pairs(uint64_t n_pairs);
 
 // product k of one round: partials[t*grid+blk] = sum over this block's pairs of prod_j line_j(t), t = 0..M (node-major, so the

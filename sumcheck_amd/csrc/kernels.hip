@@ -628,6 +628,42 @@ __global__ __launch_bounds__(kBlock) void k_fix(const uint4 *__restrict__ src, u
     }
 }
 
+// Evaluate-at-a-point pass (kernels.h, FoldArgs): lane i folds entries [i << L, (i + 1) << L) of table blockIdx.y over L variables,
+// LSB first (ark-poly's fix_variables order), in carry-free arithmetic; one canonical element out.
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_fold_multi(const FoldArgs A, const uint64_t n_out) {
+    const uint4 *__restrict__ src = A.src[blockIdx.y];
+    uint4 *__restrict__ dst = A.dst[blockIdx.y];
+    FeU r[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) r[l] = feu_from_host(A.r32[l]);
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_out; i += stride) {
+        Fe v[1 << L];
+        const uint4 *p = src + 2 * (i << L);
+#pragma unroll
+        for (int j = 0; j < (1 << L); ++j) v[j] = fe_from_fr(fr_load(p + 2 * j));
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+#pragma unroll
+            for (int j = 0; j < (1 << (L - 1 - l)); ++j)
+                v[j] = fe_carry_pass(fe_add(v[2 * j], fe_mul_u(fe_sub(v[2 * j + 1], v[2 * j]), r[l])));
+        }
+        fr_store(dst + 2 * i, fe_to_fr(v[0]));
+    }
+}
+
+hipError_t launch_fold_multi(const FoldArgs &args, int levels, int n_tables, uint64_t n_out, hipStream_t stream) {
+    const dim3 grid(grid_for_pairs(n_out), n_tables);
+    switch (levels) {
+    case 1: hipLaunchKernelGGL(k_fold_multi<1>, grid, dim3(kBlock), 0, stream, args, n_out); break;
+    case 2: hipLaunchKernelGGL(k_fold_multi<2>, grid, dim3(kBlock), 0, stream, args, n_out); break;
+    case 3: hipLaunchKernelGGL(k_fold_multi<3>, grid, dim3(kBlock), 0, stream, args, n_out); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // out[i] = s * in[i]   (start_phase2_sumcheck's f3 * f2(u), reference src/gkr_round_sumcheck/mod.rs:71-75)
 __global__ __launch_bounds__(kBlock) void k_scale(const uint4 *__restrict__ src, uint4 *__restrict__ dst, const FrHost s_h,
                                                   const uint64_t n) {

@@ -124,15 +124,20 @@ class ListOfProductsOfPolynomials:
         return PolynomialInfo(self.max_multiplicands, self.num_variables)
 
     def evaluate(self, point) -> np.ndarray:
-        """data_structures.rs:99-109 (table evaluations run on the GPU, the K+sum(m_k) scalar products on the host)"""
-        vals = [field.to_int(t.evaluate(point)) for t in self.flattened_ml_extensions]
-        acc = 0
-        for c, idxs in self.products:
-            pr = field.to_int(c)
-            for i in idxs:
-                pr = pr * vals[i] % field.P
-            acc = (acc + pr) % field.P
-        return field.from_int(acc)
+        """data_structures.rs:99-109: sum_k c_k prod_j T_j(point) -- one library call (sc_poly_evaluate: all tables folded on
+        the GPU three variables per pass, the K + sum m_k scalar products on the library's host side)."""
+        return self.evaluate_with_tables(point)[0]
+
+    def evaluate_with_tables(self, point):
+        """-> (value (4,), per-table evaluations (U, 4))"""
+        pt = np.ascontiguousarray(_np64(point).reshape(-1, 4))
+        assert pt.shape[0] == self.num_variables
+        d, keep = self._desc()
+        out = np.zeros(4, dtype=np.uint64)
+        tv = np.zeros((max(len(self.flattened_ml_extensions), 1), 4), dtype=np.uint64)
+        check(lib().sc_poly_evaluate(C.byref(d), _ptr(pt) if pt.size else None, _ptr(out), _ptr(tv)))
+        del keep
+        return out, tv[: len(self.flattened_ml_extensions)]
 
     # ---- marshalling -----------------------------------------------------------------------------
     def _desc(self, borrow: bool = False):

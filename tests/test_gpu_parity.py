@@ -218,7 +218,7 @@ def test_full_size_properties(nv, shapes, nt):
     """At full size the oracle is too slow; use the size-independent relations the reference's own tests assert:
     verifier acceptance of every round (P_i(0)+P_i(1) == P_{i-1}(r_{i-1})) and the final oracle query
     poly.evaluate(point) == expected_evaluation (test.rs:71-74), the latter computed by the independent
-    stand-alone bind kernel; plus round 1 against the oracle on a 2^16-point slice via linearity of the sum."""
+    evaluate-at-a-point kernel (sc_poly_evaluate); plus round 1 against the oracle on a 2^16-point slice via linearity of the sum."""
     poly, mles, coefs = _device_poly(nv, shapes, nt, 0x5C20241008)
     proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly, borrow=True)
     s = sc.MLSumcheck.extract_sum(proof)
@@ -372,3 +372,38 @@ def test_sharded_rounds_inside_the_library_world1():
         got, rand = sharded.prove_sharded_native(engine, ncomm, sharded.DistComm(), nv, 4, None)
         assert np.array_equal(got, want) and np.array_equal(rand, wrand)
     ncomm.close()
+
+
+@pytest.mark.parametrize("nv,nt,shapes,device", [
+    (1, 2, [[0, 1]], False),
+    (2, 3, [[0, 1, 2], [1]], True),
+    (3, 2, [[0], [1, 1]], False),
+    (4, 3, [[0, 1], [2, 2, 0]], True),
+    (5, 3, [[2, 1, 0]], False),
+    (7, 4, [[0, 1, 2, 3], [3]], True),
+    (12, 3, [[0, 1], [2]], False),
+    (13, 40, [[39, 0, 17], [33, 34], [5]], True),   # more tables than one launch takes
+    (17, 3, [[0, 1, 2]], True),
+])
+def test_poly_evaluate_matches_oracle(nv, nt, shapes, device):
+    """ListOfProductsOfPolynomials::evaluate (data_structures.rs:99-109) through sc_poly_evaluate: the value and every table's
+    evaluation against the oracle's one-variable-at-a-time fix_variables chain (the GPU folds three variables per pass)."""
+    tabs = [cref.synth_table(777 + nv, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(777 + nv, 1000, len(shapes))
+    point = cref.synth_table(778 + nv, 2000, nv)
+    poly, mles = H.hip_poly_from(nv, shapes, tabs, coefs, device="cuda:0" if device else None)
+    got, tv = poly.evaluate_with_tables(point)
+    d = H.desc_from(nv, shapes, tabs, coefs)
+    assert np.array_equal(got, cref.poly_evaluate(d, point))
+    for j, m in enumerate(poly.flattened_ml_extensions):  # pool order = order of first use (data_structures.rs:85-93)
+        u = next(i for i, x in enumerate(mles) if x is m)
+        assert np.array_equal(tv[j], cref.fix_variables(tabs[u], point).reshape(4))
+
+
+def test_poly_evaluate_rejects_bad_input():
+    tabs = [cref.synth_table(5, s, 8) for s in range(2)]
+    coefs = cref.synth_table(5, 1000, 1)
+    poly, _ = H.hip_poly_from(3, [[0, 1]], tabs, coefs)
+    bad = np.tile(np.array([[0xFFFFFFFFFFFFFFFF] * 4], dtype=np.uint64), (3, 1))  # >= p
+    with pytest.raises(sc.SumcheckError):
+        poly.evaluate(bad)

@@ -19,7 +19,7 @@ SEED = 0x5C20241008
 dev = torch.device("cuda:0")
 
 
-def ml(nv, shapes, nt, reps=10):
+def ml(nv, shapes, nt, reps=10, cpu=True):
     tabs = []
     for u in range(nt):
         t = torch.empty((1 << nv, 4), dtype=torch.int64, device=dev)
@@ -38,6 +38,11 @@ def ml(nv, shapes, nt, reps=10):
     for _ in range(reps):
         st.reset()
         t0 = time.perf_counter(); st.prove(); ts.append(time.perf_counter() - t0)
+    if not cpu:  # too large for a host copy: GPU time only, field-ops from SURVEY 8d's formula
+        U, D = nt, max(len(s) for s in shapes) + 1
+        ops = ((1 << nv) - 1) * sum(2 * len(s) * D + len(s) + D for s in shapes) + 3 * U * ((1 << nv) - 2)
+        return {"nv": nv, "shapes": shapes, "gpu_ms_median": 1e3 * float(np.median(ts)), "gpu_ms_min": 1e3 * min(ts), "field_ops": ops,
+                "gpu_field_ops_per_s": ops / float(np.median(ts)), "algorithmic_GBps": 32 * U * (4 * (1 << nv) - 6) / float(np.median(ts)) / 1e9}
     host = [t.cpu().numpy().view(np.uint64) for t in tabs]
     d = cref.PolyDesc(nv, [(coefs[k], sh) for k, sh in enumerate(shapes)], host)
     t0 = time.perf_counter(); cref.ml_prove(d, threads=cref.max_threads()); tc = time.perf_counter() - t0
@@ -64,4 +69,7 @@ def gkr(dim, reps=5):
 
 
 out = {"config2": ml(20, [[0, 1, 2]], 3), "readme_bench_shape": ml(20, [[0, 1, 2], [3, 4, 5]], 6), "config5_gkr": gkr(20)}
+if "--config4" in sys.argv:  # the whole nv=28 job of config 4 on ONE GPU (24 GiB of tables + 13.5 GiB of bound-table buffers in HBM)
+    out["config4_nv28_one_gpu"] = ml(28, [[0, 1, 2]], 3, reps=3, cpu=False)
+    out["config4_shard_nv25_one_gpu"] = ml(25, [[0, 1, 2]], 3, reps=5, cpu=False)
 print(json.dumps(out, indent=1))
