@@ -48,6 +48,7 @@ extern "C" {
     pub fn sc_prover_state(p: *mut sc_prover, randomness: *mut u64, n_randomness: *mut u32, tables_out: *mut u64, round: *mut u32) -> c_int;
     pub fn sc_prover_free(p: *mut sc_prover);
     pub fn sc_fix_variables(input: *const u64, nv: u32, point: *const u64, k: u32, out: *mut u64, flags: u32) -> c_int;
+    pub fn sc_poly_evaluate(desc: *const sc_poly_desc, point: *const u64, out_value: *mut u64, out_table_values_or_null: *mut u64) -> c_int;
     pub fn sc_ml_prove(desc: *const sc_poly_desc, rng_or_null: *mut sc_rng, out_proof: *mut u64, out_state_or_null: *mut *mut sc_prover) -> c_int;
     pub fn sc_gkr_prove(rng: *mut sc_rng, f1_idx: *const u64, f1_vals: *const u64, nnz: u64, dim: u32, f2: *const u64, f3: *const u64,
                         g: *const u64, out_proof: *mut u64, out_uv_or_null: *mut u64) -> c_int;
@@ -184,6 +185,21 @@ pub fn ml_prove<F: Limbs4>(polynomial: &ListOfProductsOfPolynomials<F>) -> Vec<V
         panic_like_reference(rc)
     }
     proof.chunks(d).take(polynomial.num_variables).map(|m| m.iter().map(|l| F::from_limbs(*l)).collect()).collect()
+}
+
+/// `ListOfProductsOfPolynomials::evaluate` (reference `src/ml_sumcheck/data_structures.rs:99-109`): the oracle query that
+/// follows a proof, with every table folded on the GPU (`sc_poly_evaluate`).
+pub fn evaluate<F: Limbs4>(polynomial: &ListOfProductsOfPolynomials<F>, point: &[F]) -> F {
+    assert_eq!(point.len(), polynomial.num_variables, "wrong number of variables");
+    let flat = flatten(polynomial);
+    let desc = flat.desc(polynomial.num_variables, polynomial.max_multiplicands);
+    let pt: Vec<[u64; 4]> = point.iter().map(|x| unsafe { *(x.limbs() as *const [u64; 4]) }).collect();
+    let mut out = [0u64; 4];
+    let rc = unsafe { sc_poly_evaluate(&desc, pt.as_ptr() as *const u64, out.as_mut_ptr(), core::ptr::null_mut()) };
+    if rc != SC_OK {
+        panic_like_reference(rc)
+    }
+    F::from_limbs(out)
 }
 
 #[allow(dead_code)]
