@@ -17,11 +17,14 @@
 //   block -> k_finalize.
 //
 // Kernels, by role:
-//   k_prod_tree<M>     production big-round kernel (M <= 4): fe.cuh carry-free arithmetic, evaluation
-//                      nodes 0,1,inf,-1,2,.. , static product tree, F29 internal table format.
-//   k_prod_round<M>    saturated 8 x u32 Comba arithmetic, consecutive-integer nodes (SC_KERNEL=0/1;
-//                      also the path for M in 5..8).
-//   k_prod_round_fe<M> fe.cuh arithmetic without the tree (SC_KERNEL=2) -- kept as a parity cross-check.
+//   k_round_tree       production big-round kernel: ONE launch per round over all products (each <= 4 multiplicands):
+//                      fe.cuh carry-free arithmetic, constant-multiplier bind, evaluation nodes 0,1,inf,-1,2, static
+//                      product tree, running sums in LDS, F29 internal table format.
+//   k_prod_tree<M>     the same pass for one product per launch (SC_MERGE=0, or more than kMaxRoundProds products).
+//   k_prod_round_fe<M> fe.cuh arithmetic node by node (5..8 multiplicands; SC_KERNEL=0 SC_FE=1 as a cross-check).
+//   k_prod_round<M>    saturated 8 x u32 Comba arithmetic (SC_KERNEL=0 SC_FE=0) -- kept as a parity cross-check.
+//   k_round_tile<M>    LDS-tiled variant (SC_KERNEL=2), a measured negative result.
+//   k_fold_multi<L>    evaluation at a point: all tables, L <= 3 variables per pass (sc_poly_evaluate).
 //   k_sum_generic/k_fix  any M, any aliasing pattern; used beyond kMaxFusedM and for > 32 tables.
 //   k_fix_multi + k_sum_combos   latency-oriented pair for rounds with <= 2^16 pairs.
 //   k_finalize         partial sums -> round message (Lagrange matrix, c_k, sum over products).
@@ -239,67 +242,12 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
 //   M = 2:  3 products  (nodes 0, 1, inf)
 //   M = 3:  q = f0 f1 at {0, 1, inf} (3), extended to -1 by additions, times f2 at {0, 1, inf, -1} (4)      =  7 (not 8)
 //   M = 4:  qa = f0 f1, qb = f2 f3 at {0, 1, inf} (6), both extended to {-1, 2}, qa qb at the five nodes (5) = 11 (not 15)
-//   M >= 5: node by node, M-1 products each.
+//   (M >= 5 runs node by node in k_prod_round_fe, M-1 products each.)
 // A quadratic q with q0 = q(0), q1 = q(1), qi = leading coefficient has q(-1) = 2 qi - q1 + 2 q0 and
 // q(2) = 2 qi + 2 q1 - q0: three lazy limb-wise additions and one carry pass in the 29-bit representation.
 // Slot modes: 0 read this round's table; 1 bind the previous table, store, use; 3 bind without storing (a repeated
-// factor whose table the same lane has already stored).
+// factor, or a table that an earlier product of the same launch stores).
 // ------------------------------------------------------------------------------------------------
-template <int M>
-__device__ __forceinline__ void tree_nodes(const Fe (&lo)[M], const Fe (&hi)[M], Fe (&P)[M + 1]) {
-    if constexpr (M == 1) {
-        P[0] = lo[0];
-        P[1] = hi[0];
-    } else if constexpr (M == 2) {
-        P[0] = fe_mul(lo[0], lo[1]);
-        P[1] = fe_mul(hi[0], hi[1]);
-        P[2] = fe_mul(fe_sub(hi[0], lo[0]), fe_sub(hi[1], lo[1]));
-    } else if constexpr (M == 3) {
-        const Fe q0 = fe_mul(lo[0], lo[1]), q1 = fe_mul(hi[0], hi[1]), qi = fe_mul(fe_sub(hi[0], lo[0]), fe_sub(hi[1], lo[1]));
-        const Fe qm1 = fe_carry_pass(fe_sub(fe_add(fe_add(qi, qi), fe_add(q0, q0)), q1));
-        P[0] = fe_mul(lo[2], q0);
-        P[1] = fe_mul(hi[2], q1);
-        P[2] = fe_mul(fe_sub(hi[2], lo[2]), qi);
-        P[3] = fe_mul(fe_sub(fe_add(lo[2], lo[2]), hi[2]), qm1); // f2(-1) = 2 lo - hi
-    } else if constexpr (M == 4) {
-        const Fe a0 = fe_mul(lo[0], lo[1]), a1 = fe_mul(hi[0], hi[1]), ai = fe_mul(fe_sub(hi[0], lo[0]), fe_sub(hi[1], lo[1]));
-        const Fe b0 = fe_mul(lo[2], lo[3]), b1 = fe_mul(hi[2], hi[3]), bi = fe_mul(fe_sub(hi[2], lo[2]), fe_sub(hi[3], lo[3]));
-        const Fe a2i = fe_add(ai, ai), b2i = fe_add(bi, bi);
-        const Fe am1 = fe_carry_pass(fe_sub(fe_add(a2i, fe_add(a0, a0)), a1)), bm1 = fe_carry_pass(fe_sub(fe_add(b2i, fe_add(b0, b0)), b1));
-        const Fe a2 = fe_carry_pass(fe_sub(fe_add(a2i, fe_add(a1, a1)), a0)), b2 = fe_carry_pass(fe_sub(fe_add(b2i, fe_add(b1, b1)), b0));
-        P[0] = fe_mul(a0, b0);
-        P[1] = fe_mul(a1, b1);
-        P[2] = fe_mul(ai, bi);
-        P[3] = fe_mul(am1, bm1);
-        P[4] = fe_mul(a2, b2);
-    } else {
-#pragma unroll
-        for (int t = 0; t <= M; ++t) {
-            const int32_t nv = node_value(t);
-#pragma unroll
-            for (int f = 0; f < M; ++f) {
-                Fe val;
-                if (nv == 0) val = lo[f];
-                else if (nv == 1) val = hi[f];
-                else if (nv == kNodeInf) val = fe_sub(hi[f], lo[f]);
-                else if (nv == -1) val = fe_sub(fe_add(lo[f], lo[f]), hi[f]);
-                else if (nv == 2) val = fe_sub(fe_add(hi[f], hi[f]), lo[f]);
-                else {
-                    const Fe step = fe_sub(hi[f], lo[f]);
-                    if (nv > 0) {
-                        val = fe_sub(fe_add(hi[f], hi[f]), lo[f]);
-                        for (int32_t c = 2; c < nv; ++c) val = fe_add(fe_carry_pass(val), step);
-                    } else {
-                        val = fe_sub(fe_add(lo[f], lo[f]), hi[f]);
-                        for (int32_t c = -1; c > nv; --c) val = fe_sub(fe_carry_pass(val), step);
-                    }
-                }
-                P[t] = (f == 0) ? ((nv == 0 || nv == 1) ? val : fe_carry_pass(val)) : fe_mul(val, P[t]);
-            }
-        }
-    }
-}
-
 // factor F of the product at pair b: its line's two end points (lo, hi), binding / storing as the slot's mode says
 template <int F>
 struct LoadFactor {

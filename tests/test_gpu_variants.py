@@ -53,3 +53,17 @@ def test_variant_matches_oracle(env, nv, nt, shapes, monkeypatch):
     _, otabs, _ = op.state()
     for u, t in enumerate(st.flattened_ml_extensions):
         assert np.array_equal(t.evaluations, otabs[u])
+
+
+def test_more_products_than_one_launch_takes():
+    """13 products (> kMaxRoundProds = 12): the big rounds fall back to one launch per product; tables shared across products."""
+    nv, nt = 18, 4
+    shapes = [[0, 1], [1, 2], [2, 3], [3, 0], [0], [1], [2], [3], [0, 2], [1, 3], [0, 1, 2], [1, 2, 3], [0, 1, 2, 3]]
+    tabs = [cref.synth_table(9090, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(9090, 1000, len(shapes))
+    d = H.desc_from(nv, shapes, tabs, coefs)
+    want, wrand = cref.ml_prove(d, threads=cref.max_threads())
+    poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs)
+    proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly)
+    assert np.array_equal(np.stack([m.evaluations for m in proof]), want)
+    assert np.array_equal(state.randomness, wrand)
