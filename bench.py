@@ -138,7 +138,7 @@ def main():
         engine = sharded.HipShardEngine(nv_local, shapes, coefs, tables, dev, borrow=True)
         handle = engine._h
         comm = sharded.DistComm()
-        tail_factory = lambda nvt, tabs: sharded.HipShardEngine(nvt, shapes, coefs, [tabs[u] for u in range(tabs.shape[0])], dev, borrow=False)
+        tail_factory = sharded.TailEngines(shapes, coefs, dev)  # the log2(N)-variable tail prover is built once, reloaded per proof
 
         ncomm = None
         if os.environ.get("SC_BENCH_PYTHON_ROUNDS") != "1":

@@ -83,6 +83,13 @@ class HipShardEngine:
         check(lib().sc_prove_round_partial(self._h, rp, C.c_void_p(out.data_ptr())))
         return out
 
+    def round_full(self, r: Optional[np.ndarray]) -> np.ndarray:
+        """-> (D,4) uint64: the round's canonical message (sc_prove_round); for provers that hold whole tables (the tail)"""
+        out = np.empty((self.D, 4), dtype=np.uint64)
+        rp = C.c_void_p(np.ascontiguousarray(r, dtype=np.uint64).ctypes.data) if r is not None else None
+        check(lib().sc_prove_round(self._h, rp, C.c_void_p(out.ctypes.data)))
+        return out
+
     def bind_final(self, r: np.ndarray):
         """-> (U,4) int64 tensor: the single remaining element of every local table"""
         out = self.torch.empty((self.U, 4), dtype=self.torch.int64, device=self.device)
@@ -93,6 +100,16 @@ class HipShardEngine:
     def reset(self):
         """rewind to round 0 over the same resident shard (borrowing handles only)"""
         check(lib().sc_prover_reset(self._h, None, 0))
+
+    def reload(self, tables):
+        """rewind to round 0 over NEW tables of the same shape (device tensors): a copying handle copies them in again, a
+        borrowing one re-points.  No allocation -- this is what keeps the per-proof tail prover cheap."""
+        torch = self.torch
+        self._tables = [t.to(self.device).contiguous() for t in tables]
+        assert len(self._tables) == self.U
+        tabs = (C.c_void_p * self.U)(*[t.data_ptr() for t in self._tables])
+        with torch.cuda.device(self.device):
+            check(lib().sc_prover_reset(self._h, C.cast(tabs, C.POINTER(C.c_void_p)), SC_TABLES_ON_DEVICE))
 
     def close(self):
         if self._h:
@@ -105,6 +122,25 @@ class HipShardEngine:
             self.close()
         except Exception:
             pass
+
+
+class TailEngines:
+    """tail_factory for prove_sharded / prove_sharded_native that builds the log2(G)-variable tail prover once and reloads it
+    on later proofs (prover_init costs a dozen allocations; a reload is U small device copies)."""
+
+    def __init__(self, shapes, coeffs, device):
+        self.shapes, self.coeffs, self.device = shapes, coeffs, device
+        self._engines = {}
+
+    def __call__(self, nvt, tabs):
+        tl = [tabs[u] for u in range(tabs.shape[0])]
+        e = self._engines.get(nvt)
+        if e is None:
+            e = HipShardEngine(nvt, self.shapes, self.coeffs, tl, self.device, borrow=False)
+            self._engines[nvt] = e
+        else:
+            e.reload(tl)
+        return e
 
 
 class DistComm:
@@ -166,12 +202,22 @@ def prove_sharded(engines: Sequence, comm: DistComm, nv_total: int, max_multipli
         tail = tail_factory(k, tables)
         rt = None
         for j in range(k):
-            evals = wide_reduce(tail.round_partial(rt).cpu().numpy().view(np.uint64))
+            evals = _tail_round(tail, rt)
             proof[nv_local + j] = evals
             rng.feed(ProverMsg(evals))
             rt = rng.sample_fr()
             rand[nv_local + j] = rt
     return proof, rand
+
+
+def _tail_round(tail, rt):
+    """one round of the tail prover: every rank holds the complete G-entry tables, so the round needs no exchange; a HIP engine
+    returns the canonical message straight from sc_prove_round (polled host-mapped result), other engines go through the
+    widened partial form"""
+    if hasattr(tail, "round_full"):
+        return tail.round_full(rt)
+    p = tail.round_partial(rt)
+    return wide_reduce((p.cpu().numpy() if hasattr(p, "cpu") else np.asarray(p)).view(np.uint64))
 
 
 class NativeComm:
@@ -232,7 +278,7 @@ def prove_sharded_native(engine: HipShardEngine, ncomm: NativeComm, comm: DistCo
         tail = tail_factory(k, tables)
         rt = None
         for j in range(k):
-            evals = wide_reduce(tail.round_partial(rt).cpu().numpy().view(np.uint64))
+            evals = _tail_round(tail, rt)
             proof[nv_local + j] = evals
             rng.feed(ProverMsg(evals))
             rt = rng.sample_fr()
@@ -246,5 +292,4 @@ def prove_logical_shards(nv: int, shapes, tables: Sequence[np.ndarray], coeffs: 
     n_loc = 1 << (nv - k)
     engines = [HipShardEngine(nv - k, shapes, coeffs, [t[g * n_loc:(g + 1) * n_loc] for t in tables], device, borrow=True)
                for g in range(G)]
-    tail_factory = lambda nvt, tabs: HipShardEngine(nvt, shapes, coeffs, [tabs[u] for u in range(tabs.shape[0])], device, borrow=False)
-    return prove_sharded(engines, DistComm(), nv, max(len(s) for s in shapes), tail_factory)
+    return prove_sharded(engines, DistComm(), nv, max(len(s) for s in shapes), TailEngines(shapes, coeffs, device))

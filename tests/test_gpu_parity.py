@@ -248,6 +248,25 @@ def test_sharded_partial_rounds_single_gpu():
     assert np.array_equal(rand, wrand)
 
 
+def test_sharded_tail_prover_is_reused_across_proofs():
+    """bench.py --gpus N proves repeatedly: the log2(G)-variable tail prover is built once (sharded.TailEngines) and reloaded
+    with every proof's gathered tables.  Two proofs over different tables through the same tail must both match the oracle."""
+    from sumcheck_amd import sharded
+    dev = _torch_dev()
+    nv, shapes, nt, G = 11, [[0, 1, 2, 3], [2], [1, 1]], 4, 8
+    coefs = cref.synth_table(56, 1000, len(shapes))
+    tail = sharded.TailEngines(shapes, coefs, dev)
+    n_loc = 1 << (nv - 3)
+    for seed in (56, 57, 58):
+        tabs = [cref.synth_table(seed, s, 1 << nv) for s in range(nt)]
+        d = H.desc_from(nv, shapes, tabs, coefs)
+        want, wrand = cref.ml_prove(d, threads=cref.max_threads())
+        engines = [sharded.HipShardEngine(nv - 3, shapes, coefs, [t[g * n_loc:(g + 1) * n_loc] for t in tabs], dev, borrow=True) for g in range(G)]
+        got, rand = sharded.prove_sharded(engines, sharded.DistComm(), nv, max(len(sh) for sh in shapes), tail)
+        assert np.array_equal(got, want)
+        assert np.array_equal(rand, wrand)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # GKR round sumcheck (BASELINE config 5): reference src/gkr_round_sumcheck/{mod.rs,test.rs}
 # ------------------------------------------------------------------------------------------------------------------
