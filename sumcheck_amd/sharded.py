@@ -152,15 +152,29 @@ class DistComm:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
 
+    def _host_backend(self) -> bool:
+        """gloo moves host tensors only: device tensors take a round trip through the host (tests: two processes on one GPU)"""
+        return self.world > 1 and self.dist.get_backend() == "gloo"
+
     def all_reduce_sum(self, t):
         if self.world > 1:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            if self._host_backend() and t.is_cuda:
+                h = t.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
 
     def all_gather(self, t):
         import torch
         if self.world == 1:
             return t.unsqueeze(0)
+        if self._host_backend() and t.is_cuda:
+            h = t.cpu()
+            out = [torch.empty_like(h) for _ in range(self.world)]
+            self.dist.all_gather(out, h)
+            return torch.stack(out).to(t.device)
         out = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t)
         return torch.stack(out)

@@ -426,3 +426,55 @@ def test_poly_evaluate_rejects_bad_input():
     bad = np.tile(np.array([[0xFFFFFFFFFFFFFFFF] * 4], dtype=np.uint64), (3, 1))  # >= p
     with pytest.raises(sc.SumcheckError):
         poly.evaluate(bad)
+
+
+def _two_rank_worker(rank, world, port, nv, shapes, nt, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sumcheck_amd import sharded
+        dev = "cuda:0"  # both ranks share the one GPU of the test box; the exchange goes through gloo
+        n_loc = (1 << nv) // world
+        coefs = cref.synth_table(93, 1000, len(shapes))
+        tail = sharded.TailEngines(shapes, coefs, dev)
+        out = []
+        for seed in (93, 94):  # two proofs: the second one reloads the cached tail prover
+            tabs = [cref.synth_table(seed, s, 1 << nv) for s in range(nt)]
+            eng = sharded.HipShardEngine(nv - 1, shapes, coefs, [t[rank * n_loc:(rank + 1) * n_loc] for t in tabs], dev, borrow=True)
+            out.append(sharded.prove_sharded([eng], sharded.DistComm(), nv, max(len(s) for s in shapes), tail))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_sharded_proof_on_one_gpu():
+    """One process per shard as under torchrun, world_size 2, with the real HIP engines: both ranks use this box's
+    single GPU and exchange through gloo (RCCL refuses two ranks on one device), so everything but the transport is the
+    multi-GPU path: per-round widened all-reduce, bind_final + all-gather, cached tail prover, replicated transcript."""
+    import socket
+    import torch.multiprocessing as mp
+    nv, shapes, nt = 13, [[0, 1, 2], [3, 3], [1]], 4
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, nv, shapes, nt, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    coefs = cref.synth_table(93, 1000, len(shapes))
+    for i, seed in enumerate((93, 94)):
+        tabs = [cref.synth_table(seed, s, 1 << nv) for s in range(nt)]
+        want, wrand = cref.ml_prove(H.desc_from(nv, shapes, tabs, coefs), threads=cref.max_threads())
+        for rank in (0, 1):
+            got, rand = res[rank][i]
+            assert np.array_equal(got, want)
+            assert np.array_equal(rand, wrand)
