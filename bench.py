@@ -95,13 +95,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     assert world & (world - 1) == 0, "the shard count must be a power of two"
+    # SC_BENCH_ONE_GPU=1 (tests only): every rank uses GPU 0 and the ranks exchange through gloo -- the multi-rank plumbing of
+    # this file on a one-GPU box (RCCL refuses two ranks on one device, so the rounds run through the torch.distributed loop,
+    # the same code the bench falls back to on any RCCL failure).  The numbers of such a run mean nothing.
+    one_gpu = os.environ.get("SC_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.check(sc.lib().sc_set_device(local_rank))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     shapes, U = C3_SHAPES, 10
     nv_local = args.nv_local
@@ -141,7 +150,7 @@ def main():
         tail_factory = sharded.TailEngines(shapes, coefs, dev)  # the log2(N)-variable tail prover is built once, reloaded per proof
 
         ncomm = None
-        if os.environ.get("SC_BENCH_PYTHON_ROUNDS") != "1":
+        if os.environ.get("SC_BENCH_PYTHON_ROUNDS") != "1" and not one_gpu:
             try:  # per-round all-reduce inside the library (RCCL on the prover's stream); the Python loop is the fallback
                 ncomm = sharded.NativeComm(dev)
             except Exception as e:
@@ -184,7 +193,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
