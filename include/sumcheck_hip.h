@@ -171,6 +171,10 @@ SC_API int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_
  * num_vars == 0 is allowed here (a table is its single entry). */
 SC_API int sc_poly_evaluate(const sc_poly_desc *desc, const uint64_t *point, uint64_t *out_value, uint64_t *out_table_values_or_null);
 
+/* The GKR entry points keep their device scratch (about 1 GB at dim = 20) and a two-table prover handle in a process-wide
+ * cache between calls (allocating and freeing them costs more than a millisecond per call).  This releases it. */
+SC_API int sc_release_caches(void);
+
 /* ---- synthetic inputs + instrumentation (bench / tests) ------------------------------------- */
 /* SplitMix64-keyed uniform field elements, generated on the device: n elements of
  * stream `stream` starting at element `first`, written to device memory d_out (n x 4 limbs). */

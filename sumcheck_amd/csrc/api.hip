@@ -44,6 +44,8 @@ static int fail(int code, const char *fmt, ...) {
     return code;
 }
 // shared with gkr.hip
+int sc_internal_device() { return g_device; } // the calling thread's device (sc_set_device), for gkr.hip
+
 int sc_internal_fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -35,6 +36,7 @@ using scd::FrU;
 using scd::kBlock;
 
 int sc_internal_fail(int code, const char *fmt, ...); // api.hip
+int sc_internal_device();                             // api.hip: the calling thread's device (sc_set_device)
 struct sc_rng {
     sch::Blake2b512Rng rng;
 };
@@ -149,17 +151,15 @@ struct DevBuf { // device scratch for the lifetime of one API call: one arena (h
                 // buffers cost more than the kernels), bump-allocated, with a plain hipMalloc fallback if the estimate is short
     char *arena = nullptr;
     size_t cap = 0, used = 0;
+    bool leased = false; // the arena belongs to the process-wide cache (GkrCache below): not freed here
     std::vector<void *> extra;
     ~DevBuf() {
-        if (arena) (void)hipFree(arena);
+        if (arena && !leased) (void)hipFree(arena);
         for (void *p : extra) (void)hipFree(p);
+        release_lease();
     }
-    hipError_t reserve(size_t bytes) {
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&arena), bytes);
-        if (e == hipSuccess) cap = bytes;
-        else (void)hipGetLastError();
-        return hipSuccess; // on failure fall back to per-buffer allocations
-    }
+    void release_lease();
+    hipError_t reserve(size_t bytes); // takes the cached arena when it is free and large enough (or grows it), else allocates
     template <typename T>
     hipError_t alloc(T **out, size_t n) {
         const size_t bytes = ((n ? n : 1) * sizeof(T) + 255) & ~size_t(255);
@@ -177,6 +177,67 @@ struct DevBuf { // device scratch for the lifetime of one API call: one arena (h
         return e;
     }
 };
+// Process-wide scratch cache: a GKR call needs ~1 GB of device scratch for dim = 20 and a two-table prover handle; allocating
+// and freeing them costs more than a millisecond per call (hipMalloc + the synchronous hipFree), a fifth of config 5.  One
+// call at a time may hold the cache (try_lock; concurrent callers simply allocate their own).  sc_release_caches() frees it.
+struct GkrCache {
+    std::mutex mu;
+    char *arena = nullptr;
+    size_t cap = 0;
+    int device = -1;
+    sc_prover *prover = nullptr; // K = 1, M = 2, U = 2 borrowing handle of `prover_dim` variables
+    uint32_t prover_dim = 0;
+};
+static GkrCache g_cache;
+static thread_local bool t_holds_cache = false;
+
+hipError_t DevBuf::reserve(size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!t_holds_cache && g_cache.mu.try_lock()) {
+        t_holds_cache = true;
+        leased = true;
+        if (g_cache.device != dev || g_cache.cap < bytes) {
+            if (g_cache.prover) { // the cached handle borrows tables inside the old arena and lives on the old device
+                sc_prover_free(g_cache.prover);
+                g_cache.prover = nullptr;
+            }
+            if (g_cache.arena) (void)hipFree(g_cache.arena);
+            g_cache.arena = nullptr;
+            g_cache.cap = 0;
+            g_cache.device = dev;
+            if (hipMalloc(reinterpret_cast<void **>(&g_cache.arena), bytes) == hipSuccess) g_cache.cap = bytes;
+            else (void)hipGetLastError();
+        }
+        arena = g_cache.arena;
+        cap = g_cache.cap;
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&arena), bytes);
+    if (e == hipSuccess) cap = bytes;
+    else (void)hipGetLastError();
+    return hipSuccess; // on failure fall back to per-buffer allocations
+}
+void DevBuf::release_lease() {
+    if (leased) {
+        leased = false;
+        t_holds_cache = false;
+        g_cache.mu.unlock();
+    }
+}
+
+extern "C" int sc_release_caches(void) {
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    if (g_cache.device >= 0) (void)hipSetDevice(g_cache.device);
+    if (g_cache.prover) sc_prover_free(g_cache.prover);
+    g_cache.prover = nullptr;
+    if (g_cache.arena) (void)hipFree(g_cache.arena);
+    g_cache.arena = nullptr;
+    g_cache.cap = 0;
+    g_cache.device = -1;
+    return SC_OK;
+}
+
 inline size_t gkr_scratch_estimate(uint64_t nnz, uint64_t N) { return (size_t)704 * (nnz + 1) + (size_t)352 * N + ((size_t)64 << 20); }
 
 inline int grid_for(uint64_t n) { return scd::grid_for_pairs(n); }
@@ -312,6 +373,7 @@ int check_gkr_args(uint64_t nnz, uint32_t dim) {
     if (dim > 21) return sc_internal_fail(SC_ERR_BAD_ARG, "dim %u: 3*dim index bits do not fit 64-bit indices", dim);
     if (nnz >= (1ULL << 32)) return sc_internal_fail(SC_ERR_BAD_ARG, "nnz too large");
     if (sc_device_count() <= 0) return sc_internal_fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    G_TRY(hipSetDevice(sc_internal_device())); // scratch, kernels and the prover handle of this call all live on the thread's device
     return SC_OK;
 }
 int check_points(const uint64_t *pt, uint32_t n, const char *what) {
@@ -440,10 +502,27 @@ static int run_phase(sch::Blake2b512Rng &rng, sc_prover **handle, const Fr *dA, 
 }
 
 namespace {
-struct ProverGuard {
+struct ProverGuard { // declared AFTER the DevBuf it pairs with, so it is destroyed first, while the cache lease is still held
     sc_prover *p = nullptr;
+    uint32_t dim = 0;
+    bool cacheable = false;
+    void take_cached(uint32_t d, bool leased) {
+        dim = d;
+        cacheable = leased;
+        if (leased && g_cache.prover && g_cache.prover_dim == d) {
+            p = g_cache.prover;
+            g_cache.prover = nullptr;
+        }
+    }
     ~ProverGuard() {
-        if (p) sc_prover_free(p);
+        if (!p) return;
+        if (cacheable && t_holds_cache) {
+            if (g_cache.prover) sc_prover_free(g_cache.prover);
+            g_cache.prover = p;
+            g_cache.prover_dim = dim;
+        } else {
+            sc_prover_free(p);
+        }
     }
 };
 } // namespace
@@ -500,6 +579,7 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     lap("phase one init");
     std::vector<sch::Fr> u(dim), v(dim);
     ProverGuard pg;
+    pg.take_cached(dim, mem.leased);
     if ((rc = run_phase(rng->rng, &pg.p, d_hg, d_f2, dim, out_proof, u.data()))) return rc; // mod.rs:107-119
     lap("phase one sumcheck");
     if ((rc = phase_two_device(mem, d_gi, d_gv, n1, dim, u.data(), d_f1gu, s))) return rc; // mod.rs:121
