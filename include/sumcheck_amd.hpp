@@ -358,7 +358,53 @@ inline DenseMultilinearExtension initialize_phase_two(const SparseMultilinearExt
     return out;
 }
 
+// gkr_round_sumcheck/data_structures.rs:22-56
+struct GKRRoundSumcheckSubClaim {
+    std::vector<Fr> u, v;
+    Fr expected_evaluation;
+    // expected_evaluation == f1(g, u, v) * f2(u) * f3(v); the three oracle queries run on the GPU
+    bool verify_subclaim(const SparseMultilinearExtension &f1, const DenseMultilinearExtension &f2, const DenseMultilinearExtension &f3,
+                         const std::vector<Fr> &g) const {
+        const size_t dim = u.size();
+        if (v.size() != dim || g.size() != dim || f1.num_vars != 3 * dim || f2.num_vars != dim || f3.num_vars != dim)
+            throw Panic(SC_ERR_BAD_ARG, "assertion failed: dimensions");
+        std::vector<Fr> guv(g);
+        guv.insert(guv.end(), u.begin(), u.end());
+        guv.insert(guv.end(), v.begin(), v.end());
+        Fr a, ab, abc;
+        check(sc_sparse_evaluate(f1.indices.data(), f1.values.empty() ? nullptr : f1.values[0].l, f1.indices.size(), (uint32_t)f1.num_vars,
+                                 guv.empty() ? nullptr : guv[0].l, a.l));
+        const Fr b = f2.evaluate(u), c = f3.evaluate(v);
+        check(sc_fr_elementwise(0, a.l, b.l, ab.l, 1));
+        check(sc_fr_elementwise(0, ab.l, c.l, abc.l, 1));
+        return abc == expected_evaluation;
+    }
+};
+
 struct GKRRoundSumcheck {
+    // verifier_init{max_multiplicands: 2} + (feed, verify_round) x dim + check_and_generate_subclaim (mod.rs:157-166, 173-182)
+    static std::pair<std::vector<Fr>, Fr> verify_phase(Blake2b512Rng &rng, const Proof &msgs, size_t dim, const Fr &asserted_sum) {
+        if (msgs.size() < dim) throw Panic(SC_ERR_BAD_ARG, "proof is incomplete");
+        std::vector<Fr> rs;
+        for (size_t i = 0; i < dim; ++i) {
+            if (msgs[i].evaluations.empty()) throw Panic(SC_ERR_BAD_ARG, "incorrect number of evaluations");
+            sc_rng_feed_prover_msg(rng.raw(), msgs[i].evaluations[0].l, (uint32_t)msgs[i].evaluations.size());
+            rs.push_back(rng.rand_fr());
+        }
+        Fr expected = asserted_sum;
+        for (size_t i = 0; i < dim; ++i) {
+            const auto &ev = msgs[i].evaluations;
+            if (ev.size() != 3) throw Panic(SC_ERR_BAD_ARG, "incorrect number of evaluations");
+            if (ev[0] + ev[1] != expected) throw Reject("Prover message is not consistent with the claim.");
+            check(sc_interpolate_uni_poly(ev[0].l, 3, rs[i].l, expected.l));
+        }
+        return {rs, expected};
+    }
+    static GKRRoundSumcheckSubClaim verify(Blake2b512Rng &rng, size_t f2_num_vars, const GKRProof &proof, const Fr &claimed_sum) { // mod.rs:147-192
+        auto p1 = verify_phase(rng, proof.phase1_sumcheck_msgs, f2_num_vars, claimed_sum);
+        auto p2 = verify_phase(rng, proof.phase2_sumcheck_msgs, f2_num_vars, p1.second);
+        return GKRRoundSumcheckSubClaim{std::move(p1.first), std::move(p2.first), p2.second};
+    }
     static GKRProof prove(Blake2b512Rng &rng, const SparseMultilinearExtension &f1, const DenseMultilinearExtension &f2,
                           const DenseMultilinearExtension &f3, const std::vector<Fr> &g) { // gkr_round_sumcheck/mod.rs:93-139
         const size_t dim = f2.num_vars;

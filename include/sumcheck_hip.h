@@ -171,6 +171,11 @@ SC_API int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_
  * num_vars == 0 is allowed here (a table is its single entry). */
 SC_API int sc_poly_evaluate(const sc_poly_desc *desc, const uint64_t *point, uint64_t *out_value, uint64_t *out_table_values_or_null);
 
+/* SparseMultilinearExtension::evaluate (ark-poly; the f1(g,u,v) factor of GKRRoundSumcheckSubClaim::verify_subclaim,
+ * src/gkr_round_sumcheck/data_structures.rs:33-56): idx distinct, < 2^num_vars, num_vars <= 63; point: num_vars x 4. */
+SC_API int sc_sparse_evaluate(const uint64_t *idx, const uint64_t *vals, uint64_t nnz, uint32_t num_vars, const uint64_t *point,
+                              uint64_t *out);
+
 /* The GKR entry points keep their device scratch (about 1 GB at dim = 20) and a two-table prover handle in a process-wide
  * cache between calls (allocating and freeing them costs more than a millisecond per call).  This releases it. */
 SC_API int sc_release_caches(void);

@@ -49,6 +49,7 @@ extern "C" {
     pub fn sc_prover_free(p: *mut sc_prover);
     pub fn sc_fix_variables(input: *const u64, nv: u32, point: *const u64, k: u32, out: *mut u64, flags: u32) -> c_int;
     pub fn sc_poly_evaluate(desc: *const sc_poly_desc, point: *const u64, out_value: *mut u64, out_table_values_or_null: *mut u64) -> c_int;
+    pub fn sc_sparse_evaluate(idx: *const u64, vals: *const u64, nnz: u64, num_vars: u32, point: *const u64, out: *mut u64) -> c_int;
     pub fn sc_ml_prove(desc: *const sc_poly_desc, rng_or_null: *mut sc_rng, out_proof: *mut u64, out_state_or_null: *mut *mut sc_prover) -> c_int;
     pub fn sc_gkr_prove(rng: *mut sc_rng, f1_idx: *const u64, f1_vals: *const u64, nnz: u64, dim: u32, f2: *const u64, f3: *const u64,
                         g: *const u64, out_proof: *mut u64, out_uv_or_null: *mut u64) -> c_int;

@@ -66,6 +66,7 @@ SIGNATURES = {
     "sc_fix_variables": (C.c_int, [_V, C.c_uint32, _V, C.c_uint32, _V, C.c_uint32]),
     "sc_poly_evaluate": (C.c_int, [_V, _V, _V, _V]),
     "sc_release_caches": (C.c_int, []),
+    "sc_sparse_evaluate": (C.c_int, [_V, _V, C.c_uint64, C.c_uint32, _V, _V]),
     "sc_rng_setup": (_V, []),
     "sc_rng_free": (None, [_V]),
     "sc_rng_feed_bytes": (None, [_V, C.c_char_p, C.c_size_t]),

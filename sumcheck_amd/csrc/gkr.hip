@@ -460,8 +460,52 @@ extern "C" int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_val
     return SC_OK;
 }
 
-// One sumcheck phase: product 1*(A*B) over two device tables (start_phase{1,2}_sumcheck, mod.rs:45-54,66-82), dim rounds
-// of prove_round / feed / sample (mod.rs:111-119,126-133).
+// SparseMultilinearExtension::evaluate(point) = fix_variables(point)[0] (ark-poly; used by GKRRoundSumcheckSubClaim::
+// verify_subclaim, src/gkr_round_sumcheck/data_structures.rs:33-56): every non-zero is weighted by eq(point, index) on the device
+// (num_vars products per entry) and the weighted values are summed with the segmented field sum over the single key 0.
+extern "C" int sc_sparse_evaluate(const uint64_t *idx, const uint64_t *vals, uint64_t nnz, uint32_t num_vars, const uint64_t *point,
+                                  uint64_t *out) {
+    if ((nnz && (!idx || !vals)) || (num_vars && !point) || !out) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    if (num_vars > 63) return sc_internal_fail(SC_ERR_BAD_ARG, "num_vars %u: indices are 64-bit", num_vars);
+    if (nnz >= (1ULL << 32)) return sc_internal_fail(SC_ERR_BAD_ARG, "nnz too large");
+    if (sc_device_count() <= 0) return sc_internal_fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    G_TRY(hipSetDevice(sc_internal_device()));
+    int rc;
+    if ((rc = check_points(point, num_vars, "point"))) return rc;
+    for (uint64_t i = 0; i < nnz; ++i)
+        if ((idx[i] >> num_vars) != 0) return sc_internal_fail(SC_ERR_BAD_ARG, "index %llu out of range", (unsigned long long)i);
+    std::memset(out, 0, 32);
+    if (nnz == 0) return SC_OK;
+    hipStream_t s = nullptr;
+    DevBuf mem;
+    (void)mem.reserve((size_t)160 * (nnz + 1) + ((size_t)16 << 20));
+    uint64_t *d_idx = nullptr, *d_key = nullptr, *d_okey = nullptr;
+    Fr *d_vals = nullptr, *d_w = nullptr, *d_oval = nullptr, *d_point = nullptr;
+    unsigned int *d_cnt = nullptr;
+    G_TRY(mem.alloc(&d_idx, nnz));
+    G_TRY(mem.alloc(&d_key, nnz));
+    G_TRY(mem.alloc(&d_okey, nnz));
+    G_TRY(mem.alloc(&d_vals, nnz));
+    G_TRY(mem.alloc(&d_w, nnz));
+    G_TRY(mem.alloc(&d_oval, nnz));
+    G_TRY(mem.alloc(&d_point, num_vars));
+    G_TRY(mem.alloc(&d_cnt, 1));
+    G_TRY(hipMemcpyAsync(d_idx, idx, nnz * 8, hipMemcpyHostToDevice, s));
+    G_TRY(hipMemcpyAsync(d_vals, vals, nnz * 32, hipMemcpyHostToDevice, s));
+    if (num_vars) G_TRY(hipMemcpyAsync(d_point, point, (size_t)num_vars * 32, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_sparse_scale_direct, dim3(grid_for(nnz)), dim3(kBlock), 0, s, d_idx, d_vals, (const uint32_t *)nullptr, d_point, num_vars, nnz,
+                       d_key, d_w);
+    G_TRY(hipGetLastError());
+    size_t tb = 0;
+    G_TRY(rocprim::reduce_by_key(nullptr, tb, d_key, d_w, nnz, d_okey, d_oval, d_cnt, FrAdd(), rocprim::equal_to<uint64_t>(), s));
+    char *tmp = nullptr;
+    G_TRY(mem.alloc(&tmp, tb));
+    G_TRY(rocprim::reduce_by_key(tmp, tb, d_key, d_w, nnz, d_okey, d_oval, d_cnt, FrAdd(), rocprim::equal_to<uint64_t>(), s));
+    G_TRY(hipMemcpyAsync(out, d_oval, 32, hipMemcpyDeviceToHost, s)); // every key is 0: one segment
+    G_TRY(hipStreamSynchronize(s));
+    return SC_OK;
+}
+
 // One sumcheck phase: product 1*(A*B) over two device tables (start_phase{1,2}_sumcheck, mod.rs:45-54,66-82), dim rounds
 // of prove_round / feed / sample (mod.rs:111-119,126-133).  The handle (stream, ping-pong buffers, pinned result page) is
 // created for phase one and rewound onto phase two's tables, so the second phase allocates nothing.

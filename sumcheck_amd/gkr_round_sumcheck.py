@@ -38,16 +38,14 @@ class SparseMultilinearExtension:
         return cls(num_vars, np.asarray(idx, dtype=np.uint64), np.stack(vals) if vals else np.zeros((0, 4), np.uint64))
 
     def evaluate(self, point) -> np.ndarray:
-        """host-side, O(nnz * num_vars): only the verifier's final oracle query needs it (data_structures.rs:53)"""
-        pt = field.to_ints(np.asarray(point, dtype=np.uint64).reshape(-1, 4))
-        assert len(pt) == self.num_vars
-        acc = 0
-        for i, v in zip(self.indices.tolist(), field.to_ints(self.values)):
-            w = v
-            for k, r in enumerate(pt):
-                w = w * (r if (i >> k) & 1 else (1 - r)) % field.P
-            acc = (acc + w) % field.P
-        return field.from_int(acc)
+        """ark-poly SparseMultilinearExtension::evaluate on the GPU (sc_sparse_evaluate): the verifier's oracle query
+        f1(g, u, v) of verify_subclaim (data_structures.rs:53)"""
+        pt = np.ascontiguousarray(np.asarray(point, dtype=np.uint64).reshape(-1, 4))
+        assert pt.shape[0] == self.num_vars
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib().sc_sparse_evaluate(_ptr(self.indices), _ptr(self.values), self.indices.shape[0], self.num_vars,
+                                       _ptr(pt) if pt.size else None, _ptr(out)))
+        return out
 
 
 def initialize_phase_one(f1: SparseMultilinearExtension, f3: DenseMultilinearExtension, g):

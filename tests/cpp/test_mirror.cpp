@@ -201,6 +201,23 @@ static void test_gkr_extract(Blake2b512Rng &rng, size_t dim) { // gkr_round_sumc
     const GKRProof proof = GKRRoundSumcheck::prove(fs, f1, f2, f3, g);
     EXPECT(proof.extract_sum() == expected);
     EXPECT(proof.phase1_sumcheck_msgs.size() == dim && proof.phase2_sumcheck_msgs.size() == dim);
+    // test_circuit (test.rs:57-69): verify with a fresh transcript, then the three oracle queries of the sub-claim
+    Blake2b512Rng vs;
+    const GKRRoundSumcheckSubClaim sub = GKRRoundSumcheck::verify(vs, dim, proof, expected);
+    EXPECT(sub.u.size() == dim && sub.v.size() == dim);
+    EXPECT(sub.verify_subclaim(f1, f2, f3, g));
+    // a wrong claimed sum is rejected in the first round; a tampered sub-claim fails the oracle check
+    bool rejected = false;
+    try {
+        Blake2b512Rng vs2;
+        GKRRoundSumcheck::verify(vs2, dim, proof, expected + Fr::one());
+    } catch (const Reject &) {
+        rejected = true;
+    }
+    EXPECT(rejected);
+    GKRRoundSumcheckSubClaim bad = sub;
+    bad.expected_evaluation = bad.expected_evaluation + Fr::one();
+    EXPECT(!bad.verify_subclaim(f1, f2, f3, g));
 }
 
 int main() {

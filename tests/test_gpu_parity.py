@@ -478,3 +478,28 @@ def test_two_process_sharded_proof_on_one_gpu():
             got, rand = res[rank][i]
             assert np.array_equal(got, want)
             assert np.array_equal(rand, wrand)
+
+
+@pytest.mark.parametrize("num_vars,nnz", [(0, 1), (1, 2), (7, 40), (24, 3000), (60, 5000), (63, 1000)])
+def test_sparse_evaluate_matches_big_integers(num_vars, nnz):
+    """SparseMultilinearExtension::evaluate through sc_sparse_evaluate against a direct big-integer evaluation of
+    sum_i v_i * prod_k (bit_k(i) ? r_k : 1 - r_k)."""
+    from sumcheck_amd import field
+    rng = np.random.default_rng(1234 + num_vars)
+    space = 1 << num_vars
+    if space <= 4 * nnz:
+        idx = rng.permutation(space)[: min(nnz, space)].astype(np.uint64)
+    else:
+        idx = np.unique(rng.integers(0, space, size=2 * nnz, dtype=np.uint64))[:nnz]
+    vals = cref.synth_table(4321, num_vars, idx.shape[0])
+    point = cref.synth_table(4322, num_vars, max(num_vars, 1))[:num_vars]
+    f = sc.SparseMultilinearExtension(num_vars, idx, vals)
+    got = field.to_int(f.evaluate(point))
+    pt = field.to_ints(point) if num_vars else []
+    want = 0
+    for i, v in zip(idx.tolist(), field.to_ints(vals)):
+        w = v
+        for k, r in enumerate(pt):
+            w = w * (r if (i >> k) & 1 else (1 - r)) % field.P
+        want = (want + w) % field.P
+    assert got == want
