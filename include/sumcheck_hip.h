@@ -190,7 +190,9 @@ SC_API int sc_synth_table_device(uint64_t seed, uint64_t stream, uint64_t first,
 SC_API int sc_prover_last_round_ms(sc_prover *p, float *ms);
 /* Per-product instrumentation: with timing on, every product kernel launch is bracketed by HIP events on the
  * handle's stream; sc_prover_get_timing returns the accumulated device milliseconds and launch counts per
- * product (K entries each) and the accumulated per-round span (all kernels of a round incl. finalize).
+ * product (K entries each) and the accumulated per-round span (all kernels of a round incl. finalize) of the rounds
+ * that were launched with events: inside sc_ml_prove / sc_gkr_prove the latency-bound late rounds are pipelined
+ * (enqueued before their challenge exists) and record none.
  * When a round runs as one launch over all its products (every product has <= 4 multiplicands: k_round_tree),
  * that launch is reported under product 0 and the other products report no launches. */
 SC_API int sc_prover_set_timing(sc_prover *p, int on);

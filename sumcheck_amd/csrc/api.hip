@@ -164,6 +164,17 @@ struct sc_prover {
     std::vector<hipStream_t> pstreams;
     std::vector<hipEvent_t> pjoin;
     hipEvent_t ev_fork = nullptr;
+    // pipelined late rounds (sc_ml_prove_handle, GKR): the next round is enqueued behind a one-lane wait kernel before the
+    // current round's message has been hashed; its bind kernel reads the challenge from the host-mapped mailbox
+    uint32_t *sig = nullptr;        // host-mapped word the wait kernel polls (after the two mailbox slots)
+    uint32_t *sig_dev = nullptr;
+    uint32_t sig_seq = 0;           // last value waited for
+    FrHost *h_mail = nullptr;       // host-mapped, two slots (+ the word above)
+    FrHost *h_mail_dev = nullptr;
+    FrHost *d_mail = nullptr;       // device-memory copy of the slot in use (two slots), filled by the wait kernel
+    uint32_t *sigmem = nullptr;     // SC_PIPELINE=2: signal memory for a command-processor wait in front of the wait kernel
+    bool pipeline_ok = true;        // cleared when the wait-value path is unavailable (or SC_PIPELINE=0)
+    bool deferred_pending = false;  // a round is enqueued behind the wait and still needs its challenge
     bool merge_rounds = false; // big rounds run as ONE launch over all products (k_round_tree); SC_MERGE=0 disables
     int rotate = 1;            // product rotation inside that launch (SC_ROTATE, see RoundArgs)
     bool use_f29 = false; // bound tables of big rounds kept in the internal 9 x 29-bit format (all products <= 4 multiplicands)
@@ -184,6 +195,11 @@ struct sc_prover {
 static void prover_destroy(sc_prover *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
+    if (p->deferred_pending && p->sig) { // release a stream that still waits for a challenge before synchronising it
+        __atomic_store_n(p->sig, p->sig_seq, __ATOMIC_RELEASE);
+        if (p->sigmem) __atomic_store_n(p->sigmem, p->sig_seq, __ATOMIC_RELEASE);
+        p->deferred_pending = false;
+    }
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
     if (p->arena) (void)hipFree(p->arena);
     if (p->d_partials) (void)hipFree(p->d_partials);
@@ -196,6 +212,9 @@ static void prover_destroy(sc_prover *p) {
     if (p->d_wide) (void)hipFree(p->d_wide);
     if (p->h_wide) (void)hipHostFree(p->h_wide);
     if (p->d_combos) (void)hipFree(p->d_combos);
+    if (p->h_mail) (void)hipHostFree(p->h_mail);
+    if (p->d_mail) (void)hipFree(p->d_mail);
+    if (p->sigmem) (void)hipFree(p->sigmem);
     if (p->d_cur_tables) (void)hipFree(p->d_cur_tables);
     if (p->h_cur_tables) (void)hipHostFree(p->h_cur_tables);
     if (p->d_slot_table) (void)hipFree(p->d_slot_table);
@@ -471,11 +490,83 @@ static int collect_timing(sc_prover *p) {
 
 // Launch one round's kernels on p->stream.  On return the round polynomial is in p->d_out (and in
 // d_wide if non-null); nothing has been synchronised.
-static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool publish_to_host) {
+static uint64_t small_pairs_limit() { // SC_SMALL_LOG2: experiment knob for the big/small round boundary
+    static const uint64_t v = [] {
+        const char *e = std::getenv("SC_SMALL_LOG2");
+        return e ? (1ULL << std::atoi(e)) : scd::kSmallRoundPairs;
+    }();
+    return v;
+}
+
+// Pipelined late rounds.  can_defer_next: the NEXT round is a latency-bound one and the wait-value machinery is available.
+static bool can_defer_next(sc_prover *p) {
+    if (!p->pipeline_ok || p->exhausted || p->round == 0 || p->round >= p->nv) return false;
+    const uint64_t n_pairs_next = 1ULL << (p->nv - (p->round + 1));
+    if (!(n_pairs_next <= small_pairs_limit() && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0)) return false;
+    if (!p->sig) { // first use: signal word + mailbox; any failure switches pipelining off for this handle
+        static const bool env_off = [] {
+            const char *e = std::getenv("SC_PIPELINE");
+            return e && std::atoi(e) == 0;
+        }();
+        bool ok = !env_off && hipSetDevice(p->device) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->h_mail), 2 * sizeof(FrHost) + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+        ok = ok && hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_mail_dev), p->h_mail, 0) == hipSuccess;
+        ok = ok && hipMalloc(reinterpret_cast<void **>(&p->d_mail), 2 * sizeof(FrHost)) == hipSuccess;
+        static const bool cp_wait = [] {
+            const char *e = std::getenv("SC_PIPELINE");
+            return e && std::atoi(e) == 2;
+        }();
+        if (ok && cp_wait) {
+            ok = hipExtMallocWithFlags(reinterpret_cast<void **>(&p->sigmem), 8, hipMallocSignalMemory) == hipSuccess;
+            if (ok) *reinterpret_cast<volatile uint64_t *>(p->sigmem) = 0;
+        }
+        if (ok) {
+            p->sig = reinterpret_cast<uint32_t *>(p->h_mail + 2);
+            p->sig_dev = reinterpret_cast<uint32_t *>(p->h_mail_dev + 2);
+            __atomic_store_n(p->sig, 0u, __ATOMIC_RELEASE);
+            p->sig_seq = 0;
+        } else {
+            (void)hipGetLastError();
+            if (p->h_mail) (void)hipHostFree(p->h_mail);
+            if (p->d_mail) (void)hipFree(p->d_mail);
+            p->sig = nullptr;
+            p->h_mail = nullptr;
+            p->d_mail = nullptr;
+            p->pipeline_ok = false;
+            return false;
+        }
+    }
+    return true;
+}
+// the challenge of the round enqueued with deferred = true: mailbox first, then the signal the stream is waiting on
+static void provide_challenge(sc_prover *p, const sch::Fr &r) {
+    p->randomness.push_back(r);
+    FrHost *slot = p->h_mail + (p->sig_seq & 1u);
+    std::memcpy(slot, &r, sizeof(FrHost));
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    __atomic_store_n(p->sig, p->sig_seq, __ATOMIC_RELEASE);
+    if (p->sigmem) __atomic_store_n(p->sigmem, p->sig_seq, __ATOMIC_RELEASE);
+    p->deferred_pending = false;
+}
+// error path: let a stream that is blocked on the wait drain (the round then runs on a stale challenge; its result is discarded)
+static void abandon_deferred(sc_prover *p) {
+    if (p->deferred_pending) {
+        __atomic_store_n(p->sig, p->sig_seq, __ATOMIC_RELEASE);
+        if (p->sigmem) __atomic_store_n(p->sigmem, p->sig_seq, __ATOMIC_RELEASE);
+        p->deferred_pending = false;
+        (void)hipStreamSynchronize(p->stream);
+        p->exhausted = true; // tables are no longer meaningful: the handle must be reset
+    }
+}
+
+// deferred = true (library-internal): the challenge does not exist yet.  The round is enqueued behind a wait on p->sig and its
+// bind kernel reads the challenge from the mailbox; provide_challenge() supplies it later.  Late (small) rounds only.
+static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool publish_to_host, bool deferred = false) {
     // validation, same precedence as the reference's panics (prover.rs:78-98)
     if (p->exhausted) return fail(SC_ERR_NOT_ACTIVE, "Prover is not active");
+    if (p->deferred_pending) return fail(SC_ERR_BAD_ARG, "a pipelined round is waiting for its challenge");
     if (r_or_null && p->round == 0) return fail(SC_ERR_FIRST_ROUND_HAS_MSG, "first round should be prover first.");
-    if (!r_or_null && p->round > 0) return fail(SC_ERR_MISSING_MSG, "verifier message is empty");
+    if (!r_or_null && p->round > 0 && !deferred) return fail(SC_ERR_MISSING_MSG, "verifier message is empty");
     if (p->round + 1 > p->nv) return fail(SC_ERR_NOT_ACTIVE, "Prover is not active");
     sch::Fr r = sch::zero();
     if (r_or_null) {
@@ -483,12 +574,12 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         if (sch::geq_p(r)) return fail(SC_ERR_BAD_ARG, "challenge is not a canonical field element");
     }
     HIP_TRY(hipSetDevice(p->device));
-    {
+    if (!deferred) { // (a pipelined round records no events: collecting would wait for the round before it)
         int rc_t = collect_timing(p);
         if (rc_t) return rc_t;
     }
-    bool bind = r_or_null != nullptr;
-    if (bind) p->randomness.push_back(r);
+    bool bind = r_or_null != nullptr || deferred;
+    if (r_or_null) p->randomness.push_back(r);
     p->round += 1;
     const uint64_t n_pairs = 1ULL << (p->nv - p->round);
     const FrHost rdev = to_dev(r);
@@ -496,10 +587,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     for (int d = 0; d < 5; ++d) r32v = sch::add(r32v, r32v);
     const FrHost r32 = to_dev(r32v);
     int scaled = 0;
-    static const uint64_t small_pairs = [] { // SC_SMALL_LOG2: experiment knob for the big/small round boundary
-        const char *e = std::getenv("SC_SMALL_LOG2");
-        return e ? (1ULL << std::atoi(e)) : scd::kSmallRoundPairs;
-    }();
+    const uint64_t small_pairs = small_pairs_limit();
     const bool small_round = n_pairs <= small_pairs && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0;
     const bool tiled = !small_round && !p->any_generic && p->kernel_variant == 2;
     scd::BindConst rc; // (only the big rounds of the tree kernels pay for it)
@@ -526,7 +614,17 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         }
     }
     int grid = tiled ? scd::grid_for_tiles(n_pairs) : scd::grid_for_pairs(n_pairs);
-    if (p->timing) HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    const bool timed = p->timing && !deferred;
+    if (timed) HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    const FrHost *r_mail = nullptr;
+    if (deferred) {
+        if (!small_round) return fail(SC_ERR_BAD_ARG, "only late rounds are pipelined");
+        p->sig_seq += 1;
+        if (p->sigmem) HIP_TRY(hipStreamWaitValue32(p->stream, p->sigmem, p->sig_seq, hipStreamWaitValueEq, 0xffffffffu));
+        HIP_TRY(scd::launch_wait_challenge(p->sig_dev, p->sig_seq, p->h_mail_dev + (p->sig_seq & 1u), p->d_mail + (p->sig_seq & 1u), p->stream));
+        r_mail = p->d_mail + (p->sig_seq & 1u);
+        p->deferred_pending = true;
+    }
 
     auto bind_table = [&](uint32_t u) -> hipError_t { // stand-alone bind of table u (2*n_pairs outputs)
         Table &t = p->tabs[u];
@@ -549,7 +647,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
                 tp.src_top[u] = t.cur_top;
                 tp.dst[u] = t.buf[t.next];
             }
-            HIP_TRY(scd::launch_fix_multi(tp, (int)p->U, rdev, 2 * n_pairs, p->stream));
+            HIP_TRY(scd::launch_fix_multi(tp, (int)p->U, rdev, r_mail, 2 * n_pairs, p->stream));
             for (uint32_t u = 0; u < p->U; ++u) {
                 Table &t = p->tabs[u];
                 t.cur = t.buf[t.next];
@@ -724,27 +822,29 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     HIP_TRY(scd::launch_finalize(p->d_finprods, p->d_W, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide,
                                  publish_to_host ? p->h_out_dev : nullptr, publish_to_host ? p->h_flag_dev : nullptr, p->seq, scaled,
                                  p->stream));
-    if (p->timing) HIP_TRY(hipEventRecord(p->ev1, p->stream));
-    p->timed = p->timing;
-    p->timing_pending = p->timing;
-    p->prod_timed = p->timing && !small;
-    p->prod_merged = merged;
+    if (timed) HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    if (!deferred) { // (a pipelined round leaves the previous round's pending event pairs to the next collect_timing)
+        p->timed = timed;
+        p->timing_pending = timed;
+        p->prod_timed = timed && !small;
+        p->prod_merged = merged;
+    }
     return SC_OK;
 }
 
-static int await_round(sc_prover *p, uint64_t *out_evals);
+static int await_round(sc_prover *p, uint64_t *out_evals, uint32_t want);
 
 extern "C" int sc_prove_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals) {
     if (!p || !out_evals) return fail(SC_ERR_BAD_ARG, "null argument");
     int rc = launch_round(p, r_or_null, nullptr, true);
     if (rc) return rc;
-    return await_round(p, out_evals);
+    return await_round(p, out_evals, p->seq);
 }
 
-static int await_round(sc_prover *p, uint64_t *out_evals) {
+// want: the sequence number the awaited round's finalize publishes (p->seq right after that round was launched)
+static int await_round(sc_prover *p, uint64_t *out_evals, const uint32_t want) {
     // The message is written by k_finalize straight into host-mapped pinned memory, followed by a system-scope release of
     // the sequence flag: poll it instead of paying a DMA copy plus an interrupt-driven stream synchronise every round.
-    const uint32_t want = p->seq;
     uint64_t spins = 0;
     bool seen = false;
     const auto t_start = std::chrono::steady_clock::now();
@@ -754,10 +854,62 @@ static int await_round(sc_prover *p, uint64_t *out_evals) {
         }
     }
     if (!seen) {
+        if (p->deferred_pending) { // the stream cannot be synchronised while the next round waits for its challenge
+            abandon_deferred(p);
+            return fail(SC_ERR_HIP, "round did not publish its message within 2 s");
+        }
         HIP_TRY(hipStreamSynchronize(p->stream));
         if (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) != want) return fail(SC_ERR_HIP, "round finished without publishing its message");
     }
     std::memcpy(out_evals, p->h_out, (size_t)p->D * 32);
+    return SC_OK;
+}
+
+// Rounds first..last-1 (0-based) of the reference's prove loop (mod.rs:57-64): prove_round, feed, sample.  Late rounds are
+// pipelined: while round i runs, round i+1 is already enqueued behind the wait, so hashing round i's message and storing the
+// challenge is all that separates the two on the critical path.  vm/have carry the pending challenge in and out.
+static int run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_t *out_msgs, sch::Fr *out_challenges_or_null,
+                      double *t_launch, double *t_wait, double *t_fs) {
+    using clk = std::chrono::steady_clock;
+    const uint32_t D = p->D;
+    sch::Fr vm = sch::zero();
+    bool have = false, enqueued = false;
+    uint32_t want = 0;
+    for (uint32_t i = 0; i < n_rounds; ++i) {
+        uint64_t *pm = out_msgs + (size_t)i * D * 4;
+        const auto t0 = clk::now();
+        int rc;
+        if (!enqueued) {
+            rc = launch_round(p, have ? vm.l : nullptr, nullptr, true);
+            if (rc) return rc;
+            want = p->seq;
+        }
+        uint32_t want_next = 0;
+        bool next_enqueued = false;
+        if (i + 1 < n_rounds && can_defer_next(p)) { // round i+1 goes in now, behind the wait
+            rc = launch_round(p, nullptr, nullptr, true, true);
+            if (rc) return rc;
+            want_next = p->seq;
+            next_enqueued = true;
+        }
+        const auto t1 = clk::now();
+        rc = await_round(p, pm, want);
+        if (rc) return rc;
+        const auto t2 = clk::now();
+        rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(pm), D); // mod.rs:61
+        vm = rng.sample_fr();                                           // mod.rs:63
+        have = true;
+        if (out_challenges_or_null) out_challenges_or_null[i] = vm;
+        if (next_enqueued) provide_challenge(p, vm);
+        enqueued = next_enqueued;
+        want = want_next;
+        if (t_launch) {
+            const auto t3 = clk::now();
+            *t_launch += std::chrono::duration<double, std::micro>(t1 - t0).count();
+            *t_wait += std::chrono::duration<double, std::micro>(t2 - t1).count();
+            *t_fs += std::chrono::duration<double, std::micro>(t3 - t2).count();
+        }
+    }
     return SC_OK;
 }
 
@@ -858,6 +1010,7 @@ extern "C" int sc_prover_get_timing(sc_prover *p, double *ms_per_product, uint64
 extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_null, uint32_t flags) {
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
     HIP_TRY(hipSetDevice(p->device));
+    abandon_deferred(p);
     {
         int rc_t = collect_timing(p);
         if (rc_t) return rc_t;
@@ -1110,37 +1263,30 @@ extern "C" int sc_poly_evaluate(const sc_poly_desc *d, const uint64_t *point, ui
 // MLSumcheck::prove_as_subprotocol (reference src/ml_sumcheck/mod.rs:50-70)
 // ---------------------------------------------------------------------------------------------------
 // The Fiat-Shamir loop of mod.rs:54-67 on an existing handle at round 0 (fresh from sc_prover_init or sc_prover_reset).
+// gkr.hip: one sumcheck phase's rounds through the same (pipelined) loop
+int sc_internal_run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_t *out_msgs, sch::Fr *out_challenges) {
+    double a = 0, b = 0, c = 0;
+    int rc = run_rounds(p, rng, n_rounds, out_msgs, out_challenges, nullptr, &b, &c);
+    (void)a;
+    if (rc) abandon_deferred(p);
+    return rc;
+}
+
 extern "C" int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *out_proof) {
     if (!p || !out_proof) return fail(SC_ERR_BAD_ARG, "null argument");
     if (p->round != 0) return fail(SC_ERR_BAD_ARG, "handle is not at round 0");
     sc_rng local;
     sch::Blake2b512Rng &rng = rng_or_null ? rng_or_null->rng : local.rng;
     rng.feed_poly_info(p->max_mult, p->nv); // mod.rs:54
-    const uint32_t D = p->D;
-    sch::Fr vm = sch::zero();
-    bool have = false;
     static const bool trace = std::getenv("SC_HOST_TRACE") != nullptr; // stderr: where the host's share of a proof goes
-    using clk = std::chrono::steady_clock;
     double t_launch = 0, t_wait = 0, t_fs = 0;
-    for (uint32_t i = 0; i < p->nv; ++i) {
-        uint64_t *pm = out_proof + (size_t)i * D * 4;
-        const auto t0 = clk::now();
-        int rc = launch_round(p, have ? vm.l : nullptr, nullptr, true);
-        if (rc) return rc;
-        const auto t1 = clk::now();
-        rc = await_round(p, pm);
-        if (rc) return rc;
-        const auto t2 = clk::now();
-        rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(pm), D); // mod.rs:61
-        vm = rng.sample_fr();                                           // mod.rs:63
-        have = true;
-        if (trace) {
-            const auto t3 = clk::now();
-            t_launch += std::chrono::duration<double, std::micro>(t1 - t0).count();
-            t_wait += std::chrono::duration<double, std::micro>(t2 - t1).count();
-            t_fs += std::chrono::duration<double, std::micro>(t3 - t2).count();
-        }
+    std::vector<sch::Fr> ch(p->nv);
+    int rc = run_rounds(p, rng, p->nv, out_proof, ch.data(), trace ? &t_launch : nullptr, &t_wait, &t_fs);
+    if (rc) {
+        abandon_deferred(p);
+        return rc;
     }
+    const sch::Fr vm = p->nv ? ch[p->nv - 1] : sch::zero();
     if (trace) std::fprintf(stderr, "[sc] proof host time: launch %.1f us, wait %.1f us, transcript %.1f us (%u rounds)\n", t_launch, t_wait, t_fs, p->nv);
     p->randomness.push_back(vm); // mod.rs:65-67: recorded, never bound
     return SC_OK;

@@ -37,6 +37,7 @@ using scd::kBlock;
 
 int sc_internal_fail(int code, const char *fmt, ...); // api.hip
 int sc_internal_device();                             // api.hip: the calling thread's device (sc_set_device)
+int sc_internal_run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_t *out_msgs, sch::Fr *out_challenges); // api.hip
 struct sc_rng {
     sch::Blake2b512Rng rng;
 };
@@ -531,18 +532,7 @@ static int run_phase(sch::Blake2b512Rng &rng, sc_prover **handle, const Fr *dA, 
         rc = sc_prover_reset(*handle, tabs, SC_TABLES_ON_DEVICE);
     }
     if (rc) return rc;
-    sch::Fr vm = sch::zero();
-    bool have = false;
-    for (uint32_t i = 0; i < dim; ++i) {
-        uint64_t *pm = out_msgs + (size_t)i * 12;
-        rc = sc_prove_round(*handle, have ? vm.l : nullptr, pm);
-        if (rc) return rc;
-        rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(pm), 3);
-        vm = rng.sample_fr();
-        have = true;
-        challenges[i] = vm;
-    }
-    return SC_OK;
+    return sc_internal_run_rounds(*handle, rng, dim, out_msgs, challenges); // prove_round / feed / sample x dim (late rounds pipelined)
 }
 
 namespace {

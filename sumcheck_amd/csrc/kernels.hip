@@ -627,8 +627,32 @@ __global__ __launch_bounds__(kBlock) void k_scale(const uint4 *__restrict__ src,
 // one launch binds every table (one product deep), one launch computes every (product, point) combination with
 // one lane per (combination, pair) (M-1 products deep).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_fix_multi(const TablePtrs tp, const FrHost r_h, const uint64_t n_out) {
-    const FrU r = fru_from_host(r_h);
+// Pipelined rounds: holds the stream until the host has published challenge number `want` (a system-scope word in host-mapped
+// memory), then copies the challenge from the host-mapped mailbox into device memory, so that the round's kernels behind it
+// read it like any other device data (thousands of blocks fetching it over PCIe cost 30-100 us per round).  One wavefront,
+// lane 0 polls with s_sleep back-off; the spin is bounded (~2^22 polls, seconds) so a host that never answers cannot hang the
+// queue -- the kernels behind it then run on a stale challenge and the host discards their result.
+__global__ void k_wait_challenge(const uint32_t *__restrict__ flag, const uint32_t want, const uint64_t *__restrict__ mail_host,
+                                 uint64_t *__restrict__ mail_dev) {
+    if (threadIdx.x == 0) {
+        for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+            if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == want) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) mail_dev[threadIdx.x] = __hip_atomic_load(mail_host + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_wait_challenge(const uint32_t *flag_dev, uint32_t want, const FrHost *mail_host_dev, FrHost *mail_dev, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wait_challenge, dim3(1), dim3(64), 0, stream, flag_dev, want, reinterpret_cast<const uint64_t *>(mail_host_dev),
+                       reinterpret_cast<uint64_t *>(mail_dev));
+    return hipGetLastError();
+}
+
+// r_mail != nullptr: the launch was enqueued before the challenge existed (pipelined rounds, api.hip); the challenge is read from
+// the device-memory mailbox that k_wait_challenge, the kernel in front of this one, filled
+__global__ __launch_bounds__(kBlock) void k_fix_multi(const TablePtrs tp, const FrHost r_h, const FrHost *__restrict__ r_mail, const uint64_t n_out) {
+    const FrU r = fru_from_host(r_mail ? *r_mail : r_h); // uniform: scalar loads either way
     const uint4 *__restrict__ src = tp.src[blockIdx.y];
     uint4 *__restrict__ dst = tp.dst[blockIdx.y];
     const int32_t *__restrict__ stop = tp.src_top[blockIdx.y];
@@ -1050,8 +1074,8 @@ hipError_t launch_finalize(const FinProd *d_prods, const FrHost *d_W, int K, int
     return hipGetLastError();
 }
 
-hipError_t launch_fix_multi(const TablePtrs &tp, int n_tables, const FrHost &r, uint64_t n_out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_fix_multi, dim3(grid_for_pairs(n_out), n_tables), dim3(kBlock), 0, stream, tp, r, n_out);
+hipError_t launch_fix_multi(const TablePtrs &tp, int n_tables, const FrHost &r, const FrHost *r_mail, uint64_t n_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fix_multi, dim3(grid_for_pairs(n_out), n_tables), dim3(kBlock), 0, stream, tp, r, r_mail, n_out);
     return hipGetLastError();
 }
 
