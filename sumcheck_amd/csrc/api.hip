@@ -1462,15 +1462,33 @@ extern "C" int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *r
     }
     rng->rng.feed_poly_info(p->max_mult, nv_total); // mod.rs:54: the GLOBAL instance's info
     sch::Fr vm = sch::zero();
-    bool have = false;
+    bool have = false, enqueued = false;
+    uint32_t want = 0;
     std::vector<uint64_t> evals((size_t)p->D * 4);
-    for (uint32_t i = 0; i < n_rounds; ++i) {
-        int rc = launch_round(p, have ? vm.l : nullptr, p->d_wide, false);
+    // one round on the stream: local kernels -> d_wide, integer all-reduce in place, publish to the host-mapped page.  With
+    // deferred = true the whole sequence sits behind the wait kernel (pipelined late rounds, see run_rounds): every rank's host
+    // derives the same challenge at about the same time, so the ranks' all-reduces still meet.
+    auto enqueue = [&](const uint64_t *r, bool deferred, uint32_t *want_out) -> int {
+        int rc = launch_round(p, r, p->d_wide, false, deferred);
         if (rc) return rc;
         NCCL_TRY(g_nccl.AllReduce(p->d_wide, p->d_wide, (size_t)n_words, ncclUint64, ncclSum, comm->comm, p->stream));
         p->seq += 1;
-        const uint32_t want = p->seq;
-        HIP_TRY(scd::launch_publish_words(p->d_wide, p->h_wide_dev, n_words, p->h_flag_dev, want, p->stream));
+        *want_out = p->seq;
+        HIP_TRY(scd::launch_publish_words(p->d_wide, p->h_wide_dev, n_words, p->h_flag_dev, *want_out, p->stream));
+        return SC_OK;
+    };
+    for (uint32_t i = 0; i < n_rounds; ++i) {
+        int rc;
+        if (!enqueued && (rc = enqueue(have ? vm.l : nullptr, false, &want))) return rc;
+        uint32_t want_next = 0;
+        bool next_enqueued = false;
+        if (i + 1 < n_rounds && can_defer_next(p)) {
+            if ((rc = enqueue(nullptr, true, &want_next))) {
+                abandon_deferred(p);
+                return rc;
+            }
+            next_enqueued = true;
+        }
         uint64_t spins = 0;
         bool seen = false;
         const auto t_start = std::chrono::steady_clock::now();
@@ -1478,16 +1496,26 @@ extern "C" int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *r
             if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) break;
         }
         if (!seen) {
+            if (p->deferred_pending) {
+                abandon_deferred(p);
+                return fail(SC_ERR_HIP, "sharded round did not publish within 20 s");
+            }
             HIP_TRY(hipStreamSynchronize(p->stream));
             if (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) != want) return fail(SC_ERR_HIP, "sharded round finished without publishing");
         }
         rc = sc_wide_reduce(p->h_wide, p->D, evals.data());
-        if (rc) return rc;
+        if (rc) {
+            abandon_deferred(p);
+            return rc;
+        }
         std::memcpy(out_proof + (size_t)i * p->D * 4, evals.data(), (size_t)p->D * 32);
         rng->rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(evals.data()), p->D); // mod.rs:61
         vm = rng->rng.sample_fr();                                                          // mod.rs:63
         have = true;
         std::memcpy(out_randomness + (size_t)i * 4, vm.l, 32);
+        if (next_enqueued) provide_challenge(p, vm);
+        enqueued = next_enqueued;
+        want = want_next;
     }
     return SC_OK;
 }
