@@ -504,18 +504,13 @@ static bool can_defer_next(sc_prover *p) {
     const uint64_t n_pairs_next = 1ULL << (p->nv - (p->round + 1));
     if (!(n_pairs_next <= small_pairs_limit() && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0)) return false;
     if (!p->sig) { // first use: signal word + mailbox; any failure switches pipelining off for this handle
-        static const bool env_off = [] {
-            const char *e = std::getenv("SC_PIPELINE");
-            return e && std::atoi(e) == 0;
-        }();
+        const char *env = std::getenv("SC_PIPELINE"); // read per handle, at its first late round
+        const bool env_off = env && std::atoi(env) == 0;
         bool ok = !env_off && hipSetDevice(p->device) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->h_mail), 2 * sizeof(FrHost) + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
         ok = ok && hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_mail_dev), p->h_mail, 0) == hipSuccess;
         ok = ok && hipMalloc(reinterpret_cast<void **>(&p->d_mail), 2 * sizeof(FrHost)) == hipSuccess;
-        static const bool cp_wait = [] {
-            const char *e = std::getenv("SC_PIPELINE");
-            return e && std::atoi(e) == 2;
-        }();
+        const bool cp_wait = env && std::atoi(env) == 2;
         if (ok && cp_wait) {
             ok = hipExtMallocWithFlags(reinterpret_cast<void **>(&p->sigmem), 8, hipMallocSignalMemory) == hipSuccess;
             if (ok) *reinterpret_cast<volatile uint64_t *>(p->sigmem) = 0;

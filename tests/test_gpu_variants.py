@@ -18,6 +18,8 @@ pytestmark = pytest.mark.gpu
     {"SC_KERNEL": "3", "SC_ROTATE": "0"},  # ... every block walks the products in the same order
     {"SC_KERNEL": "3", "SC_ROTATE": "2"},  # ... rotated per block
     {"SC_KERNEL": "3", "SC_MERGE": "0"},  # one launch per product
+    {"SC_PIPELINE": "0"},                 # late rounds launched after their challenge (no wait kernel)
+    {"SC_PIPELINE": "2"},                 # late rounds behind a command-processor wait + copy kernel
     {"SC_KERNEL": "3", "SC_F29": "0"},   # product tree, canonical tables
     {"SC_KERNEL": "0", "SC_FE": "1"},    # node-by-node, carry-free arithmetic
     {"SC_KERNEL": "0", "SC_FE": "0"},    # node-by-node, saturated Comba (inline asm)
@@ -29,7 +31,7 @@ pytestmark = pytest.mark.gpu
     (18, 6, [[0, 1, 2, 3, 4], [5, 5], [2]]),                # five multiplicands: outside the tree, no F29
 ])
 def test_variant_matches_oracle(env, nv, nt, shapes, monkeypatch):
-    for k in ("SC_KERNEL", "SC_F29", "SC_FE", "SC_MERGE", "SC_ROTATE"):
+    for k in ("SC_KERNEL", "SC_F29", "SC_FE", "SC_MERGE", "SC_ROTATE", "SC_PIPELINE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
