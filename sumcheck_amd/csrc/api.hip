@@ -519,6 +519,7 @@ static bool can_defer_next(sc_prover *p) {
             p->sig = reinterpret_cast<uint32_t *>(p->h_mail + 2);
             p->sig_dev = reinterpret_cast<uint32_t *>(p->h_mail_dev + 2);
             __atomic_store_n(p->sig, 0u, __ATOMIC_RELEASE);
+            __atomic_store_n(p->sig + 1, 0u, __ATOMIC_RELEASE); // give-up marker of the wait kernel
             p->sig_seq = 0;
         } else {
             (void)hipGetLastError();
@@ -543,6 +544,8 @@ static void provide_challenge(sc_prover *p, const sch::Fr &r) {
     if (p->sigmem) __atomic_store_n(p->sigmem, p->sig_seq, __ATOMIC_RELEASE);
     p->deferred_pending = false;
 }
+// the give-up marker of k_wait_challenge (non-zero once any wait of this handle has expired; cleared by sc_prover_reset)
+static bool wait_gave_up(sc_prover *p) { return p->sig && __atomic_load_n(p->sig + 1, __ATOMIC_ACQUIRE) != 0; }
 // error path: let a stream that is blocked on the wait drain (the round then runs on a stale challenge; its result is discarded)
 static void abandon_deferred(sc_prover *p) {
     if (p->deferred_pending) {
@@ -856,6 +859,11 @@ static int await_round(sc_prover *p, uint64_t *out_evals, const uint32_t want) {
         HIP_TRY(hipStreamSynchronize(p->stream));
         if (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) != want) return fail(SC_ERR_HIP, "round finished without publishing its message");
     }
+    if (wait_gave_up(p)) { // a wait kernel's bound expired before its challenge arrived: that round ran on a stale one
+        abandon_deferred(p);
+        p->exhausted = true;
+        return fail(SC_ERR_HIP, "the host took longer than the wait kernel's bound to deliver a challenge; the proof is void");
+    }
     std::memcpy(out_evals, p->h_out, (size_t)p->D * 32);
     return SC_OK;
 }
@@ -1006,6 +1014,10 @@ extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_nu
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
     HIP_TRY(hipSetDevice(p->device));
     abandon_deferred(p);
+    if (wait_gave_up(p)) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        __atomic_store_n(p->sig + 1, 0u, __ATOMIC_RELEASE);
+    }
     {
         int rc_t = collect_timing(p);
         if (rc_t) return rc_t;
@@ -1497,6 +1509,11 @@ extern "C" int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *r
             }
             HIP_TRY(hipStreamSynchronize(p->stream));
             if (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) != want) return fail(SC_ERR_HIP, "sharded round finished without publishing");
+        }
+        if (wait_gave_up(p)) {
+            abandon_deferred(p);
+            p->exhausted = true;
+            return fail(SC_ERR_HIP, "the host took longer than the wait kernel's bound to deliver a challenge; the proof is void");
         }
         rc = sc_wide_reduce(p->h_wide, p->D, evals.data());
         if (rc) {

@@ -132,9 +132,9 @@ hipError_t launch_sum_generic(const uint4 *const *d_cur_tables, const uint32_t *
 // out[b] = in[2b] + r*(in[2b+1]-in[2b]), b < n_out
 hipError_t launch_fix(const uint4 *src, uint4 *dst, const FrHost &r, uint64_t n_out, hipStream_t stream);
 // small rounds: bind every table in one launch (grid.y = table) ...
-// one-wave kernel that holds the stream until *flag_dev == want (host-mapped word; bounded spin), then copies the challenge from
-// the host-mapped mailbox to device memory
-hipError_t launch_wait_challenge(const uint32_t *flag_dev, uint32_t want, const FrHost *mail_host_dev, FrHost *mail_dev, hipStream_t stream);
+// one-wave kernel that holds the stream until flag_dev[0] == want (host-mapped word; bounded spin -- on giving up it stores want
+// to flag_dev[1]), then copies the challenge from the host-mapped mailbox to device memory
+hipError_t launch_wait_challenge(uint32_t *flag_dev, uint32_t want, const FrHost *mail_host_dev, FrHost *mail_dev, hipStream_t stream);
 // r_mail (device-visible, may be host-mapped) overrides r when non-null: the challenge is fetched at run time
 hipError_t launch_fix_multi(const TablePtrs &tp, int n_tables, const FrHost &r, const FrHost *r_mail, uint64_t n_out, hipStream_t stream);
 // ... and one launch for every (product, evaluation point) combination (grid.y = combination), one lane per pair

@@ -631,20 +631,27 @@ __global__ __launch_bounds__(kBlock) void k_scale(const uint4 *__restrict__ src,
 // memory), then copies the challenge from the host-mapped mailbox into device memory, so that the round's kernels behind it
 // read it like any other device data (thousands of blocks fetching it over PCIe cost 30-100 us per round).  One wavefront,
 // lane 0 polls with s_sleep back-off; the spin is bounded (~2^22 polls, seconds) so a host that never answers cannot hang the
-// queue -- the kernels behind it then run on a stale challenge and the host discards their result.
-__global__ void k_wait_challenge(const uint32_t *__restrict__ flag, const uint32_t want, const uint64_t *__restrict__ mail_host,
-                                 uint64_t *__restrict__ mail_dev) {
+// queue -- the kernels behind it then run on a stale challenge, and the give-up marker makes the host discard their result.
+__global__ void k_wait_challenge(uint32_t *__restrict__ flag, const uint32_t want, const uint32_t max_spins,
+                                 const uint64_t *__restrict__ mail_host, uint64_t *__restrict__ mail_dev) {
     if (threadIdx.x == 0) {
-        for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
-            if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == want) break;
-            __builtin_amdgcn_s_sleep(8);
+        bool seen = false;
+        for (uint32_t spin = 0; spin < max_spins && !seen; ++spin) {
+            seen = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == want;
+            if (!seen) __builtin_amdgcn_s_sleep(8);
         }
+        // gave up: tell the host (flag[1]) so that it rejects whatever the kernels behind this one publish
+        if (!seen) __hip_atomic_store(flag + 1, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
     if (threadIdx.x < 4) mail_dev[threadIdx.x] = __hip_atomic_load(mail_host + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-hipError_t launch_wait_challenge(const uint32_t *flag_dev, uint32_t want, const FrHost *mail_host_dev, FrHost *mail_dev, hipStream_t stream) {
-    hipLaunchKernelGGL(k_wait_challenge, dim3(1), dim3(64), 0, stream, flag_dev, want, reinterpret_cast<const uint64_t *>(mail_host_dev),
+hipError_t launch_wait_challenge(uint32_t *flag_dev, uint32_t want, const FrHost *mail_host_dev, FrHost *mail_dev, hipStream_t stream) {
+    static const uint32_t max_spins = [] { // SC_WAIT_SPINS: tests shorten the bound to exercise the give-up path
+        const char *e = std::getenv("SC_WAIT_SPINS");
+        return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (1u << 22);
+    }();
+    hipLaunchKernelGGL(k_wait_challenge, dim3(1), dim3(64), 0, stream, flag_dev, want, max_spins, reinterpret_cast<const uint64_t *>(mail_host_dev),
                        reinterpret_cast<uint64_t *>(mail_dev));
     return hipGetLastError();
 }

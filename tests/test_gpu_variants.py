@@ -69,3 +69,30 @@ def test_more_products_than_one_launch_takes():
     proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly)
     assert np.array_equal(np.stack([m.evaluations for m in proof]), want)
     assert np.array_equal(state.randomness, wrand)
+
+
+def test_wait_kernel_give_up_is_detected():
+    """Pipelined late rounds: if the host does not deliver a challenge within the wait kernel's bound, the round behind it runs on
+    a stale challenge.  The library must notice (give-up marker) and void the proof instead of returning wrong messages.  A
+    subprocess shortens the bound to one poll (SC_WAIT_SPINS is read once per process)."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sumcheck_amd as sc
+from oracle import cref
+from tests import helpers as H
+nv, shapes = 12, [[0, 1, 2], [1]]
+tabs = [cref.synth_table(7, s, 1 << nv) for s in range(3)]
+coefs = cref.synth_table(7, 1000, len(shapes))
+poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs)
+try:
+    sc.MLSumcheck.prove(poly)
+    print("NO-ERROR")
+except sc.SumcheckError as e:
+    print("ERROR", e)
+'''
+    env = dict(os.environ, SC_WAIT_SPINS="1", SC_PIPELINE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ERROR" in r.stdout and "proof is void" in r.stdout, r.stdout + r.stderr[-500:]
