@@ -137,7 +137,11 @@ SC_API void sc_rng_sample_fr(sc_rng *rng, uint64_t *out);                       
 
 /* ---- MLSumcheck::prove / prove_as_subprotocol (reference src/ml_sumcheck/mod.rs:42-70) ------- */
 /* rng_or_null: NULL = fresh Blake2b512Rng::setup() (MLSumcheck::prove).  out_proof: num_vars x (deg+1) x 4.
- * out_state_or_null: receives the ProverState handle (caller frees) as prove_as_subprotocol returns it. */
+ * out_state_or_null: receives the ProverState handle (caller frees) as prove_as_subprotocol returns it.
+ * The latency-bound late rounds are pipelined: the next round is enqueued behind a wait kernel before the current
+ * round's message is hashed.  The wait is bounded (seconds); if the calling thread is stalled for longer, the call
+ * returns SC_ERR_HIP ("... the proof is void") rather than messages computed on a stale challenge -- reset the
+ * handle and prove again.  SC_PIPELINE=0 in the environment turns the pipelining off. */
 SC_API int sc_ml_prove(const sc_poly_desc *desc, sc_rng *rng_or_null, uint64_t *out_proof, sc_prover **out_state_or_null);
 /* the same loop on an existing handle at round 0 (sc_prover_init / sc_prover_reset): no allocation per proof */
 SC_API int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *out_proof);
