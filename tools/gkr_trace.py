@@ -1,4 +1,5 @@
-import sys,os; sys.path.insert(0,'/root/repo')
+"""SC_GKR_TRACE=1 python tools/gkr_trace.py: stage times of one config-5 GKR proof (dim 20) on stderr."""
+import sys,os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, sumcheck_amd as sc
 from oracle import cref
 dim=20; n=1<<dim; rng=np.random.default_rng(1)
