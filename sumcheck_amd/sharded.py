@@ -281,7 +281,15 @@ def prove_sharded_native(engine: HipShardEngine, ncomm: NativeComm, comm: DistCo
     rand = np.empty((nv_total, 4), dtype=np.uint64)
     lp = np.empty((nv_local, D, 4), dtype=np.uint64)
     lr = np.empty((nv_local, 4), dtype=np.uint64)
-    check(lib().sc_ml_prove_sharded_rounds(engine._h, ncomm._h, rng._h, nv_total, nv_local, C.c_void_p(lp.ctypes.data), C.c_void_p(lr.ctypes.data)))
+    # The library loop runs on the handle's own non-blocking stream: its pipelined late rounds park a polling wait kernel on the
+    # stream, which must not be torch's (possibly legacy-default, implicitly synchronising) stream.  Both switches synchronise.
+    torch.cuda.current_stream(engine.device).synchronize()
+    check(lib().sc_prover_set_stream(engine._h, None, 1))
+    try:
+        check(lib().sc_ml_prove_sharded_rounds(engine._h, ncomm._h, rng._h, nv_total, nv_local, C.c_void_p(lp.ctypes.data),
+                                               C.c_void_p(lr.ctypes.data)))
+    finally:
+        check(lib().sc_prover_set_stream(engine._h, C.c_void_p(torch.cuda.current_stream(engine.device).cuda_stream), 0))
     proof[:nv_local] = lp
     rand[:nv_local] = lr
     if k > 0:
