@@ -151,6 +151,9 @@ struct sc_prover {
     uint64_t *h_wide = nullptr;      // ... and its host-mapped landing page
     uint64_t *h_wide_dev = nullptr;
     Combo *d_combos = nullptr;    // (product, point) combinations for the small-round kernel
+    std::vector<FinProd> h_finprods; // host copy of d_finprods (kernel-argument path of k_finalize)
+    scd::ComboMeta meta;          // the same metadata as a kernel argument (when it fits: has_meta)
+    bool has_meta = false;
     int n_combos = 0;
     bool any_generic = false;
     const uint4 **d_cur_tables = nullptr;
@@ -401,6 +404,7 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     HIP_TRY(hipMalloc(&p->d_partials, std::max<uint64_t>(partial_elems, 1) * 32));
     HIP_TRY(hipMalloc(&p->d_finprods, std::max<size_t>(p->K, 1) * sizeof(FinProd)));
     if (p->K) HIP_TRY(hipMemcpyAsync(p->d_finprods, fin.data(), p->K * sizeof(FinProd), hipMemcpyHostToDevice, p->stream));
+    p->h_finprods = fin;
     HIP_TRY(hipMalloc(&p->d_W, std::max<size_t>(Wall.size(), 1) * 32));
     if (!Wall.empty()) HIP_TRY(hipMemcpyAsync(p->d_W, Wall.data(), Wall.size() * 32, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMalloc(&p->d_scratch, (size_t)(2 + p->D) * std::max<uint32_t>(p->K, 1) * p->D * 32));
@@ -410,6 +414,13 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     *p->h_flag = 0;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_out_dev), p->h_out, 0));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_flag_dev), p->h_flag, 0));
+    p->has_meta = combos.size() <= (size_t)scd::kMetaCombos && slot_table.size() <= (size_t)scd::kMetaSlots;
+    if (p->has_meta) {
+        std::memset(&p->meta, 0, sizeof(p->meta));
+        std::copy(combos.begin(), combos.end(), p->meta.combo);
+        std::copy(slot_table.begin(), slot_table.end(), p->meta.slot_table);
+        std::copy(slot_exp.begin(), slot_exp.end(), p->meta.slot_exp);
+    }
     p->n_combos = (int)combos.size();
     HIP_TRY(hipMalloc(&p->d_combos, std::max<size_t>(combos.size(), 1) * sizeof(Combo)));
     if (!combos.empty()) HIP_TRY(hipMemcpyAsync(p->d_combos, combos.data(), combos.size() * sizeof(Combo), hipMemcpyHostToDevice, p->stream));
@@ -654,7 +665,8 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
             }
         }
         for (uint32_t u = 0; u < p->U; ++u) tp.src[u] = p->tabs[u].cur;
-        HIP_TRY(scd::launch_sum_combos(tp, p->d_combos, p->n_combos, p->d_slot_table, p->d_slot_exp, n_pairs, p->d_partials, grid, p->stream));
+        if (p->has_meta) HIP_TRY(scd::launch_sum_combos_meta(tp, p->meta, p->n_combos, n_pairs, p->d_partials, grid, p->stream));
+        else HIP_TRY(scd::launch_sum_combos(tp, p->d_combos, p->n_combos, p->d_slot_table, p->d_slot_exp, n_pairs, p->d_partials, grid, p->stream));
         bind = false;
     }
     if (bind && p->any_generic) { // generic products read bound tables: bind everything up front
@@ -817,7 +829,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
             if (!bound[u]) HIP_TRY(bind_table(u));
     }
     p->seq += 1;
-    HIP_TRY(scd::launch_finalize(p->d_finprods, p->d_W, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide,
+    HIP_TRY(scd::launch_finalize(p->d_finprods, p->h_finprods.empty() ? nullptr : p->h_finprods.data(), p->d_W, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide,
                                  publish_to_host ? p->h_out_dev : nullptr, publish_to_host ? p->h_flag_dev : nullptr, p->seq, scaled,
                                  p->stream));
     if (timed) HIP_TRY(hipEventRecord(p->ev1, p->stream));

@@ -107,6 +107,18 @@ struct FoldArgs {
 // dst[y][i] = fold over `levels` variables of src[y][i << levels ...], i < n_out, y < n_tables (grid.y)
 hipError_t launch_fold_multi(const FoldArgs &args, int levels, int n_tables, uint64_t n_out, hipStream_t stream);
 
+constexpr int kMetaProds = 16;
+struct FinMeta {
+    FinProd prod[kMetaProds];
+};
+// the small-round sum kernel's metadata as a kernel argument when it fits (no dependent global loads before the table loads)
+constexpr int kMetaCombos = 24, kMetaSlots = 48;
+struct ComboMeta {
+    Combo combo[kMetaCombos];
+    uint32_t slot_table[kMetaSlots];
+    uint32_t slot_exp[kMetaSlots];
+};
+
 int grid_for_pairs(uint64_t n_pairs);
 
 // product k of one round: partials[t*grid+blk] = sum over this block's pairs of prod_j line_j(t), t = 0..M (node-major, so the
@@ -140,8 +152,12 @@ hipError_t launch_fix_multi(const TablePtrs &tp, int n_tables, const FrHost &r, 
 // ... and one launch for every (product, evaluation point) combination (grid.y = combination), one lane per pair
 hipError_t launch_sum_combos(const TablePtrs &tp, const Combo *d_combos, int n_combos, const uint32_t *d_slot_table,
                              const uint32_t *d_slot_exp, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
+// the same with the metadata passed by value (n_combos <= kMetaCombos, slot entries <= kMetaSlots)
+hipError_t launch_sum_combos_meta(const TablePtrs &tp, const ComboMeta &meta, int n_combos, uint64_t n_pairs, FrHost *d_partials, int grid,
+                                  hipStream_t stream);
 // combine per-block partials of all products into the round polynomial (D evaluations)
-hipError_t launch_finalize(const FinProd *d_prods, const FrHost *d_W, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
+// h_prods_or_null: host copy of the records; with at most kMetaProds products they travel as a kernel argument
+hipError_t launch_finalize(const FinProd *d_prods, const FinProd *h_prods_or_null, const FrHost *d_W, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
                            FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
                            int scaled, hipStream_t stream);
 hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);

@@ -33,6 +33,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace scd {
 
@@ -686,11 +687,10 @@ __global__ __launch_bounds__(kBlock) void k_f29_to_sat(const uint4 *__restrict__
         fr_store(dst + 2 * i, fe_to_fr(fe_load_f29(src, i, stop[i])));
 }
 
-__global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const Combo *__restrict__ combos,
-                                                       const uint32_t *__restrict__ slot_table, const uint32_t *__restrict__ slot_exp,
-                                                       const uint64_t n_pairs, uint4 *__restrict__ partials) {
-    __shared__ uint32_t sm[kBlock / 64][8];
-    const Combo c = combos[blockIdx.y];
+// one (product, node) combination over the block's pairs; the metadata comes from device memory or from a kernel argument
+template <typename SlotsT>
+__device__ __forceinline__ void sum_combo_body(const TablePtrs &tp, const Combo c, const SlotsT slot_table, const SlotsT slot_exp,
+                                               const uint64_t n_pairs, uint4 *__restrict__ partials, uint32_t (*sm)[8]) {
     const uint32_t t = c.t;
     const int32_t nv = node_value((int)t);
     const Fr tf = node_constant(nv);
@@ -706,7 +706,10 @@ __global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const
             else if (nv == 1) val = fr_load(p + 2);
             else {
                 const Fr lo = fr_load(p), hi = fr_load(p + 2);
-                val = (nv == kNodeInf) ? fr_sub(hi, lo) : fr_add(lo, fr_mul(fr_sub(hi, lo), tf));
+                if (nv == kNodeInf) val = fr_sub(hi, lo);
+                else if (nv == -1) val = fr_sub(fr_add(lo, lo), hi); // the line at -1 and at 2: two modular adds, no product
+                else if (nv == 2) val = fr_sub(fr_add(hi, hi), lo);
+                else val = fr_add(lo, fr_mul(fr_sub(hi, lo), tf));
             }
             uint32_t k = 0;
             if (first) { prod = val; k = 1; first = false; }
@@ -716,6 +719,18 @@ __global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const
     }
     const Fr s = block_sum(acc, sm);
     if (threadIdx.x == 0) fr_store(partials + 2 * (c.partial_off + (uint64_t)t * gridDim.x + blockIdx.x), s);
+}
+
+__global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const Combo *__restrict__ combos,
+                                                       const uint32_t *__restrict__ slot_table, const uint32_t *__restrict__ slot_exp,
+                                                       const uint64_t n_pairs, uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    sum_combo_body(tp, combos[blockIdx.y], slot_table, slot_exp, n_pairs, partials, sm);
+}
+__global__ __launch_bounds__(kBlock) void k_sum_combos_meta(const TablePtrs tp, const ComboMeta meta, const uint64_t n_pairs,
+                                                            uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    sum_combo_body(tp, meta.combo[blockIdx.y], meta.slot_table, meta.slot_exp, n_pairs, partials, sm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -728,8 +743,8 @@ __global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const
 // ------------------------------------------------------------------------------------------------
 constexpr int kFinBlock = 1024; // 16 wavefronts: one per (product, point) combination for typical shapes
 constexpr size_t kFinLdsMax = 48 * 1024;
-template <bool kLds>
-__global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restrict__ prods, const uint4 *__restrict__ Wm, const int K, const int D,
+template <bool kLds, bool kMeta>
+__global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restrict__ prods, const FinMeta meta, const uint4 *__restrict__ Wm, const int K, const int D,
                                                         const int nblocks, const uint4 *__restrict__ partials, uint4 *__restrict__ scratch,
                                                         uint4 *__restrict__ out, uint64_t *__restrict__ out_wide,
                                                         uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag, const uint32_t seq,
@@ -737,13 +752,18 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
     constexpr int kBlock = kFinBlock; // shadows the 256-thread constant inside this kernel
     extern __shared__ uint4 fin_lds[];
     if constexpr (kLds) scratch = fin_lds;
+    // the per-product records come from the kernel argument when they fit (kMeta): no global load in front of the partial loads
+    auto prod_of = [&](int k) -> FinProd {
+        if constexpr (kMeta) return meta.prod[k];
+        else return prods[k];
+    };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // phase 1: one wave per (product, node) combination, eight independent loads in flight per lane
     for (int combo = wave; combo < K * D; combo += kBlock / 64) {
         const int k = combo / D, t = combo % D;
-        const int M = (int)prods[k].M;
+        const int M = (int)prod_of(k).M;
         if (t > M) continue;
-        const uint4 *base = partials + 2 * prods[k].partial_off;
+        const uint4 *base = partials + 2 * prod_of(k).partial_off;
         Fr acc = fr_zero();
         for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {
             Fr x[8];
@@ -768,10 +788,10 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
     // Montgomery product (a lone lane needs ~1 us per product, so the M+1 products of a point must not be chained) ...
     for (int idx = threadIdx.x; idx < K * D * D; idx += kBlock) {
         const int k = idx / (D * D), t = (idx / D) % D, sN = idx % D;
-        const int M = (int)prods[k].M;
+        const int M = (int)prod_of(k).M;
         if (sN > M) continue;
         // partials from the 2^261-radix kernels carry 2^(-5(M-1)); the second copy of the matrix undoes it
-        const uint64_t woff = prods[k].w_off + ((scaled && M <= kMaxFusedM) ? (uint64_t)D * (M + 1) : 0);
+        const uint64_t woff = prod_of(k).w_off + ((scaled && M <= kMaxFusedM) ? (uint64_t)D * (M + 1) : 0);
         const uint4 *Wk = Wm + 2 * (woff + (uint64_t)t * (M + 1));
         fr_store(scratch + 2 * ((2 * K) * D + idx), fr_mul(fr_load(Wk + 2 * sN), fr_load(scratch + 2 * (k * D + sN))));
     }
@@ -779,7 +799,7 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
     // ... and one thread per (k, t) adds them up
     for (int combo = threadIdx.x; combo < K * D; combo += kBlock) {
         const int k = combo / D;
-        const int M = (int)prods[k].M;
+        const int M = (int)prod_of(k).M;
         Fr acc = fr_zero();
         for (int sN = 0; sN <= M; ++sN) acc = fr_add(acc, fr_load(scratch + 2 * ((2 * K) * D + combo * D + sN)));
         fr_store(scratch + 2 * ((K + k) * D + combo % D), acc);
@@ -1066,16 +1086,24 @@ hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t 
     return hipGetLastError();
 }
 
-hipError_t launch_finalize(const FinProd *d_prods, const FrHost *d_W, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
+hipError_t launch_finalize(const FinProd *d_prods, const FinProd *h_prods_or_null, const FrHost *d_W, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
                            FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
                            int scaled, hipStream_t stream) {
     const size_t lds = (size_t)K * D * (D + 2) * 32;
-    if (lds <= kFinLdsMax)
-        hipLaunchKernelGGL(k_finalize<true>, dim3(1), dim3(kFinBlock), lds, stream, d_prods, (const uint4 *)d_W, K, D, nblocks,
+    FinMeta meta;
+    std::memset(&meta, 0, sizeof(meta));
+    const bool use_meta = h_prods_or_null && K <= kMetaProds;
+    if (use_meta) std::memcpy(meta.prod, h_prods_or_null, (size_t)K * sizeof(FinProd));
+    if (lds <= kFinLdsMax && use_meta)
+        hipLaunchKernelGGL((k_finalize<true, true>), dim3(1), dim3(kFinBlock), lds, stream, d_prods, meta, (const uint4 *)d_W, K, D, nblocks,
+                           (const uint4 *)d_partials, (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq,
+                           scaled);
+    else if (lds <= kFinLdsMax)
+        hipLaunchKernelGGL((k_finalize<true, false>), dim3(1), dim3(kFinBlock), lds, stream, d_prods, meta, (const uint4 *)d_W, K, D, nblocks,
                            (const uint4 *)d_partials, (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq,
                            scaled);
     else
-        hipLaunchKernelGGL(k_finalize<false>, dim3(1), dim3(kFinBlock), 0, stream, d_prods, (const uint4 *)d_W, K, D, nblocks,
+        hipLaunchKernelGGL((k_finalize<false, false>), dim3(1), dim3(kFinBlock), 0, stream, d_prods, meta, (const uint4 *)d_W, K, D, nblocks,
                            (const uint4 *)d_partials, (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq,
                            scaled);
     return hipGetLastError();
@@ -1090,6 +1118,12 @@ hipError_t launch_sum_combos(const TablePtrs &tp, const Combo *d_combos, int n_c
                              const uint32_t *d_slot_exp, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_sum_combos, dim3(grid, n_combos), dim3(kBlock), 0, stream, tp, d_combos, d_slot_table, d_slot_exp, n_pairs,
                        (uint4 *)d_partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_combos_meta(const TablePtrs &tp, const ComboMeta &meta, int n_combos, uint64_t n_pairs, FrHost *d_partials, int grid,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(k_sum_combos_meta, dim3(grid, n_combos), dim3(kBlock), 0, stream, tp, meta, n_pairs, (uint4 *)d_partials);
     return hipGetLastError();
 }
 
