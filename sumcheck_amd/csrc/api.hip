@@ -516,7 +516,12 @@ static bool can_defer_next(sc_prover *p) {
     if (!(n_pairs_next <= small_pairs_limit() && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0)) return false;
     if (!p->sig) { // first use: signal word + mailbox; any failure switches pipelining off for this handle
         const char *env = std::getenv("SC_PIPELINE"); // read per handle, at its first late round
-        const bool env_off = env && std::atoi(env) == 0;
+        bool env_off = env && std::atoi(env) == 0;
+        // a runtime that makes every launch wait for its kernel would block on the wait kernel until its bound expires
+        for (const char *name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING"}) {
+            const char *v = std::getenv(name);
+            if (v && std::atoi(v) != 0) env_off = true;
+        }
         bool ok = !env_off && hipSetDevice(p->device) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->h_mail), 2 * sizeof(FrHost) + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
         ok = ok && hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_mail_dev), p->h_mail, 0) == hipSuccess;
