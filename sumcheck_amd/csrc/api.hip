@@ -509,6 +509,33 @@ static uint64_t small_pairs_limit() { // SC_SMALL_LOG2: experiment knob for the 
     return v;
 }
 
+// One-time probe per process: does a kernel launch return before the kernel has finished?  A wait kernel with a short bound
+// (a few milliseconds) is enqueued on a word nobody sets; an asynchronous runtime returns from the launch call at once, a
+// serialising one (a profiler collecting counters, *_LAUNCH_BLOCKING) only when the bound has expired -- and then pipelined
+// rounds, whose wait kernels must be enqueued BEFORE the host produces the challenge, are not possible.
+static bool launches_are_async(sc_prover *p) {
+    static const bool ok = [p] {
+        uint32_t *h = nullptr, *d = nullptr;
+        FrHost *dm = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&h), 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return false;
+        bool good = hipHostGetDevicePointer(reinterpret_cast<void **>(&d), h, 0) == hipSuccess &&
+                    hipMalloc(reinterpret_cast<void **>(&dm), sizeof(FrHost)) == hipSuccess;
+        if (good) {
+            std::memset(h, 0, 256);
+            const auto t0 = std::chrono::steady_clock::now();
+            good = scd::launch_wait_challenge(d, 0xffffffffu, reinterpret_cast<const FrHost *>(d + 16), dm, p->stream, 1u << 11) == hipSuccess;
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            (void)hipStreamSynchronize(p->stream);
+            good = good && ms < 1.0; // 2^11 polls take a few milliseconds; an asynchronous launch call a few microseconds
+        }
+        if (dm) (void)hipFree(dm);
+        (void)hipHostFree(h);
+        (void)hipGetLastError();
+        return good;
+    }();
+    return ok;
+}
+
 // Pipelined late rounds.  can_defer_next: the NEXT round is a latency-bound one and the wait-value machinery is available.
 static bool can_defer_next(sc_prover *p) {
     if (!p->pipeline_ok || p->exhausted || p->round == 0 || p->round >= p->nv) return false;
@@ -522,7 +549,7 @@ static bool can_defer_next(sc_prover *p) {
             const char *v = std::getenv(name);
             if (v && std::atoi(v) != 0) env_off = true;
         }
-        bool ok = !env_off && hipSetDevice(p->device) == hipSuccess;
+        bool ok = !env_off && hipSetDevice(p->device) == hipSuccess && launches_are_async(p);
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->h_mail), 2 * sizeof(FrHost) + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
         ok = ok && hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_mail_dev), p->h_mail, 0) == hipSuccess;
         ok = ok && hipMalloc(reinterpret_cast<void **>(&p->d_mail), 2 * sizeof(FrHost)) == hipSuccess;

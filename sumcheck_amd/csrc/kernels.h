@@ -146,7 +146,8 @@ hipError_t launch_fix(const uint4 *src, uint4 *dst, const FrHost &r, uint64_t n_
 // small rounds: bind every table in one launch (grid.y = table) ...
 // one-wave kernel that holds the stream until flag_dev[0] == want (host-mapped word; bounded spin -- on giving up it stores want
 // to flag_dev[1]), then copies the challenge from the host-mapped mailbox to device memory
-hipError_t launch_wait_challenge(uint32_t *flag_dev, uint32_t want, const FrHost *mail_host_dev, FrHost *mail_dev, hipStream_t stream);
+hipError_t launch_wait_challenge(uint32_t *flag_dev, uint32_t want, const FrHost *mail_host_dev, FrHost *mail_dev, hipStream_t stream,
+                                 uint32_t spins_override = 0);
 // r_mail (device-visible, may be host-mapped) overrides r when non-null: the challenge is fetched at run time
 hipError_t launch_fix_multi(const TablePtrs &tp, int n_tables, const FrHost &r, const FrHost *r_mail, uint64_t n_out, hipStream_t stream);
 // ... and one launch for every (product, evaluation point) combination (grid.y = combination), one lane per pair

@@ -647,11 +647,13 @@ __global__ void k_wait_challenge(uint32_t *__restrict__ flag, const uint32_t wan
     __syncthreads();
     if (threadIdx.x < 4) mail_dev[threadIdx.x] = __hip_atomic_load(mail_host + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-hipError_t launch_wait_challenge(uint32_t *flag_dev, uint32_t want, const FrHost *mail_host_dev, FrHost *mail_dev, hipStream_t stream) {
-    static const uint32_t max_spins = [] { // SC_WAIT_SPINS: tests shorten the bound to exercise the give-up path
+hipError_t launch_wait_challenge(uint32_t *flag_dev, uint32_t want, const FrHost *mail_host_dev, FrHost *mail_dev, hipStream_t stream,
+                                 uint32_t spins_override) {
+    static const uint32_t env_spins = [] { // SC_WAIT_SPINS: tests shorten the bound to exercise the give-up path
         const char *e = std::getenv("SC_WAIT_SPINS");
         return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (1u << 22);
     }();
+    const uint32_t max_spins = spins_override ? spins_override : env_spins;
     hipLaunchKernelGGL(k_wait_challenge, dim3(1), dim3(64), 0, stream, flag_dev, want, max_spins, reinterpret_cast<const uint64_t *>(mail_host_dev),
                        reinterpret_cast<uint64_t *>(mail_dev));
     return hipGetLastError();
