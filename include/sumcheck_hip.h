@@ -209,7 +209,7 @@ SC_API int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_null, 
  * op 0 mul (production path) | 1 add | 2 sub | 3 mul, plain-C++ CIOS | 4 mul, Comba asm | 5 a[i] * b[0] with b[0] uniform. */
 SC_API int sc_fr_elementwise(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n);
 /* Elementwise micro-kernel: dependent chains of `reps` field ops per lane, 4 chains per lane (ceilings):
- * variant 0 mul CIOS | 1 add | 2 mul Comba | 3 mul Comba by a uniform operand. */
+ * variant 0 mul CIOS | 1 add | 2 mul Comba | 3 mul Comba by a uniform operand | 4 two Comba products interleaved. */
 SC_API int sc_bench_modmul(uint64_t n_threads, uint32_t reps, uint32_t variant, float *ms_out, uint64_t *checksum_out);
 
 #ifdef __cplusplus

@@ -137,19 +137,6 @@ __device__ __forceinline__ void fe_store_f29(uint4 *main, uint64_t entry, const 
     main[f29_chunk(entry, 0)] = make_uint4((uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
     main[f29_chunk(entry, 1)] = make_uint4((uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
 }
-// Bound value -> storable form: the value of e0 + r*(e1-e0) lies in (-2^251, 2p + 2^252); one conditional subtraction
-// of p decided by the top limb keeps stored values in (-2^251, p + 2^233) for ever (no growth from round to round),
-// and two parallel carry passes leave limbs 0..7 in [-1, 2^29): differences of two stored elements stay within the
-// 2^29 operand bound of fe_mul.
-__device__ __forceinline__ Fe fe_tighten(const Fe &v) {
-    Fe c = fe_carry_pass(v);
-    constexpr int32_t PH = 0x0073eda7; // floor(p / 2^232)
-    const int32_t mask = (c.l[8] > PH) ? -1 : 0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) c.l[i] -= fe_p_limb(i) & mask;
-    return fe_carry_pass(c);
-}
-
 // a * b / 2^261 (mod p), |result value| < 2^257; result limbs 0..7 in [0, 2^29), limb 8 signed and small.
 template <typename B>
 __device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {

@@ -865,7 +865,8 @@ __global__ __launch_bounds__(kBlock) void k_synth(const uint64_t key, const uint
 
 // ------------------------------------------------------------------------------------------------
 // modmul ceiling micro-kernel: a dependent chain of `reps` Montgomery products per lane, 4 independent
-// chains per lane for ILP.  variant 0: fr_mul; variant 1: fr_add chain (VALU add/sub ceiling).
+// chains per lane for ILP.  variant 0: CIOS product; 1: fr_add chain (VALU add/sub ceiling); 2: Comba product; 3: Comba by a
+// wave-uniform operand; 4: two Comba products interleaved per asm statement.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_bench_modmul(const uint32_t reps, const uint32_t variant, uint64_t *__restrict__ sink) {
     const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -887,25 +888,6 @@ __global__ __launch_bounds__(kBlock) void k_bench_modmul(const uint32_t reps, co
 #pragma unroll
             for (int c = 0; c < 4; ++c) x[c] = fr_mul_comba(x[c], y);
         }
-    } else if (variant == 5 || variant == 6) { // carry-free 29-bit-limb product, 4 (variant 5) or 2 (variant 6) chains
-        Fe fx[4], fy = fe_from_fr(y);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) fx[c] = fe_from_fr(x[c]);
-        if (variant == 5) {
-            for (uint32_t k = 0; k < reps; ++k) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) fx[c] = fe_mul(fy, fx[c]);
-            }
-        } else {
-            for (uint32_t k = 0; k < reps; ++k) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c) fx[c] = fe_mul(fy, fx[c]);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) fx[c] = fe_mul(fy, fx[c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) x[c] = fe_to_fr(fx[c]);
     } else if (variant == 4) {
         for (uint32_t k = 0; k < reps; ++k) {
             fr_mul2_comba(x[0], y, x[1], y, x[0], x[1]);

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sumcheck_amd as sc
 from sumcheck_amd import _lib
 
-for variant, name in ((0, "fr_mul_cios"), (2, "fr_mul_comba"), (4, "fr_mul2_comba"), (5, "fe_mul_4chains"), (6, "fe_mul_2chains"), (3, "fr_mul_comba_uniform"), (1, "fr_add")):
+for variant, name in ((0, "fr_mul_cios"), (2, "fr_mul_comba"), (4, "fr_mul2_comba"), (3, "fr_mul_comba_uniform"), (1, "fr_add")):
     for blocks_per_cu in (2, 4, 8, 16):
         n_threads = 256 * 256 * blocks_per_cu
         reps = 2000 if variant != 1 else 20000
