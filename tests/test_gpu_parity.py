@@ -503,3 +503,20 @@ def test_sparse_evaluate_matches_big_integers(num_vars, nnz):
             w = w * (r if (i >> k) & 1 else (1 - r)) % field.P
         want = (want + w) % field.P
     assert got == want
+
+
+def test_gkr_scratch_cache_release_and_reuse():
+    """The GKR entry points keep their scratch and prover handle between calls; sc_release_caches frees them and the next call
+    allocates afresh.  Proofs before and after (and across two dimensions, which re-sizes the cache) are identical."""
+    def run(dim):
+        rng = np.random.default_rng(99 + dim)
+        n = 1 << dim
+        idx = np.unique(rng.integers(0, 1 << (3 * dim), size=2 * n, dtype=np.uint64))[:n]
+        vals, f2, f3, g = cref.synth_table(31, 1, idx.shape[0]), cref.synth_table(31, 2, n), cref.synth_table(31, 3, n), cref.synth_table(31, 4, dim)
+        f1 = sc.SparseMultilinearExtension(3 * dim, idx, vals)
+        pr = sc.GKRRoundSumcheck.prove(sc.Blake2b512Rng.setup(), f1, sc.DenseMultilinearExtension(dim, f2), sc.DenseMultilinearExtension(dim, f3), g)
+        return np.stack([m.evaluations for m in pr.phase1_sumcheck_msgs + pr.phase2_sumcheck_msgs])
+    a10, a7 = run(10), run(7)          # second call shrinks nothing, re-uses the larger arena; the handle is rebuilt for dim 7
+    assert sc.lib().sc_release_caches() == 0
+    assert np.array_equal(run(10), a10) and np.array_equal(run(7), a7) and np.array_equal(run(7), a7)
+    assert sc.lib().sc_release_caches() == 0
