@@ -143,6 +143,9 @@ SC_API void sc_rng_sample_fr(sc_rng *rng, uint64_t *out);                       
  * returns SC_ERR_HIP ("... the proof is void") rather than messages computed on a stale challenge -- reset the
  * handle and prove again.  SC_PIPELINE=0 in the environment turns the pipelining off. */
 SC_API int sc_ml_prove(const sc_poly_desc *desc, sc_rng *rng_or_null, uint64_t *out_proof, sc_prover **out_state_or_null);
+/* n_rounds x (prove_round, feed, sample) of that loop (mod.rs:57-64) on a handle at round 0, continuing `rng` without feeding
+ * PolynomialInfo: the last log2 G rounds of a sharded proof, on the gathered G-entry tables.  out_randomness: n_rounds x 4. */
+SC_API int sc_ml_prove_rounds(sc_prover *p, sc_rng *rng, uint32_t n_rounds, uint64_t *out_proof, uint64_t *out_randomness);
 /* the same loop on an existing handle at round 0 (sc_prover_init / sc_prover_reset): no allocation per proof */
 SC_API int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *out_proof);
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "sc_ml_prove_sharded_rounds": (C.c_int, [_V, _V, _V, C.c_uint32, C.c_uint32, _V, _V]),
     "sc_fix_variables": (C.c_int, [_V, C.c_uint32, _V, C.c_uint32, _V, C.c_uint32]),
     "sc_poly_evaluate": (C.c_int, [_V, _V, _V, _V]),
+    "sc_ml_prove_rounds": (C.c_int, [_V, _V, C.c_uint32, _V, _V]),
     "sc_release_caches": (C.c_int, []),
     "sc_sparse_evaluate": (C.c_int, [_V, _V, C.c_uint64, C.c_uint32, _V, _V]),
     "sc_rng_setup": (_V, []),

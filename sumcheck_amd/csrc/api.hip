@@ -1323,6 +1323,17 @@ int sc_internal_run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rou
     return rc;
 }
 
+// n_rounds of the prove loop on a handle at round 0, continuing `rng` (no PolynomialInfo is fed): the tail of a sharded proof
+extern "C" int sc_ml_prove_rounds(sc_prover *p, sc_rng *rng, uint32_t n_rounds, uint64_t *out_proof, uint64_t *out_randomness) {
+    if (!p || !rng || !out_proof || !out_randomness) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (p->round != 0 || n_rounds > p->nv) return fail(SC_ERR_BAD_ARG, "handle must be at round 0 and hold at least n_rounds variables");
+    std::vector<sch::Fr> ch(n_rounds);
+    int rc = sc_internal_run_rounds(p, rng->rng, n_rounds, out_proof, ch.data());
+    if (rc) return rc;
+    if (n_rounds) std::memcpy(out_randomness, ch.data(), (size_t)n_rounds * 32);
+    return SC_OK;
+}
+
 extern "C" int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *out_proof) {
     if (!p || !out_proof) return fail(SC_ERR_BAD_ARG, "null argument");
     if (p->round != 0) return fail(SC_ERR_BAD_ARG, "handle is not at round 0");

@@ -90,6 +90,20 @@ class HipShardEngine:
         check(lib().sc_prove_round(self._h, rp, C.c_void_p(out.ctypes.data)))
         return out
 
+    def prove_rounds(self, rng: Blake2b512Rng, n_rounds: int):
+        """-> (messages (n_rounds, D, 4), challenges (n_rounds, 4)): n_rounds x (prove_round, feed, sample) inside the library,
+        continuing `rng` (sc_ml_prove_rounds); for provers that hold whole tables (the tail)"""
+        msgs = np.empty((n_rounds, self.D, 4), dtype=np.uint64)
+        ch = np.empty((n_rounds, 4), dtype=np.uint64)
+        torch = self.torch
+        # on the handle's own non-blocking stream (see prove_sharded_native): its pipelined rounds park a polling kernel there
+        check(lib().sc_prover_set_stream(self._h, None, 1))  # synchronises the torch stream the tables were copied on
+        try:
+            check(lib().sc_ml_prove_rounds(self._h, rng._h, n_rounds, C.c_void_p(msgs.ctypes.data), C.c_void_p(ch.ctypes.data)))
+        finally:
+            check(lib().sc_prover_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), 0))
+        return msgs, ch
+
     def bind_final(self, r: np.ndarray):
         """-> (U,4) int64 tensor: the single remaining element of every local table"""
         out = self.torch.empty((self.U, 4), dtype=self.torch.int64, device=self.device)
@@ -214,14 +228,25 @@ def prove_sharded(engines: Sequence, comm: DistComm, nv_total: int, max_multipli
         U = local.shape[1]
         tables = allsh.reshape(G, U, 4).permute(1, 0, 2).contiguous()   # (U, G, 4): entry g of table u came from shard g
         tail = tail_factory(k, tables)
-        rt = None
-        for j in range(k):
-            evals = _tail_round(tail, rt)
-            proof[nv_local + j] = evals
-            rng.feed(ProverMsg(evals))
-            rt = rng.sample_fr()
-            rand[nv_local + j] = rt
+        _run_tail(tail, rng, k, proof[nv_local:], rand[nv_local:])
     return proof, rand
+
+
+def _run_tail(tail, rng, k, proof_out, rand_out):
+    """the last k rounds, on the gathered tables every rank holds in full: one library call for a HIP engine, the per-round
+    loop otherwise (test doubles)"""
+    if hasattr(tail, "prove_rounds"):
+        msgs, ch = tail.prove_rounds(rng, k)
+        proof_out[:k] = msgs
+        rand_out[:k] = ch
+        return
+    rt = None
+    for j in range(k):
+        evals = _tail_round(tail, rt)
+        proof_out[j] = evals
+        rng.feed(ProverMsg(evals))
+        rt = rng.sample_fr()
+        rand_out[j] = rt
 
 
 def _tail_round(tail, rt):
@@ -298,13 +323,7 @@ def prove_sharded_native(engine: HipShardEngine, ncomm: NativeComm, comm: DistCo
         U = local.shape[1]
         tables = allsh.reshape(G, U, 4).permute(1, 0, 2).contiguous()
         tail = tail_factory(k, tables)
-        rt = None
-        for j in range(k):
-            evals = _tail_round(tail, rt)
-            proof[nv_local + j] = evals
-            rng.feed(ProverMsg(evals))
-            rt = rng.sample_fr()
-            rand[nv_local + j] = rt
+        _run_tail(tail, rng, k, proof[nv_local:], rand[nv_local:])
     return proof, rand
 
 
