@@ -973,8 +973,17 @@ extern "C" int sc_prover_bind_final(sc_prover *p, const uint64_t *r, uint64_t *d
     if (sch::geq_p(rr)) return fail(SC_ERR_BAD_ARG, "challenge is not a canonical field element");
     HIP_TRY(hipSetDevice(p->device));
     p->randomness.push_back(rr);
-    for (uint32_t u = 0; u < p->U; ++u)
-        HIP_TRY(scd::launch_fix(p->tabs[u].cur, reinterpret_cast<uint4 *>(d_out + 4 * (size_t)u), to_dev(rr), 1, p->stream));
+    for (uint32_t u0 = 0; u0 < p->U; u0 += (uint32_t)scd::kMaxSmallTables) { // one launch per 32 tables
+        const uint32_t cnt = std::min<uint32_t>(p->U - u0, (uint32_t)scd::kMaxSmallTables);
+        TablePtrs tp;
+        std::memset(&tp, 0, sizeof(tp));
+        for (uint32_t j = 0; j < cnt; ++j) {
+            tp.src[j] = p->tabs[u0 + j].cur;
+            tp.src_top[j] = p->tabs[u0 + j].cur_top;
+            tp.dst[j] = reinterpret_cast<uint4 *>(d_out + 4 * (size_t)(u0 + j));
+        }
+        HIP_TRY(scd::launch_fix_multi(tp, (int)cnt, to_dev(rr), nullptr, 1, p->stream));
+    }
     p->exhausted = true;
     return SC_OK;
 }
