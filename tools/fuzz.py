@@ -1,0 +1,32 @@
+"""One-off differential fuzz on a GPU box: random product lists (shared tables, repeated factors, 1..6 multiplicands, up to 14
+products) at sizes that run big rounds (merged and per-product launches), whole proofs against the C oracle.
+python tools/fuzz.py [cases] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import sumcheck_amd as sc
+from oracle import cref
+from tests import helpers as H
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+bad = 0
+t0 = time.time()
+for c in range(cases):
+    nv = int(rng.choice([1, 2, 5, 9, 13, 16, 17, 18, 19], p=[.04, .04, .05, .07, .1, .1, .2, .25, .15]))
+    nt = int(rng.integers(1, 9))
+    K = int(rng.integers(1, 15)) if rng.random() < 0.15 else int(rng.integers(1, 6))
+    maxm = 6 if rng.random() < 0.2 else 4
+    shapes = [[int(x) for x in rng.integers(0, nt, size=int(rng.integers(1, maxm + 1)))] for _ in range(K)]
+    tabs = [cref.synth_table(1000 + c, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(1000 + c, 1000, K)
+    want, wrand = cref.ml_prove(H.desc_from(nv, shapes, tabs, coefs), threads=cref.max_threads())
+    dev = "cuda:0" if rng.random() < 0.5 else None
+    poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device=dev)
+    proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly)
+    got = np.stack([m.evaluations for m in proof])
+    ok = np.array_equal(got, want) and np.array_equal(state.randomness, wrand)
+    if not ok:
+        bad += 1
+        print("MISMATCH", c, nv, nt, shapes, dev)
+print(f"FUZZ {'OK' if bad == 0 else 'FAILED'}: {cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
