@@ -47,6 +47,13 @@ struct Fr {
     bool operator!=(const Fr &o) const { return !(*this == o); }
     static Fr one() { return Fr{{0x00000001fffffffeULL, 0x5884b7fa00034802ULL, 0x998c4fefecbc4ff5ULL, 0x1824b159acc5056fULL}}; }
     static Fr zero() { return Fr{}; }
+    // a valid ark_ff::Fp holds a residue < p; anything else is not a field element (operator+ below relies on it)
+    bool is_canonical() const {
+        static const uint64_t P[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+        for (int i = 3; i >= 0; --i)
+            if (l[i] != P[i]) return l[i] < P[i];
+        return false;
+    }
     // a + b mod p (host; only extract_sum needs it)
     friend Fr operator+(const Fr &a, const Fr &b) {
         static const uint64_t P[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
@@ -303,7 +310,7 @@ struct MLSumcheck {
         }
         SubClaim sub;
         sub.point.resize(std::max<size_t>(nv, 1));
-        check(sc_ml_verify((uint32_t)nv, (uint32_t)info.max_multiplicands, claimed_sum.l, flat[0].l, fs_rng.raw(), sub.point[0].l,
+        check(sc_ml_verify((uint32_t)nv, (uint32_t)info.max_multiplicands, claimed_sum.l, flat[0].l, (uint64_t)(nv * Dg), fs_rng.raw(), sub.point[0].l,
                            sub.expected_evaluation.l));
         sub.point.resize(nv);
         return sub;
@@ -392,9 +399,12 @@ struct GKRRoundSumcheck {
             rs.push_back(rng.rand_fr());
         }
         Fr expected = asserted_sum;
+        if (!expected.is_canonical()) throw Panic(SC_ERR_BAD_ARG, "claimed sum is not a canonical field element");
         for (size_t i = 0; i < dim; ++i) {
             const auto &ev = msgs[i].evaluations;
             if (ev.size() != 3) throw Panic(SC_ERR_BAD_ARG, "incorrect number of evaluations");
+            for (const Fr &e : ev) // the raw-limb sum below is only a field addition on canonical operands
+                if (!e.is_canonical()) throw Panic(SC_ERR_BAD_ARG, "proof element is not a canonical field element");
             if (ev[0] + ev[1] != expected) throw Reject("Prover message is not consistent with the claim.");
             check(sc_interpolate_uni_poly(ev[0].l, 3, rs[i].l, expected.l));
         }

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 1
+#define SC_ABI_VERSION 2
 #define SC_API __attribute__((visibility("default")))
 
 enum sc_status {
@@ -150,11 +150,17 @@ SC_API int sc_ml_prove_rounds(sc_prover *p, sc_rng *rng, uint32_t n_rounds, uint
 SC_API int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *out_proof);
 
 /* ---- verifier (reference src/ml_sumcheck/protocol/verifier.rs:90-251) -- host side, O(nv*deg) - */
+/* interpolate_uni_poly (verifier.rs:139-251, including its three tiers: i64 ratios for len <= 20, i128 for len <= 33, field
+ * elements beyond).  Every input element must be canonical (< p), else SC_ERR_BAD_ARG. */
 SC_API int sc_interpolate_uni_poly(const uint64_t *p_i, uint32_t len, const uint64_t *eval_at, uint64_t *out);
 /* MLSumcheck::verify_as_subprotocol (mod.rs:84-100): returns SC_OK / SC_ERR_REJECT;
+ * proof: num_vars x (max_multiplicands+1) x 4 limbs; proof_elems: the number of field elements the caller's buffer holds --
+ * anything but num_vars * (max_multiplicands+1) is SC_ERR_BAD_ARG "incorrect number of evaluations" (verifier.rs:60-62), so
+ * the library never reads past it.  claimed_sum and every proof element must be canonical (< p): the reference's Fp cannot
+ * hold anything else, and a non-canonical encoding is rejected with SC_ERR_BAD_ARG before any arithmetic.
  * out_point: num_vars x 4, out_expected: 4 limbs (SubClaim, verifier.rs:29-34). */
 SC_API int sc_ml_verify(uint32_t num_vars, uint32_t max_multiplicands, const uint64_t *claimed_sum, const uint64_t *proof,
-                 sc_rng *rng_or_null, uint64_t *out_point, uint64_t *out_expected);
+                 uint64_t proof_elems, sc_rng *rng_or_null, uint64_t *out_point, uint64_t *out_expected);
 
 /* ---- GKR round sumcheck (reference src/gkr_round_sumcheck/mod.rs) ---------------------------- */
 /* f1 is a SparseMultilinearExtension over 3*dim variables given as nnz (index, value) pairs with

@@ -78,7 +78,7 @@ SIGNATURES = {
     "sc_ml_prove": (C.c_int, [C.POINTER(PolyDesc), _V, _V, C.POINTER(_V)]),
     "sc_ml_prove_handle": (C.c_int, [_V, _V, _V]),
     "sc_interpolate_uni_poly": (C.c_int, [_V, C.c_uint32, _V, _V]),
-    "sc_ml_verify": (C.c_int, [C.c_uint32, C.c_uint32, _V, _V, _V, _V, _V]),
+    "sc_ml_verify": (C.c_int, [C.c_uint32, C.c_uint32, _V, _V, C.c_uint64, _V, _V, _V]),
     "sc_gkr_phase_one": (C.c_int, [_V, _V, C.c_uint64, C.c_uint32, _V, _V, _V, _V, _V, u64p]),
     "sc_gkr_phase_two": (C.c_int, [_V, _V, C.c_uint64, C.c_uint32, _V, _V]),
     "sc_gkr_prove": (C.c_int, [_V, _V, _V, C.c_uint64, C.c_uint32, _V, _V, _V, _V, _V]),

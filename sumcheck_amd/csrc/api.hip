@@ -1382,35 +1382,92 @@ extern "C" int sc_ml_prove(const sc_poly_desc *desc, sc_rng *rng_or_null, uint64
 // ---------------------------------------------------------------------------------------------------
 // verifier side (host; O(nv * deg) scalar work) -- reference src/ml_sumcheck/protocol/verifier.rs
 // ---------------------------------------------------------------------------------------------------
+static sch::Fr fr_from_u128(sch::u128 x) { // F::from(u128): lo + hi * 2^64
+    const sch::Fr lo = sch::from_u64((uint64_t)x), hi = sch::from_u64((uint64_t)(x >> 64));
+    static const sch::Fr two64 = sch::mul(sch::Fr{{0, 1, 0, 0}}, sch::kR2);
+    return sch::add(lo, sch::mul(hi, two64));
+}
+
+// verifier.rs:139-251, literally: the value at x of the unique polynomial of degree < len through (i, y[i]), with the same
+// three tiers for the ratio of denominators (machine i64 / i128 / field) and the same early returns.  Every tier computes
+// the same field value; they are kept so that a reader can diff this against the reference line by line.
 static sch::Fr interpolate(const sch::Fr *y, uint32_t len, const sch::Fr &x) {
-    // verifier.rs:139-251: value at x of the unique degree < len polynomial through (i, y[i]).
-    sch::Fr node = sch::zero();
-    for (uint32_t i = 0; i < len; ++i) { // verifier.rs:152-164: x is one of the nodes
-        if (sch::eq(x, node)) return y[i];
-        node = sch::add(node, sch::kOne);
+    std::vector<sch::Fr> evals;
+    evals.reserve(len);
+    sch::Fr prod = x;
+    evals.push_back(x);
+    sch::Fr check = sch::zero();
+    for (uint32_t i = 1; i < len; ++i) { // verifier.rs:150-160
+        if (sch::eq(x, check)) return y[i - 1];
+        check = sch::add(check, sch::kOne);
+        const sch::Fr tmp = sch::sub(x, check);
+        evals.push_back(tmp);
+        prod = sch::mul(prod, tmp);
     }
-    // barycentric form: sum_i y_i * w_i / (x - i) * prod_j (x - j), w_i = 1 / prod_{j != i} (i - j)
-    std::vector<sch::Fr> diff(len);
-    sch::Fr full = sch::kOne;
-    for (uint32_t j = 0; j < len; ++j) {
-        diff[j] = sch::sub(x, sch::from_u64(j));
-        full = sch::mul(full, diff[j]);
-    }
-    sch::Fr acc = sch::zero();
-    for (uint32_t i = 0; i < len; ++i) {
-        sch::Fr den = diff[i];
-        for (uint32_t j = 0; j < len; ++j) {
-            if (j == i) continue;
-            const sch::Fr d = i > j ? sch::from_u64(i - j) : sch::neg(sch::from_u64(j - i));
-            den = sch::mul(den, d);
+    if (sch::eq(x, check)) return y[len - 1]; // verifier.rs:162-164
+    sch::Fr res = sch::zero();
+    auto term = [&](uint32_t i, const sch::Fr &num, const sch::Fr &den) { // res += p_i[i] * prod * num / (den * evals[i])
+        res = sch::add(res, sch::mul(sch::mul(sch::mul(y[i], prod), num), sch::inverse(sch::mul(den, evals[i]))));
+    };
+    if (len <= 20) { // verifier.rs:193-213: i64 / u64 ratio
+        uint64_t fact = 1;
+        for (uint32_t k = 2; k < len; ++k) fact *= k;
+        const sch::Fr last_denom = sch::from_u64(fact);
+        int64_t ratio_numerator = 1;
+        uint64_t ratio_enumerator = 1;
+        for (uint32_t i = len; i-- > 0;) {
+            const sch::Fr rn = ratio_numerator < 0 ? sch::neg(sch::from_u64((uint64_t)(-ratio_numerator))) : sch::from_u64((uint64_t)ratio_numerator);
+            term(i, sch::from_u64(ratio_enumerator), sch::mul(last_denom, rn));
+            if (i != 0) {
+                ratio_numerator *= -((int64_t)len - (int64_t)i);
+                ratio_enumerator *= (uint64_t)i;
+            }
         }
-        acc = sch::add(acc, sch::mul(sch::mul(y[i], full), sch::inverse(den)));
+    } else if (len <= 33) { // verifier.rs:214-234: i128 / u128 ratio
+        sch::u128 fact = 1;
+        for (uint32_t k = 2; k < len; ++k) fact *= k;
+        const sch::Fr last_denom = fr_from_u128(fact);
+        __int128 ratio_numerator = 1;
+        sch::u128 ratio_enumerator = 1;
+        for (uint32_t i = len; i-- > 0;) {
+            const sch::Fr rn = ratio_numerator < 0 ? sch::neg(fr_from_u128((sch::u128)(-ratio_numerator))) : fr_from_u128((sch::u128)ratio_numerator);
+            term(i, fr_from_u128(ratio_enumerator), sch::mul(last_denom, rn));
+            if (i != 0) {
+                ratio_numerator *= -((__int128)len - (__int128)i);
+                ratio_enumerator *= (sch::u128)i;
+            }
+        }
+    } else { // verifier.rs:235-248: the ratio as field elements
+        sch::Fr denom_up = sch::kOne; // field_factorial(len - 1)
+        for (uint32_t k = 1; k < len; ++k) denom_up = sch::mul(denom_up, sch::from_u64(k));
+        sch::Fr denom_down = sch::kOne;
+        for (uint32_t i = len; i-- > 0;) {
+            term(i, denom_down, denom_up);
+            if (i != 0) {
+                denom_up = sch::mul(denom_up, sch::neg(sch::from_u64(len - i)));
+                denom_down = sch::mul(denom_down, sch::from_u64(i));
+            }
+        }
     }
-    return acc;
+    return res;
+}
+
+// every element handed to the verifier must be a canonical Montgomery residue (< p): the reference's Fp cannot hold anything
+// else, and host_fr.hpp's add() assumes it (a non-canonical ev0 + p, ev1 + p would wrap past 2^256 and pass the sum check)
+static int require_canonical(const uint64_t *limbs, size_t n_elems, const char *what) {
+    for (size_t i = 0; i < n_elems; ++i) {
+        sch::Fr v;
+        std::memcpy(&v, limbs + 4 * i, 32);
+        if (sch::geq_p(v)) return fail(SC_ERR_BAD_ARG, "%s element %zu is not a canonical field element", what, i);
+    }
+    return SC_OK;
 }
 
 extern "C" int sc_interpolate_uni_poly(const uint64_t *p_i, uint32_t len, const uint64_t *eval_at, uint64_t *out) {
     if (!p_i || !eval_at || !out || len == 0) return fail(SC_ERR_BAD_ARG, "null argument");
+    int rc = require_canonical(p_i, len, "p_i");
+    if (!rc) rc = require_canonical(eval_at, 1, "eval_at");
+    if (rc) return rc;
     sch::Fr x;
     std::memcpy(&x, eval_at, 32);
     const sch::Fr v = interpolate(reinterpret_cast<const sch::Fr *>(p_i), len, x);
@@ -1419,11 +1476,16 @@ extern "C" int sc_interpolate_uni_poly(const uint64_t *p_i, uint32_t len, const 
 }
 
 extern "C" int sc_ml_verify(uint32_t num_vars, uint32_t max_multiplicands, const uint64_t *claimed_sum, const uint64_t *proof,
-                            sc_rng *rng_or_null, uint64_t *out_point, uint64_t *out_expected) {
+                            uint64_t proof_elems, sc_rng *rng_or_null, uint64_t *out_point, uint64_t *out_expected) {
     if (!claimed_sum || !proof || !out_point || !out_expected) return fail(SC_ERR_BAD_ARG, "null argument");
+    const uint32_t D = max_multiplicands + 1;
+    // verifier.rs:60-62 panics on a message of the wrong length; here the caller states how many elements `proof` holds
+    if (proof_elems != (uint64_t)num_vars * D) return fail(SC_ERR_BAD_ARG, "incorrect number of evaluations");
+    int rc = require_canonical(claimed_sum, 1, "claimed_sum");
+    if (!rc) rc = require_canonical(proof, (size_t)proof_elems, "proof");
+    if (rc) return rc;
     sc_rng local;
     sch::Blake2b512Rng &rng = rng_or_null ? rng_or_null->rng : local.rng;
-    const uint32_t D = max_multiplicands + 1;
     rng.feed_poly_info(max_multiplicands, num_vars); // mod.rs:90
     const sch::Fr *msgs = reinterpret_cast<const sch::Fr *>(proof);
     std::vector<sch::Fr> rs(num_vars);

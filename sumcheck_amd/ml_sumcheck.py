@@ -357,13 +357,18 @@ class MLSumcheck:
                               proof: Sequence[ProverMsg]) -> SubClaim:
         """mod.rs:84-100; rejects with SumcheckError(SC_ERR_REJECT, "Prover message is not consistent with the claim.")"""
         nv = polynomial_info.num_variables
+        D = polynomial_info.max_multiplicands + 1
         if len(proof) < nv:
             raise SumcheckError(5, "proof is incomplete")
-        flat = np.ascontiguousarray(np.stack([_np64(m.evaluations) for m in proof[:nv]])) if nv else np.zeros((1, 1, 4), np.uint64)
+        msgs = [_np64(m.evaluations).reshape(-1, 4) for m in proof[:nv]]
+        for m in msgs:  # verifier.rs:60-62 panics on a message of the wrong length
+            if m.shape != (D, 4):
+                raise SumcheckError(5, "incorrect number of evaluations")
+        flat = np.ascontiguousarray(np.stack(msgs)) if nv else np.zeros((1, D, 4), np.uint64)
         point = np.empty((max(nv, 1), 4), dtype=np.uint64)
         exp = np.empty(4, dtype=np.uint64)
-        check(lib().sc_ml_verify(nv, polynomial_info.max_multiplicands, _ptr(_np64(claimed_sum).reshape(4)), _ptr(flat), fs_rng._h,
-                                 _ptr(point), _ptr(exp)))
+        cs = _np64(claimed_sum).reshape(4)  # bound to a local: the converted array must outlive the call
+        check(lib().sc_ml_verify(nv, polynomial_info.max_multiplicands, _ptr(cs), _ptr(flat), nv * D, fs_rng._h, _ptr(point), _ptr(exp)))
         return SubClaim(point[:nv].copy(), exp)
 
 
@@ -371,5 +376,6 @@ def interpolate_uni_poly(p_i, eval_at) -> np.ndarray:
     """verifier.rs:139-251"""
     p_i = _np64(p_i).reshape(-1, 4)
     out = np.empty(4, dtype=np.uint64)
-    check(lib().sc_interpolate_uni_poly(_ptr(p_i), p_i.shape[0], _ptr(_np64(eval_at).reshape(4)), _ptr(out)))
+    at = _np64(eval_at).reshape(4)
+    check(lib().sc_interpolate_uni_poly(_ptr(p_i), p_i.shape[0], _ptr(at), _ptr(out)))
     return out

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/sumcheck_hip.h but not exported"
     assert set(declared) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert sc.lib().sc_abi_version() == 1
+    assert sc.lib().sc_abi_version() == 2
 
 
 def test_transcript_matches_golden():
@@ -90,6 +90,54 @@ def test_verifier_accepts_golden_proofs(name):
     if case["nv"] > 1:
         with pytest.raises(sc.SumcheckError):
             sc.MLSumcheck.verify_as_subprotocol(vr, info, H.mont([case["sum"]])[0], proof)
+
+
+def test_verifier_rejects_non_canonical_encodings_and_short_messages():
+    """A proof element (or claimed sum) >= p is not a field element: the reference's Fp cannot hold it.  ev0 + p, ev1 + p would
+    hash to the honest transcript and, through a raw 256-bit add that drops the carry, pass P(0) + P(1) == claim for a claim
+    that is off by R -- every entry point must refuse the encoding before any arithmetic.  Messages of the wrong length are the
+    reference's "incorrect number of evaluations" panic (verifier.rs:60-62)."""
+    case = H.load("ml_nv3_c1shape.json")
+    info = sc.PolynomialInfo(max(len(s) for s in case["shapes"]), case["nv"])
+    good = [H.mont(r) for r in case["fs_proof"]]
+    claim = H.mont([case["sum"]])[0]
+    pl = np.array([(field.P >> (64 * k)) & ((1 << 64) - 1) for k in range(4)], dtype=np.uint64)
+
+    def plus_p(x):
+        v = sum(int(x[k]) << (64 * k) for k in range(4)) + field.P
+        assert v < 1 << 256
+        return np.array([(v >> (64 * k)) & ((1 << 64) - 1) for k in range(4)], dtype=np.uint64)
+
+    sc.MLSumcheck.verify(info, claim, [sc.ProverMsg(m) for m in good])  # the honest proof passes
+    for i in range(case["nv"]):
+        for j in range(good[i].shape[0]):
+            bad = [m.copy() for m in good]
+            bad[i][j] = plus_p(bad[i][j])
+            with pytest.raises(sc.SumcheckError, match="canonical") as e:
+                sc.MLSumcheck.verify(info, claim, [sc.ProverMsg(m) for m in bad])
+            assert e.value.code == _lib.SC_ERR_BAD_ARG
+    # the attack of the advisor's finding: both first-round values shifted by p, claim off by one (in Montgomery form: by R)
+    bad = [m.copy() for m in good]
+    bad[0][0], bad[0][1] = plus_p(bad[0][0]), plus_p(bad[0][1])
+    for c in (claim, field.from_int(H.hx(case["sum"]) - 1), field.from_int(H.hx(case["sum"]) + 1)):
+        with pytest.raises(sc.SumcheckError):
+            sc.MLSumcheck.verify(info, c, [sc.ProverMsg(m) for m in bad])
+    with pytest.raises(sc.SumcheckError, match="canonical"):
+        sc.MLSumcheck.verify(info, plus_p(claim) if int(claim[3]) < (1 << 62) else pl, [sc.ProverMsg(m) for m in good])
+    with pytest.raises(sc.SumcheckError, match="canonical"):
+        sc.interpolate_uni_poly(np.stack([pl, good[0][1]]), field.from_int(7))
+    with pytest.raises(sc.SumcheckError, match="canonical"):
+        sc.interpolate_uni_poly(good[0], pl)
+    # every message one evaluation short: stacks fine, must not be read with the wrong stride
+    short = [sc.ProverMsg(m[:-1].copy()) for m in good]
+    with pytest.raises(sc.SumcheckError, match="incorrect number of evaluations"):
+        sc.MLSumcheck.verify(info, claim, short)
+    # the C entry point refuses a proof buffer of the wrong length outright
+    flat = np.ascontiguousarray(np.stack(good))
+    point, exp = np.empty((case["nv"], 4), np.uint64), np.empty(4, np.uint64)
+    rc = sc.lib().sc_ml_verify(case["nv"], info.max_multiplicands, C.c_void_p(claim.ctypes.data), C.c_void_p(flat.ctypes.data),
+                               flat.shape[0] * flat.shape[1] - 1, None, C.c_void_p(point.ctypes.data), C.c_void_p(exp.ctypes.data))
+    assert rc == _lib.SC_ERR_BAD_ARG and b"incorrect number of evaluations" in sc.lib().sc_last_error()
 
 
 def test_interpolate_uni_poly():
