@@ -2,11 +2,18 @@
 """bench.py -- MLSumcheck prover field-ops/s (BLS12-381 Fr) on N MI355X (BASELINE.json's metric).
 
 A "step" is one complete MLSumcheck::prove over HBM-resident synthetic tables: every round's fused bind+sum
-kernels, the D2H of the round polynomial, the host Fiat-Shamir hash and the challenge going back as a kernel
-argument.  Workload at N=1: BASELINE config 3 (the configuration the metric is quoted on): nv=24, products
-[0,1,2,3],[4,5,6],[7,8],[9] over 10 tables (5 GiB).  At N>1 every rank holds a config-3-sized shard
-(weak scaling): the global instance has nv = 24 + log2 N variables, tables sharded by the high index bits,
-one integer all-reduce of the round polynomial per round over RCCL.
+kernels, the round polynomial landing on the host, the host Fiat-Shamir hash and the challenge going back.
+
+Workloads (named in config.workload):
+  --config 3 (default)  BASELINE config 3, the configuration the metric is quoted on: products [0,1,2,3],[4,5,6],[7,8],[9] over
+                        10 tables (5 GiB at nv=24).
+      --scaling strong (default)  the metric as worded, "nv=24 at 1/2/4/8 MI355X": the SAME nv=24 instance split N ways by the
+                                  high index bits (2^24/N entries of every table per GPU).
+      --scaling weak              every GPU holds a config-3-sized shard: global nv = 24 + log2 N.
+  --config 4            BASELINE config 4: one product of 3 tables, nv=28 (24 GiB), sharded N ways (nv_local = 28 - log2 N; N=1 holds
+                        the whole instance, 38 GiB with the bound-table buffers).
+At N>1 the proof is one sc_ml_prove_sharded call per rank (local rounds with one integer all-reduce of the round polynomial per
+round over RCCL, bind + all-gather, log2 N tail rounds), one process per GPU.
 
 value = field_ops(global instance) / t, field_ops as executed by the reference algorithm:
   (2^nv - 1) * sum_k (2 m_k D + m_k + D) + 3 U (2^nv - 2).
@@ -46,43 +53,74 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(shapes, n_tables, budget_s=15.0):
-    """The CPU restatement of the reference algorithm (oracle/oracle.c, rayon-shaped OpenMP) timed on this host's
-    cores on a bounded sample of the same workload shape (same products, smaller nv)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(shapes, n_tables, nv_full=24, budget_s=12.0):
+    """The CPU restatement of the reference algorithm (oracle/oracle.c: the loop nest of prover.rs:110-148 in rayon-shaped OpenMP,
+    >= 1024-point chunks, bind parallel across tables only as prover.rs:87) timed on this host's cores on a bounded sample of the
+    same workload, in the three flavours SURVEY 8(d) asks for: all cores (the reported value), one thread, and all cores with the
+    bind also parallel inside a table ("improved": NOT what the reference does)."""
     from oracle import cref
     threads = cref.max_threads()
+    coefs = cref.synth_table(SEED, 1000, len(shapes))
 
-    def run(nv):
+    def run(nv, nthreads, improved=False):
         tabs = [cref.synth_table(SEED, s, 1 << nv) for s in range(n_tables)]
-        coefs = cref.synth_table(SEED, 1000, len(shapes))
         d = cref.PolyDesc(nv, [(coefs[k], s) for k, s in enumerate(shapes)], tabs)
         t0 = time.perf_counter()
-        cref.ml_prove(d, threads=threads)
+        if improved:
+            rng = cref.Rng()
+            rng.feed_poly_info(d.max_multiplicands, nv)
+            pr = cref.Prover(d, threads=nthreads, improved_fix=True)
+            r = None
+            for _ in range(nv):  # mod.rs:57-64
+                m = pr.prove_round(r)
+                rng.feed_prover_msg(m)
+                r = rng.sample_fr()
+            pr.close()
+        else:
+            cref.ml_prove(d, threads=nthreads)
         return time.perf_counter() - t0
 
-    nv = 18
-    t = run(nv)
-    rate = field_ops(nv, shapes, n_tables) / t
-    nv_big = nv
-    while nv_big < 24 and field_ops(nv_big + 1, shapes, n_tables) / rate < budget_s:
-        nv_big += 1
-    if nv_big > nv:
-        t = run(nv_big)
-        rate = field_ops(nv_big, shapes, n_tables) / t
-    while nv_big < 24 and 2.2 * t < budget_s:  # small instances parallelise worse: re-estimate from the last sample
-        nv_big += 1
-        t = run(nv_big)
-        rate = field_ops(nv_big, shapes, n_tables) / t
-    return {"value": rate, "unit": "field-ops/s", "cores": threads, "kind": "port",
-            "sample": f"same products at nv={nv_big} ({field_ops(nv_big, shapes, n_tables):.3e} field-ops, {t:.1f} s, OpenMP {threads} threads)"}
+    def sized(nthreads, improved, budget):  # the largest nv <= nv_full whose run fits the budget, found by doubling
+        nv = 14 if nthreads == 1 else 18
+        t = run(nv, nthreads, improved)
+        while nv < nv_full and 2.3 * t < budget:
+            nv += 1
+            t = run(nv, nthreads, improved)
+        return {"value": field_ops(nv, shapes, n_tables) / t, "unit": "field-ops/s", "cores": nthreads,
+                "sample": f"same products at nv={nv} ({field_ops(nv, shapes, n_tables):.3e} field-ops, {t:.2f} s)"}
+
+    allc = sized(threads, False, budget_s)
+    one = sized(1, False, budget_s / 2)
+    imp = sized(threads, True, budget_s)
+    return {"value": allc["value"], "unit": "field-ops/s", "cores": threads, "kind": "port",
+            "sample": allc["sample"] + f", OpenMP {threads} threads", "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+            "one_thread": one, "all_cores_improved_bind": imp,
+            "note": "port = oracle/oracle.c, a C restatement of the reference algorithm (the Rust reference cannot be built here); "
+                    "all_cores_improved_bind parallelises fix_variables inside a table, which the reference does not"}
+
+
+C4_SHAPES = [[0, 1, 2]]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nv-local", type=int, default=24, help="variables per GPU shard (24 = BASELINE config 3)")
+    ap.add_argument("--config", type=int, default=3, choices=(3, 4), help="BASELINE config: 3 = the metric's workload (default), 4 = nv=28 sharded")
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
+                    help="config 3 at N>1: strong = the nv=24 instance split N ways (the metric as worded), weak = nv=24 per GPU")
+    ap.add_argument("--nv", type=int, default=0, help="override the GLOBAL number of variables (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -96,11 +134,33 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     assert world & (world - 1) == 0, "the shard count must be a power of two"
     # SC_BENCH_ONE_GPU=1 (tests only): every rank uses GPU 0 and the ranks exchange through gloo -- the multi-rank plumbing of
-    # this file on a one-GPU box (RCCL refuses two ranks on one device, so the rounds run through the torch.distributed loop,
-    # the same code the bench falls back to on any RCCL failure).  The numbers of such a run mean nothing.
+    # this file on a one-GPU box (RCCL refuses two ranks on one device, so the library's collectives go through its host
+    # transport over torch.distributed).  The numbers of such a run mean nothing.
     one_gpu = os.environ.get("SC_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
+    k = world.bit_length() - 1
+    if args.config == 4:
+        shapes, U, nv_total, scaling = C4_SHAPES, 3, 28, "strong"
+    else:
+        shapes, U = C3_SHAPES, 10
+        scaling = args.scaling
+        nv_total = 24 + (k if scaling == "weak" else 0)
+    if args.nv:
+        nv_total = args.nv
+    nv_local = nv_total - k
+    n_loc = 1 << nv_local
+
+    # The CPU leg runs FIRST (rank 0, N=1 only), so that the GPU leg is the last thing this command does and an outside
+    # sampler of GPU activity sees it.
+    force_sharded = os.environ.get("SC_BENCH_FORCE_SHARDED") == "1"  # exercise the N>1 code path on one GPU (tests)
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and not force_sharded:
+        try:
+            cpu = cpu_baseline(shapes, U, nv_full=min(nv_total, 24))
+        except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+            cpu = {"value": None, "unit": "field-ops/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     _lib.check(sc.lib().sc_set_device(local_rank))
@@ -111,12 +171,6 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-
-    shapes, U = C3_SHAPES, 10
-    nv_local = args.nv_local
-    k = world.bit_length() - 1
-    nv_total = nv_local + k
-    n_loc = 1 << nv_local
 
     # synthetic tables generated on the device; rank g holds entries [g*2^nv_local, (g+1)*2^nv_local) of every table
     tables = []
@@ -129,9 +183,7 @@ def main():
     coefs = ct.cpu().numpy().view(np.uint64)
     torch.cuda.synchronize()
 
-    ncomm = None
-    state_box = {"ncomm": None}
-    force_sharded = os.environ.get("SC_BENCH_FORCE_SHARDED") == "1"  # exercise the N>1 code path on one GPU (tests)
+    round_loop = "library"
     if world == 1 and not force_sharded:
         mles = [sc.DenseMultilinearExtension(nv_local, t) for t in tables]
         poly = sc.ListOfProductsOfPolynomials(nv_local)
@@ -146,29 +198,27 @@ def main():
     else:
         engine = sharded.HipShardEngine(nv_local, shapes, coefs, tables, dev, borrow=True)
         handle = engine._h
-        comm = sharded.DistComm()
-        tail_factory = sharded.TailEngines(shapes, coefs, dev)  # the log2(N)-variable tail prover is built once, reloaded per proof
-
-        ncomm = None
-        if os.environ.get("SC_BENCH_PYTHON_ROUNDS") != "1" and not one_gpu:
-            try:  # per-round all-reduce inside the library (RCCL on the prover's stream); the Python loop is the fallback
-                ncomm = sharded.NativeComm(dev)
+        box = {"comm": None, "python": os.environ.get("SC_BENCH_PYTHON_ROUNDS") == "1"}
+        if not box["python"]:
+            try:  # the whole sharded proof inside the library: RCCL on the prover's stream, or (one-GPU test mode) its host transport
+                box["comm"] = sharded.HostComm.over_torch_distributed() if one_gpu else sharded.NativeComm(dev)
+                round_loop = "library+host-transport(gloo)" if one_gpu else "library+rccl"
             except Exception as e:
-                log(f"[bench] in-library RCCL rounds unavailable ({e}); using the torch.distributed round loop")
-                ncomm = None
-
-        state_box = {"ncomm": ncomm}
+                log(f"[bench] in-library sharded proof unavailable ({e}); using the torch.distributed round loop")
+                box["python"] = True
+        dcomm = sharded.DistComm()
+        tail_factory = sharded.TailEngines(shapes, coefs, dev)  # only the Python loop uses it
 
         def step():
             engine.reset()
-            if state_box["ncomm"] is not None:
+            if not box["python"]:
                 try:
-                    return sharded.prove_sharded_native(engine, state_box["ncomm"], comm, nv_total, max(len(s) for s in shapes), tail_factory)[0]
+                    return sharded.prove_sharded_library(engine, box["comm"], nv_total)[0]
                 except Exception as e:  # same on every rank (collective failure): drop to the torch.distributed loop for good
-                    log(f"[bench] in-library RCCL rounds failed ({e}); falling back to the torch.distributed round loop")
-                    state_box["ncomm"] = None
+                    log(f"[bench] in-library sharded proof failed ({e}); falling back to the torch.distributed round loop")
+                    box["python"] = True
                     engine.reset()
-            return sharded.prove_sharded([engine], comm, nv_total, max(len(s) for s in shapes), tail_factory)[0]
+            return sharded.prove_sharded([engine], dcomm, nv_total, max(len(s) for s in shapes), tail_factory)[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -196,6 +246,10 @@ def main():
         te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
+        if box["python"]:
+            round_loop = "torch.distributed"
+    elif force_sharded and box["python"]:
+        round_loop = "torch.distributed"
 
     K = len(shapes)
     ms = (C.c_double * K)()
@@ -206,13 +260,11 @@ def main():
     if rank == 0:
         ops = field_ops(nv_total, shapes, U)
         value = ops * args.steps / elapsed
-        # dominant kernel: k_round_tree (all products; or k_prod_tree<4>, product 0, with SC_MERGE=0).  It is launched once per BIG round (more than 2^16
-        # pairs; later rounds are latency-bound and run through k_fix_multi / k_sum_combos).  Algorithmic bytes of those launches:
-        # round 1 reads the product's tables once; round i >= 2 reads T_{i-1} and writes T_i (32-byte elements).
-        # With every product at <= 4 multiplicands the library runs a big round as ONE launch, k_round_tree, over all products:
-        # its event pair is reported under product 0 and the other products report no launches.
+        # dominant kernel: k_round_tree (every product of the round in one launch), launched once per BIG round (more than 2^16
+        # pairs on this GPU; later rounds are latency-bound and run through the small-round kernels).  Algorithmic bytes of those
+        # launches: round 1 reads the tables once; round i >= 2 reads T_{i-1} and writes T_i, 32 bytes per element.
         dom = int(np.argmax(list(ms)))
-        merged = K > 1 and ln[0] > 0 and all(ln[k] == 0 for k in range(1, K))
+        merged = ln[0] > 0 and all(ln[q] == 0 for q in range(1, K))
         u_dom = U if merged else len(set(shapes[dom]))
         kname = "k_round_tree" if merged else f"k_prod_tree<{len(shapes[dom])}>"
         big_rounds = max(nv_local - 17, 1) if nv_local > 17 else 0
@@ -224,43 +276,38 @@ def main():
         traffic = None  # measured off-line with rocprofv3 PMC passes (tools/profile.sh), per launch of the same kernel
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")))
-            if tj.get("kernel", "").endswith(kname) and nv_local == 24:
+            if tj.get("kernel", "").endswith(kname) and nv_local == 24 and args.config == 3:
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             pass
         # rounds_ms: event span of the rounds launched with events = the big rounds (late rounds are pipelined and record none)
         big_all_bytes = 32 * U * ((1 << nv_local) + sum((1 << (nv_local - i + 2)) + (1 << (nv_local - i + 1)) for i in range(2, big_rounds + 1)))
         big_rounds_gbps = big_all_bytes * args.steps / (rounds_ms.value * 1e-3) / 1e9 if rounds_ms.value > 0 else 0.0
+        cfg_name = ("BASELINE config 4" if args.config == 4 else "BASELINE config 3") + (f", {scaling} scaling" if world > 1 else "")
         out = {
-            "metric": "MLSumcheck prover field-ops/s (BLS12-381 Fr, nv=24)",
+            "metric": "MLSumcheck prover field-ops/s (BLS12-381 Fr, nv=24)" if args.config == 3 else "MLSumcheck prover field-ops/s (BLS12-381 Fr, nv=28, config 4)",
             "value": value, "unit": "field-ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": float(np.median(step_s)) * 1e3, "ms_per_step_min": min(step_s) * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u256 (BLS12-381 Fr, Montgomery form; integer arithmetic on 9 x 29-bit limbs)", "data": "synthetic",
-            "config": {"workload": f"MLSumcheck prove, ListOfProducts {shapes} over {U} tables, nv={nv_total}"
+            "config": {"workload": f"{cfg_name}: MLSumcheck prove, ListOfProducts {shapes} over {U} tables, nv={nv_total}"
                                    f" ({nv_local} per GPU shard), BLS12-381 Fr, tables HBM-resident",
                        "nv": nv_total, "nv_per_gpu": nv_local, "tables": U, "degree": max(len(s) for s in shapes),
                        "field_ops_per_step": ops, "sharding": f"high-bit x{world}" if world > 1 else "none",
-                       "round_loop": ("library+rccl" if (world > 1 or force_sharded) and state_box["ncomm"] is not None else
-                                      ("torch.distributed" if (world > 1 or force_sharded) else "library"))},
+                       "round_loop": round_loop},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "kernel": f"{kname} ({'all products, one launch per big round' if merged else f'product {dom}, big rounds'})",
                          "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "big_rounds_GBps_incl_finalize": big_rounds_gbps, "big_rounds_ms_per_step": rounds_ms.value / args.steps,
+                         "whole_proof_GBps": algorithmic_bytes(nv_local, U) * args.steps / elapsed / 1e9,
                          "per_product_ms_per_step": [m / args.steps for m in ms],
                          # reference-algorithm multiplications per second over the measured Montgomery-product
                          # ceiling of the chip (137.6 G/s, saturated Comba product, profiles/r1_modmul_ceiling.txt).  It can
                          # exceed 1: the kernels execute fewer products than the reference algorithm (nodes, product tree).
                          "modmul_fraction": (((1 << nv_total) - 1) * sum(len(sh) * (max(len(x) for x in shapes) + 1) for sh in shapes)
                                              + U * ((1 << nv_total) - 2)) * args.steps / elapsed / 137.6e9 / world},
+            "cpu_baseline": cpu,
         }
-        if world == 1 and not args.no_cpu_baseline and not force_sharded:
-            try:
-                out["cpu_baseline"] = cpu_baseline(shapes, U)
-            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
-                out["cpu_baseline"] = {"value": None, "unit": "field-ops/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-        else:
-            out["cpu_baseline"] = None
         try:  # RCCL prints its NCCL_DEBUG=VERSION banner through C stdio: push it out first so the JSON line is the last line
             C.CDLL(None).fflush(None)
         except Exception:

@@ -17,7 +17,9 @@
  * DenseMultilinearExtension).
  *
  * OWNERSHIP.  sc_prover_init copies its inputs (as prover_init deep-copies, prover.rs:55-59) unless
- * SC_TABLES_BORROW is set; it never writes caller memory.  A handle owns its device memory until
+ * SC_TABLES_BORROW is set; it never writes caller memory.  Device tables that are COPIED (init or reset) are read after a
+ * device-wide synchronise, so work still in flight on the caller's streams that produces them is waited for.  BORROWED device
+ * tables are read by kernels on the handle's stream: the caller must have synchronised their producer before the first round.  A handle owns its device memory until
  * sc_prover_free.  Outputs go to caller-owned host buffers unless the parameter says "device".
  *
  * THREADING.  One handle = one host thread at a time.  Distinct handles are independent.  Calls are
@@ -108,16 +110,33 @@ SC_API int sc_wide_reduce(const uint64_t *wide, uint32_t n_elems, uint64_t *out)
  * device), asynchronous on the handle's stream.  After this the handle is exhausted. */
 SC_API int sc_prover_bind_final(sc_prover *p, const uint64_t *r, uint64_t *d_out);
 
-/* Sharded rounds inside the library: one RCCL all-reduce (sum, uint64) of the widened round polynomial per round on the
- * handle's stream.  RCCL is bound at run time (dlopen).  Rank 0 creates the 128-byte unique id and ships it to the other
- * ranks by any means (bench.py: torch.distributed broadcast); every rank then calls sc_comm_init on its own device.
- * sc_ml_prove_sharded_rounds runs the first n_rounds rounds of MLSumcheck::prove_as_subprotocol (mod.rs:54-64) for the
- * GLOBAL instance of nv_total variables on this rank's shard (handle at round 0): out_proof n_rounds x (deg+1) x 4,
- * out_randomness n_rounds x 4, identical on every rank. */
+/* Multi-GPU proofs inside the library.  PROCESS MODEL: one sc_prover per GPU, each holding one contiguous
+ * high-bit shard of every table (rank g: entries [g * 2^nv_local, (g+1) * 2^nv_local)), driven by one host thread per GPU --
+ * either one process per GPU (torchrun, MPI) or one thread per GPU inside one process (sc_set_device is per thread; this is how
+ * a Rust host would use it).  There is no single-handle "n_gpus" mode: every rank runs the same call and they meet in the
+ * collectives.  A communicator is
+ *   - an RCCL one: rank 0 creates the 128-byte unique id (sc_comm_unique_id) and ships it to the other ranks by any means;
+ *     every rank then calls sc_comm_init on its own device.  RCCL is bound at run time (dlopen).  The per-round all-reduce
+ *     (sum, uint64, (deg+1) x 8 lanes) and the tail's all-gather run on the handle's stream;
+ *   - or a HOST transport (sc_comm_init_host): two caller functions that exchange small host buffers (MPI, gloo, shared
+ *     memory between threads, ...).  allreduce sums `count` uint64 words in place over all ranks; allgather delivers every
+ *     rank's `bytes` bytes in rank order into recv (nranks * bytes).  Both return 0 on success.
+ * sc_ml_prove_sharded = MLSumcheck::prove_as_subprotocol (mod.rs:50-70) for the GLOBAL instance of nv_total variables: the
+ * nv_total - log2(nranks) local rounds, then bind + all-gather + the last log2(nranks) rounds on the gathered tables.
+ * p: this rank's shard, at round 0.  out_proof: nv_total x (deg+1) x 4, out_randomness: nv_total x 4 -- identical on every
+ * rank.  rng_or_null: NULL = a fresh transcript.  nranks must be a power of two.
+ * sc_ml_prove_sharded_rounds: only the first n_rounds local rounds (PolynomialInfo of the global instance is fed first). */
 typedef struct sc_comm sc_comm;
+typedef int (*sc_allreduce_u64_fn)(void *ctx, uint64_t *inout, size_t count);
+typedef int (*sc_allgather_fn)(void *ctx, const void *send, void *recv, size_t bytes);
 SC_API int sc_comm_unique_id(uint8_t *out128);
 SC_API int sc_comm_init(const uint8_t *id128, int rank, int nranks, sc_comm **out);
+SC_API int sc_comm_init_host(int rank, int nranks, sc_allreduce_u64_fn allreduce, sc_allgather_fn allgather, void *ctx, sc_comm **out);
+/* diagnostic, collective: one all-reduce and one all-gather of known patterns over the communicator, checked on every rank */
+SC_API int sc_comm_selftest(sc_comm *comm);
 SC_API void sc_comm_free(sc_comm *comm);
+SC_API int sc_ml_prove_sharded(sc_prover *p, sc_comm *comm, sc_rng *rng_or_null, uint32_t nv_total, uint64_t *out_proof,
+                               uint64_t *out_randomness);
 SC_API int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *rng, uint32_t nv_total, uint32_t n_rounds, uint64_t *out_proof,
                                       uint64_t *out_randomness);
 

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libsumcheck_hip.so")
+# SC_LIB_VARIANT=exp (tests/test_gpu_variants.py only): the -DSC_EXPERIMENTS build with the cross-check kernels and their knobs
+SO_PATH = os.path.join(HERE, "libsumcheck_hip_exp.so" if os.environ.get("SC_LIB_VARIANT") == "exp" else "libsumcheck_hip.so")
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
@@ -61,7 +62,10 @@ SIGNATURES = {
     "sc_prover_bind_final": (C.c_int, [_V, _V, _V]),
     "sc_comm_unique_id": (C.c_int, [_V]),
     "sc_comm_init": (C.c_int, [_V, C.c_int, C.c_int, C.POINTER(_V)]),
+    "sc_comm_init_host": (C.c_int, [C.c_int, C.c_int, _V, _V, _V, C.POINTER(_V)]),
+    "sc_comm_selftest": (C.c_int, [_V]),
     "sc_comm_free": (None, [_V]),
+    "sc_ml_prove_sharded": (C.c_int, [_V, _V, _V, C.c_uint32, _V, _V]),
     "sc_ml_prove_sharded_rounds": (C.c_int, [_V, _V, _V, C.c_uint32, C.c_uint32, _V, _V]),
     "sc_fix_variables": (C.c_int, [_V, C.c_uint32, _V, C.c_uint32, _V, C.c_uint32]),
     "sc_poly_evaluate": (C.c_int, [_V, _V, _V, _V]),

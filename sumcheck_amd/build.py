@@ -1,4 +1,11 @@
-"""Build libsumcheck_hip.so (gfx950) in-tree with hipcc.  Cross-compiles without a GPU."""
+"""Build libsumcheck_hip.so (gfx950) in-tree with hipcc.  Cross-compiles without a GPU.
+
+Two libraries come out of the same sources:
+  libsumcheck_hip.so      the product: one production path (product-tree kernel, carry-free arithmetic, F29 bound tables) plus the
+                          generic fallback for very long products;
+  libsumcheck_hip_exp.so  -DSC_EXPERIMENTS: additionally the cross-check kernels (saturated Comba arithmetic, node-by-node, LDS-tiled)
+                          and the environment knobs that select them.  Loaded only by tests/test_gpu_variants.py (SC_LIB_VARIANT=exp).
+"""
 from __future__ import annotations
 
 import os
@@ -8,40 +15,60 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsumcheck_hip.so")
+OUT_EXP = os.path.join(HERE, "libsumcheck_hip_exp.so")
 SOURCES = ["kernels.hip", "gkr.hip", "api.hip"]
-HEADERS = ["fr.cuh", "fe.cuh", "fr_mac.inc", "fr_mul_gen.inc", "kernels.h", "host_fr.hpp", "transcript.hpp", os.path.join("..", "..", "include", "sumcheck_hip.h")]
+HEADERS = ["fr_device.hpp", "fe_device.hpp", "fr_mac.inc", "fr_mul_gen.inc", "kernels.h", "host_fr.hpp", "transcript.hpp", os.path.join("..", "..", "include", "sumcheck_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(OUT):
+def _stale(out: str) -> bool:
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
+    t = os.path.getmtime(out)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return OUT
+def _start(experiments: bool, verbose: bool):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    bdir = os.path.join(HERE, "build_exp" if experiments else "build")
+    os.makedirs(bdir, exist_ok=True)
+    procs, objs = [], []
     for s in SOURCES:
-        o = os.path.join(HERE, "build", s + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        o = os.path.join(bdir, s + ".o")
+        cmd = [hipcc] + FLAGS + (["-DSC_EXPERIMENTS"] if experiments else []) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(o)
+    return hipcc, procs, objs
+
+
+def _finish(hipcc, procs, objs, out):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
-    subprocess.check_call(cmd)
-    return OUT
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    return out
+
+
+def build(force: bool = False, verbose: bool = False, experiments: bool = False) -> str:
+    out = OUT_EXP if experiments else OUT
+    if not force and not _stale(out):
+        return out
+    return _finish(*_start(experiments, verbose), out)
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    """both libraries, compiled concurrently"""
+    jobs = []
+    for exp, out in ((False, OUT), (True, OUT_EXP)):
+        if force or _stale(out):
+            jobs.append((_start(exp, verbose), out))
+    for st, out in jobs:
+        _finish(*st, out)
+    return OUT, OUT_EXP
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build_all(force="--force" in sys.argv, verbose=True))

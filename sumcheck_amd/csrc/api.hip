@@ -150,6 +150,9 @@ struct sc_prover {
     uint64_t *d_wide = nullptr;      // sharded rounds inside the library: all-reduce buffer (D x 8 lanes) ...
     uint64_t *h_wide = nullptr;      // ... and its host-mapped landing page
     uint64_t *h_wide_dev = nullptr;
+    void *d_tail_send = nullptr, *d_tail_recv = nullptr, *d_tail_tabs = nullptr; // sc_ml_prove_sharded: bind_final out, all-gather out, G-entry tables
+    sc_prover *tail = nullptr;       // ... and the log2 G-variable prover over them (built once, rewound per proof)
+    std::vector<std::vector<uint32_t>> prod_indices; // the descriptor's product lists as given (for the tail's descriptor)
     Combo *d_combos = nullptr;    // (product, point) combinations for the small-round kernel
     std::vector<FinProd> h_finprods; // host copy of d_finprods (kernel-argument path of k_finalize)
     scd::ComboMeta meta;          // the same metadata as a kernel argument (when it fits: has_meta)
@@ -161,12 +164,6 @@ struct sc_prover {
     uint32_t *d_slot_table = nullptr, *d_slot_exp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    // products over pairwise disjoint tables may run concurrently (SC_STREAMS=1): one side stream per product, forked after
-    // the round's start event and joined before finalize
-    bool par_products = false;
-    std::vector<hipStream_t> pstreams;
-    std::vector<hipEvent_t> pjoin;
-    hipEvent_t ev_fork = nullptr;
     // pipelined late rounds (sc_ml_prove_handle, GKR): the next round is enqueued behind a one-lane wait kernel before the
     // current round's message has been hashed; its bind kernel reads the challenge from the host-mapped mailbox
     uint32_t *sig = nullptr;        // host-mapped word the wait kernel polls (after the two mailbox slots)
@@ -175,14 +172,14 @@ struct sc_prover {
     FrHost *h_mail = nullptr;       // host-mapped, two slots (+ the word above)
     FrHost *h_mail_dev = nullptr;
     FrHost *d_mail = nullptr;       // device-memory copy of the slot in use (two slots), filled by the wait kernel
-    uint32_t *sigmem = nullptr;     // SC_PIPELINE=2: signal memory for a command-processor wait in front of the wait kernel
     bool pipeline_ok = true;        // cleared when the wait-value path is unavailable (or SC_PIPELINE=0)
     bool deferred_pending = false;  // a round is enqueued behind the wait and still needs its challenge
-    bool merge_rounds = false; // big rounds run as ONE launch over all products (k_round_tree); SC_MERGE=0 disables
-    int rotate = 1;            // product rotation inside that launch (SC_ROTATE, see RoundArgs)
+    bool merge_rounds = false; // big rounds run as ONE launch over all products (k_round_tree): <= kMaxRoundProds products of <= 4 multiplicands
     bool use_f29 = false; // bound tables of big rounds kept in the internal 9 x 29-bit format (all products <= 4 multiplicands)
-    bool use_fe = true; // big rounds in carry-free arithmetic (fe.cuh); SC_FE=0 selects the saturated kernels
-    int kernel_variant = 3; // SC_KERNEL: 0 = lane-per-pair (k_prod_round[_fe]), 2 = tiled LDS-staged (k_round_tile), 3 = product tree
+    // The production path is fixed: product tree, carry-free arithmetic.  A -DSC_EXPERIMENTS build (libsumcheck_hip_exp.so, used by
+    // tests/test_gpu_variants.py) lets the environment select the cross-check kernels instead.
+    bool use_fe = true;     // experiments: SC_FE=0 selects the saturated (Comba asm) kernels
+    int kernel_variant = 3; // experiments: SC_KERNEL 0 = node by node (k_prod_round[_fe]), 2 = tiled LDS-staged (k_round_tile), 3 = product tree
     // reset support + per-product instrumentation
     bool borrow = false;
     std::vector<const uint4 *> origin; // borrowed table pointers (borrow mode)
@@ -200,7 +197,6 @@ static void prover_destroy(sc_prover *p) {
     (void)hipSetDevice(p->device);
     if (p->deferred_pending && p->sig) { // release a stream that still waits for a challenge before synchronising it
         __atomic_store_n(p->sig, p->sig_seq, __ATOMIC_RELEASE);
-        if (p->sigmem) __atomic_store_n(p->sigmem, p->sig_seq, __ATOMIC_RELEASE);
         p->deferred_pending = false;
     }
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
@@ -212,12 +208,15 @@ static void prover_destroy(sc_prover *p) {
     if (p->d_out) (void)hipFree(p->d_out);
     if (p->h_out) (void)hipHostFree(p->h_out);
     if (p->h_flag) (void)hipHostFree(p->h_flag);
+    if (p->tail) prover_destroy(p->tail);
+    if (p->d_tail_send) (void)hipFree(p->d_tail_send);
+    if (p->d_tail_recv) (void)hipFree(p->d_tail_recv);
+    if (p->d_tail_tabs) (void)hipFree(p->d_tail_tabs);
     if (p->d_wide) (void)hipFree(p->d_wide);
     if (p->h_wide) (void)hipHostFree(p->h_wide);
     if (p->d_combos) (void)hipFree(p->d_combos);
     if (p->h_mail) (void)hipHostFree(p->h_mail);
     if (p->d_mail) (void)hipFree(p->d_mail);
-    if (p->sigmem) (void)hipFree(p->sigmem);
     if (p->d_cur_tables) (void)hipFree(p->d_cur_tables);
     if (p->h_cur_tables) (void)hipHostFree(p->h_cur_tables);
     if (p->d_slot_table) (void)hipFree(p->d_slot_table);
@@ -225,9 +224,6 @@ static void prover_destroy(sc_prover *p) {
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     for (hipEvent_t e : p->prod_ev) (void)hipEventDestroy(e);
-    for (hipEvent_t e : p->pjoin) (void)hipEventDestroy(e);
-    for (hipStream_t st : p->pstreams) (void)hipStreamDestroy(st);
-    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     delete p;
 }
@@ -305,10 +301,17 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     p->K = d->n_products;
     p->U = d->n_tables;
     p->randomness.reserve(p->nv);
+#ifdef SC_EXPERIMENTS
     if (const char *e = std::getenv("SC_FE")) p->use_fe = std::atoi(e) != 0;
     if (const char *e = std::getenv("SC_KERNEL")) p->kernel_variant = std::atoi(e);
+    // one arithmetic per round: k_finalize's 2^(5(M-1)) compensation is chosen per round, so the saturated kernels never share a
+    // round with the (carry-free) tree kernel
+    if (!p->use_fe && p->kernel_variant == 3) p->kernel_variant = 0;
+#endif
     p->use_f29 = p->kernel_variant == 3;
+#ifdef SC_EXPERIMENTS
     if (const char *e = std::getenv("SC_F29")) p->use_f29 = p->use_f29 && std::atoi(e) != 0;
+#endif
     for (uint32_t k = 0; k < d->n_products; ++k)
         if (d->prod_offsets[k + 1] - d->prod_offsets[k] > 4) p->use_f29 = false;
     // with more tables than the small-round kernels take, the big-round kernels also run the short rounds, whose tables are
@@ -317,8 +320,9 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     p->merge_rounds = p->kernel_variant == 3 && d->n_products > 0 && d->n_products <= (uint32_t)scd::kMaxRoundProds;
     for (uint32_t k = 0; k < d->n_products; ++k)
         if (d->prod_offsets[k + 1] - d->prod_offsets[k] > 4) p->merge_rounds = false;
+#ifdef SC_EXPERIMENTS
     if (const char *e = std::getenv("SC_MERGE")) p->merge_rounds = p->merge_rounds && std::atoi(e) != 0;
-    if (const char *e = std::getenv("SC_ROTATE")) p->rotate = std::atoi(e);
+#endif
 
     // products: distinct tables + multiplicities
     uint64_t partial_elems = 0;
@@ -340,6 +344,7 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
                 pr.exps[it - pr.tables.begin()]++;
             }
         }
+        p->prod_indices.emplace_back(d->prod_indices + d->prod_offsets[k], d->prod_indices + d->prod_offsets[k + 1]);
         pr.M = d->prod_offsets[k + 1] - d->prod_offsets[k];
         pr.fused = pr.M <= (uint32_t)scd::kMaxFusedM;
         if (!pr.fused) p->any_generic = true;
@@ -383,6 +388,9 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     HIP_TRY(hipMalloc(&p->arena, per_table * p->U));
     p->tabs.resize(p->U);
     p->borrow = borrow;
+    // Device tables are copied on the handle's own non-blocking stream, which is ordered after nothing the caller enqueued:
+    // wait for whatever produced them (any stream of this device) before reading.
+    if (on_device && !borrow) HIP_TRY(hipDeviceSynchronize());
     for (uint32_t u = 0; u < p->U; ++u) {
         Table &t = p->tabs[u];
         char *base = static_cast<char *>(p->arena) + per_table * u;
@@ -434,27 +442,6 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
         HIP_TRY(hipMalloc(&p->d_cur_tables, p->U * sizeof(void *)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_cur_tables), p->U * sizeof(void *), hipHostMallocDefault));
     }
-    if (const char *e = std::getenv("SC_STREAMS")) {
-        if (std::atoi(e) != 0 && p->K > 1) {
-            std::vector<int> owner(p->U, -1);
-            bool disjoint = true;
-            for (uint32_t k = 0; k < p->K; ++k)
-                for (uint32_t t : p->prods[k].tables) {
-                    if (owner[t] >= 0 && owner[t] != (int)k) disjoint = false;
-                    owner[t] = (int)k;
-                }
-            if (disjoint) {
-                p->par_products = true;
-                p->pstreams.resize(p->K);
-                p->pjoin.resize(p->K);
-                for (uint32_t k = 0; k < p->K; ++k) {
-                    HIP_TRY(hipStreamCreateWithFlags(&p->pstreams[k], hipStreamNonBlocking));
-                    HIP_TRY(hipEventCreateWithFlags(&p->pjoin[k], hipEventDisableTiming));
-                }
-                HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-            }
-        }
-    }
     HIP_TRY(hipStreamSynchronize(p->stream)); // inputs are copied: the caller may drop them now (prover.rs:55-59)
     return SC_OK;
 }
@@ -501,12 +488,16 @@ static int collect_timing(sc_prover *p) {
 
 // Launch one round's kernels on p->stream.  On return the round polynomial is in p->d_out (and in
 // d_wide if non-null); nothing has been synchronised.
-static uint64_t small_pairs_limit() { // SC_SMALL_LOG2: experiment knob for the big/small round boundary
+static uint64_t small_pairs_limit() { // the big/small round boundary
+#ifdef SC_EXPERIMENTS // SC_SMALL_LOG2
     static const uint64_t v = [] {
         const char *e = std::getenv("SC_SMALL_LOG2");
         return e ? (1ULL << std::atoi(e)) : scd::kSmallRoundPairs;
     }();
     return v;
+#else
+    return scd::kSmallRoundPairs;
+#endif
 }
 
 // One-time probe per process: does a kernel launch return before the kernel has finished?  A wait kernel with a short bound
@@ -545,7 +536,7 @@ static bool can_defer_next(sc_prover *p) {
         const char *env = std::getenv("SC_PIPELINE"); // read per handle, at its first late round
         bool env_off = env && std::atoi(env) == 0;
         // a runtime that makes every launch wait for its kernel would block on the wait kernel until its bound expires
-        for (const char *name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING"}) {
+        for (const char *name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"}) {
             const char *v = std::getenv(name);
             if (v && std::atoi(v) != 0) env_off = true;
         }
@@ -553,11 +544,6 @@ static bool can_defer_next(sc_prover *p) {
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->h_mail), 2 * sizeof(FrHost) + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
         ok = ok && hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_mail_dev), p->h_mail, 0) == hipSuccess;
         ok = ok && hipMalloc(reinterpret_cast<void **>(&p->d_mail), 2 * sizeof(FrHost)) == hipSuccess;
-        const bool cp_wait = env && std::atoi(env) == 2;
-        if (ok && cp_wait) {
-            ok = hipExtMallocWithFlags(reinterpret_cast<void **>(&p->sigmem), 8, hipMallocSignalMemory) == hipSuccess;
-            if (ok) *reinterpret_cast<volatile uint64_t *>(p->sigmem) = 0;
-        }
         if (ok) {
             p->sig = reinterpret_cast<uint32_t *>(p->h_mail + 2);
             p->sig_dev = reinterpret_cast<uint32_t *>(p->h_mail_dev + 2);
@@ -584,7 +570,6 @@ static void provide_challenge(sc_prover *p, const sch::Fr &r) {
     std::memcpy(slot, &r, sizeof(FrHost));
     __atomic_thread_fence(__ATOMIC_RELEASE);
     __atomic_store_n(p->sig, p->sig_seq, __ATOMIC_RELEASE);
-    if (p->sigmem) __atomic_store_n(p->sigmem, p->sig_seq, __ATOMIC_RELEASE);
     p->deferred_pending = false;
 }
 // the give-up marker of k_wait_challenge (non-zero once any wait of this handle has expired; cleared by sc_prover_reset)
@@ -593,7 +578,6 @@ static bool wait_gave_up(sc_prover *p) { return p->sig && __atomic_load_n(p->sig
 static void abandon_deferred(sc_prover *p) {
     if (p->deferred_pending) {
         __atomic_store_n(p->sig, p->sig_seq, __ATOMIC_RELEASE);
-        if (p->sigmem) __atomic_store_n(p->sigmem, p->sig_seq, __ATOMIC_RELEASE);
         p->deferred_pending = false;
         (void)hipStreamSynchronize(p->stream);
         p->exhausted = true; // tables are no longer meaningful: the handle must be reset
@@ -630,9 +614,14 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     int scaled = 0;
     const uint64_t small_pairs = small_pairs_limit();
     const bool small_round = n_pairs <= small_pairs && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0;
+#ifdef SC_EXPERIMENTS
     const bool tiled = !small_round && !p->any_generic && p->kernel_variant == 2;
+#else
+    const bool tiled = false;
+    (void)tiled;
+#endif
     scd::BindConst rc; // (only the big rounds of the tree kernels pay for it)
-    std::memset(&rc, 0, sizeof(rc)); // tree kernels: rows (r * 2^(29 i + 58)) mod p as plain 29-bit limbs (fe.cuh, fe_mul_bind)
+    std::memset(&rc, 0, sizeof(rc)); // tree kernels: rows (r * 2^(29 i + 58)) mod p as plain 29-bit limbs (fe_device.hpp, fe_mul_bind)
     if (bind && !small_round && p->kernel_variant == 3) {
         static const std::array<sch::Fr, 9> pow2 = [] { // Montgomery form of 2^(29 i + 58)
             std::array<sch::Fr, 9> t;
@@ -654,14 +643,16 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
             }
         }
     }
-    int grid = tiled ? scd::grid_for_tiles(n_pairs) : scd::grid_for_pairs(n_pairs);
+    int grid = scd::grid_for_pairs(n_pairs);
+#ifdef SC_EXPERIMENTS
+    if (tiled) grid = scd::grid_for_tiles(n_pairs);
+#endif
     const bool timed = p->timing && !deferred;
     if (timed) HIP_TRY(hipEventRecord(p->ev0, p->stream));
     const FrHost *r_mail = nullptr;
     if (deferred) {
         if (!small_round) return fail(SC_ERR_BAD_ARG, "only late rounds are pipelined");
         p->sig_seq += 1;
-        if (p->sigmem) HIP_TRY(hipStreamWaitValue32(p->stream, p->sigmem, p->sig_seq, hipStreamWaitValueEq, 0xffffffffu));
         HIP_TRY(scd::launch_wait_challenge(p->sig_dev, p->sig_seq, p->h_mail_dev + (p->sig_seq & 1u), p->d_mail + (p->sig_seq & 1u), p->stream));
         r_mail = p->d_mail + (p->sig_seq & 1u);
         p->deferred_pending = true;
@@ -707,10 +698,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     }
     std::vector<uint8_t> bound(p->U, 0);
     bool ptrs_uploaded = false;
-    hipStream_t main_stream = p->stream;
-    const bool fork = p->par_products && !small;
-    if (fork) HIP_TRY(hipEventRecord(p->ev_fork, main_stream));
-    const bool merged = !small && !fork && p->merge_rounds && !p->any_generic;
+    const bool merged = !small && p->merge_rounds && !p->any_generic;
     if (merged) {
         grid = std::min(grid, scd::kRoundTreeGrid);
         // One launch for the round.  The first factor touching a table binds and stores it (mode 1); every later factor on
@@ -719,7 +707,6 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         scd::RoundArgs ra;
         std::memset(&ra, 0, sizeof(ra));
         ra.n_prod = (int)p->K;
-        ra.rotate = p->rotate;
         std::vector<const uint4 *> old_src(p->U);
         std::vector<const int32_t *> old_top(p->U);
         for (uint32_t u = 0; u < p->U; ++u) {
@@ -765,10 +752,6 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     for (uint32_t k = 0; k < p->K && !small && !merged; ++k) {
         const Product &pr = p->prods[k];
         FrHost *partials = p->d_partials + pr.partial_off;
-        if (fork) {
-            p->stream = p->pstreams[k];
-            HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_fork, 0));
-        }
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[2 * k], p->stream));
         if (pr.fused && p->kernel_variant == 3 && pr.M <= 4) {
             // product tree: one argument slot per FACTOR.  The first factor touching a table this round binds and stores it;
@@ -811,7 +794,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
             }
             HIP_TRY(scd::launch_prod_tree((int)pr.M, a, rc, n_pairs, partials, grid, p->stream));
             scaled = 1;
-        } else         if (pr.fused) {
+        } else if (pr.fused) {
             ProdArgs a;
             std::memset(&a, 0, sizeof(a));
             a.n_slots = (int)pr.tables.size();
@@ -831,14 +814,17 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
                     a.slot[s].dst = nullptr;
                 }
             }
+#ifdef SC_EXPERIMENTS
             if (tiled) {
                 HIP_TRY(scd::launch_round_tile((int)pr.M, a, r32, n_pairs, partials, grid, p->stream));
                 scaled = 1;
-            } else if (p->use_fe) {
+            } else if (!p->use_fe) {
+                HIP_TRY(scd::launch_prod_round((int)pr.M, a, rdev, n_pairs, partials, grid, p->stream));
+            } else
+#endif
+            {
                 HIP_TRY(scd::launch_prod_round_fe((int)pr.M, a, r32, n_pairs, partials, grid, p->stream));
                 scaled = 1;
-            } else {
-                HIP_TRY(scd::launch_prod_round((int)pr.M, a, rdev, n_pairs, partials, grid, p->stream));
             }
         } else {
             if (!ptrs_uploaded) {
@@ -850,11 +836,6 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
                                             (int)pr.tables.size(), (int)pr.M, n_pairs, partials, grid, p->stream));
         }
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[2 * k + 1], p->stream));
-        if (fork) {
-            HIP_TRY(hipEventRecord(p->pjoin[k], p->stream));
-            p->stream = main_stream;
-            HIP_TRY(hipStreamWaitEvent(main_stream, p->pjoin[k], 0));
-        }
     }
     if (bind) { // tables that no product refers to still follow the state machine
         for (uint32_t u = 0; u < p->U; ++u)
@@ -1089,6 +1070,7 @@ extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_nu
     } else {
         if (!tables_or_null) return fail(SC_ERR_BAD_ARG, "a copying handle needs the tables again to reset");
         const bool on_device = flags & SC_TABLES_ON_DEVICE;
+        if (on_device) HIP_TRY(hipDeviceSynchronize()); // the producer of the new tables may still be running on another stream
         for (uint32_t u = 0; u < p->U; ++u) {
             if (!tables_or_null[u]) return fail(SC_ERR_BAD_ARG, "table %u is null", u);
             HIP_TRY(hipMemcpyAsync(p->tabs[u].buf[0], tables_or_null[u], n * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -1516,6 +1498,7 @@ struct NcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
@@ -1529,15 +1512,22 @@ static int nccl_load() {
     g_nccl.GetUniqueId = reinterpret_cast<decltype(&ncclGetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     g_nccl.CommInitRank = reinterpret_cast<decltype(&ncclCommInitRank)>(dlsym(h, "ncclCommInitRank"));
     g_nccl.AllReduce = reinterpret_cast<decltype(&ncclAllReduce)>(dlsym(h, "ncclAllReduce"));
+    g_nccl.AllGather = reinterpret_cast<decltype(&ncclAllGather)>(dlsym(h, "ncclAllGather"));
     g_nccl.CommDestroy = reinterpret_cast<decltype(&ncclCommDestroy)>(dlsym(h, "ncclCommDestroy"));
     g_nccl.GetErrorString = reinterpret_cast<decltype(&ncclGetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    if (!g_nccl.GetUniqueId || !g_nccl.CommInitRank || !g_nccl.AllReduce || !g_nccl.CommDestroy) return fail(SC_ERR_HIP, "librccl lacks the NCCL entry points");
+    if (!g_nccl.GetUniqueId || !g_nccl.CommInitRank || !g_nccl.AllReduce || !g_nccl.AllGather || !g_nccl.CommDestroy)
+        return fail(SC_ERR_HIP, "librccl lacks the NCCL entry points");
     g_nccl.lib = h;
     return SC_OK;
 }
+// A communicator is either an RCCL one (collectives enqueued on the prover's stream, device buffers) or a HOST transport: two
+// caller-supplied functions that exchange host buffers (MPI, gloo, shared memory between the threads of one process, ...).
 struct sc_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    sc_allreduce_u64_fn h_allreduce = nullptr;
+    sc_allgather_fn h_allgather = nullptr;
+    void *ctx = nullptr;
 };
 #define NCCL_TRY(expr)                                                                                             \
     do {                                                                                                           \
@@ -1572,6 +1562,53 @@ extern "C" int sc_comm_init(const uint8_t *id128, int rank, int nranks, sc_comm 
     *out = c;
     return SC_OK;
 }
+extern "C" int sc_comm_init_host(int rank, int nranks, sc_allreduce_u64_fn allreduce, sc_allgather_fn allgather, void *ctx, sc_comm **out) {
+    if (!out || rank < 0 || rank >= nranks || (nranks > 1 && (!allreduce || !allgather))) return fail(SC_ERR_BAD_ARG, "bad argument");
+    sc_comm *c = new (std::nothrow) sc_comm();
+    if (!c) return fail(SC_ERR_OOM, "host allocation failed");
+    c->rank = rank;
+    c->nranks = nranks;
+    c->h_allreduce = allreduce;
+    c->h_allgather = allgather;
+    c->ctx = ctx;
+    *out = c;
+    return SC_OK;
+}
+// Diagnostic: one all-reduce and one all-gather of known patterns over the communicator, checked on every rank.
+extern "C" int sc_comm_selftest(sc_comm *c) {
+    if (!c) return fail(SC_ERR_BAD_ARG, "null argument");
+    const int G = c->nranks, n = 40;
+    std::vector<uint64_t> lanes(n), gathered((size_t)n * G);
+    for (int i = 0; i < n; ++i) lanes[i] = (uint64_t)(c->rank + 1) * (uint64_t)(i + 1) + ((uint64_t)(c->rank + 1) << 40);
+    const std::vector<uint64_t> mine = lanes;
+    if (c->comm) {
+        HIP_TRY(hipSetDevice(g_device));
+        uint64_t *d = nullptr, *dg = nullptr;
+        HIP_TRY(hipMalloc(&d, n * 8));
+        HIP_TRY(hipMalloc(&dg, (size_t)n * 8 * G));
+        HIP_TRY(hipMemcpy(d, lanes.data(), n * 8, hipMemcpyHostToDevice));
+        NCCL_TRY(g_nccl.AllGather(d, dg, (size_t)n, ncclUint64, c->comm, nullptr));
+        NCCL_TRY(g_nccl.AllReduce(d, d, (size_t)n, ncclUint64, ncclSum, c->comm, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        HIP_TRY(hipMemcpy(lanes.data(), d, n * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(gathered.data(), dg, (size_t)n * 8 * G, hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        (void)hipFree(dg);
+    } else if (G > 1) {
+        if (c->h_allgather(c->ctx, mine.data(), gathered.data(), (size_t)n * 8) != 0) return fail(SC_ERR_HIP, "the host transport's all-gather failed");
+        if (c->h_allreduce(c->ctx, lanes.data(), (size_t)n) != 0) return fail(SC_ERR_HIP, "the host transport's all-reduce failed");
+    } else {
+        gathered = mine;
+    }
+    const uint64_t tri = (uint64_t)G * (uint64_t)(G + 1) / 2;
+    for (int i = 0; i < n; ++i) {
+        if (lanes[i] != tri * (uint64_t)(i + 1) + (tri << 40)) return fail(SC_ERR_HIP, "all-reduce returned a wrong sum in word %d", i);
+        for (int g = 0; g < G; ++g)
+            if (gathered[(size_t)g * n + i] != (uint64_t)(g + 1) * (uint64_t)(i + 1) + ((uint64_t)(g + 1) << 40))
+                return fail(SC_ERR_HIP, "all-gather returned a wrong word (rank %d, word %d)", g, i);
+    }
+    return SC_OK;
+}
 extern "C" void sc_comm_free(sc_comm *c) {
     if (!c) return;
     if (c->comm && g_nccl.CommDestroy) (void)g_nccl.CommDestroy(c->comm);
@@ -1579,13 +1616,10 @@ extern "C" void sc_comm_free(sc_comm *c) {
 }
 
 // The first n_rounds rounds of MLSumcheck::prove_as_subprotocol (reference src/ml_sumcheck/mod.rs:54-64) on this rank's shard:
-// per round the shard's kernels, one ncclAllReduce(sum, uint64) of the (deg+1) x 8 zero-extended limbs on the same stream, a
-// tiny publish kernel, then -- on every rank identically -- fold, feed, sample.  The handle is left after round n_rounds (its
-// tables have two entries when n_rounds == its num_vars); *last_challenge is the challenge to bind next.
-extern "C" int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *rng, uint32_t nv_total, uint32_t n_rounds, uint64_t *out_proof,
-                                          uint64_t *out_randomness) {
-    if (!p || !comm || !rng || !out_proof || !out_randomness) return fail(SC_ERR_BAD_ARG, "null argument");
-    if (p->round != 0 || n_rounds > p->nv) return fail(SC_ERR_BAD_ARG, "handle must be at round 0 and hold at least n_rounds variables");
+// per round the shard's kernels, one all-reduce (sum, uint64) of the (deg+1) x 8 zero-extended limbs -- ncclAllReduce on the same
+// stream, or the host transport's function on the published lanes -- then, on every rank identically, fold, feed, sample.  The
+// handle is left after round n_rounds (its tables have two entries when n_rounds == its num_vars).
+static int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_t *out_proof, uint64_t *out_randomness) {
     HIP_TRY(hipSetDevice(p->device));
     const int n_words = (int)p->D * 8;
     if (!p->d_wide) {
@@ -1593,7 +1627,7 @@ extern "C" int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *r
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_wide), (size_t)n_words * 8, hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_wide_dev), p->h_wide, 0));
     }
-    rng->rng.feed_poly_info(p->max_mult, nv_total); // mod.rs:54: the GLOBAL instance's info
+    const bool on_stream = comm->comm != nullptr; // RCCL: the reduction is a stream operation between the round and its publication
     sch::Fr vm = sch::zero();
     bool have = false, enqueued = false;
     uint32_t want = 0;
@@ -1604,7 +1638,7 @@ extern "C" int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *r
     auto enqueue = [&](const uint64_t *r, bool deferred, uint32_t *want_out) -> int {
         int rc = launch_round(p, r, p->d_wide, false, deferred);
         if (rc) return rc;
-        NCCL_TRY(g_nccl.AllReduce(p->d_wide, p->d_wide, (size_t)n_words, ncclUint64, ncclSum, comm->comm, p->stream));
+        if (on_stream) NCCL_TRY(g_nccl.AllReduce(p->d_wide, p->d_wide, (size_t)n_words, ncclUint64, ncclSum, comm->comm, p->stream));
         p->seq += 1;
         *want_out = p->seq;
         HIP_TRY(scd::launch_publish_words(p->d_wide, p->h_wide_dev, n_words, p->h_flag_dev, *want_out, p->stream));
@@ -1641,14 +1675,21 @@ extern "C" int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *r
             p->exhausted = true;
             return fail(SC_ERR_HIP, "the host took longer than the wait kernel's bound to deliver a challenge; the proof is void");
         }
-        rc = sc_wide_reduce(p->h_wide, p->D, evals.data());
+        std::vector<uint64_t> lanes(p->h_wide, p->h_wide + n_words); // (the device reuses the page for the next round)
+        if (!on_stream && comm->nranks > 1) {
+            if (comm->h_allreduce(comm->ctx, lanes.data(), (size_t)n_words) != 0) {
+                abandon_deferred(p);
+                return fail(SC_ERR_HIP, "the host transport's all-reduce failed");
+            }
+        }
+        rc = sc_wide_reduce(lanes.data(), p->D, evals.data());
         if (rc) {
             abandon_deferred(p);
             return rc;
         }
         std::memcpy(out_proof + (size_t)i * p->D * 4, evals.data(), (size_t)p->D * 32);
-        rng->rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(evals.data()), p->D); // mod.rs:61
-        vm = rng->rng.sample_fr();                                                          // mod.rs:63
+        rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(evals.data()), p->D); // mod.rs:61
+        vm = rng.sample_fr();                                                       // mod.rs:63
         have = true;
         std::memcpy(out_randomness + (size_t)i * 4, vm.l, 32);
         if (next_enqueued) provide_challenge(p, vm);
@@ -1656,6 +1697,95 @@ extern "C" int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *r
         want = want_next;
     }
     return SC_OK;
+}
+
+extern "C" int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *rng, uint32_t nv_total, uint32_t n_rounds, uint64_t *out_proof,
+                                          uint64_t *out_randomness) {
+    if (!p || !comm || !rng || !out_proof || !out_randomness) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (p->round != 0 || n_rounds > p->nv) return fail(SC_ERR_BAD_ARG, "handle must be at round 0 and hold at least n_rounds variables");
+    rng->rng.feed_poly_info(p->max_mult, nv_total); // mod.rs:54: the GLOBAL instance's info
+    return sharded_rounds(p, comm, rng->rng, n_rounds, out_proof, out_randomness);
+}
+
+// The tail of a sharded proof: after its last local round every shard holds two entries per table; binding the next challenge
+// leaves one, the G ranks' elements are all-gathered, and every rank finishes the last log2 G rounds on the same G-entry tables
+// (no exchange needed any more; the transcripts stay in step because they absorb identical messages).
+static int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, const uint64_t *last_challenge, uint32_t k, uint64_t *out_proof,
+                        uint64_t *out_randomness) {
+    const uint32_t G = (uint32_t)comm->nranks, U = p->U;
+    const size_t send_bytes = (size_t)U * 32;
+    if (!p->d_tail_send) {
+        HIP_TRY(hipMalloc(&p->d_tail_send, send_bytes));
+        HIP_TRY(hipMalloc(&p->d_tail_recv, send_bytes * G));
+        HIP_TRY(hipMalloc(&p->d_tail_tabs, send_bytes * G));
+    }
+    int rc = sc_prover_bind_final(p, last_challenge, reinterpret_cast<uint64_t *>(p->d_tail_send));
+    if (rc) return rc;
+    if (comm->comm) {
+        NCCL_TRY(g_nccl.AllGather(p->d_tail_send, p->d_tail_recv, (size_t)U * 4, ncclUint64, comm->comm, p->stream));
+    } else {
+        std::vector<uint64_t> send((size_t)U * 4), recv((size_t)U * 4 * G);
+        HIP_TRY(hipMemcpyAsync(send.data(), p->d_tail_send, send_bytes, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (comm->h_allgather(comm->ctx, send.data(), recv.data(), send_bytes) != 0) return fail(SC_ERR_HIP, "the host transport's all-gather failed");
+        HIP_TRY(hipMemcpyAsync(p->d_tail_recv, recv.data(), send_bytes * G, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream)); // `recv` goes out of scope
+    }
+    HIP_TRY(scd::launch_gather_to_tables(static_cast<const uint4 *>(p->d_tail_recv), static_cast<uint4 *>(p->d_tail_tabs), G, U, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream)); // the tail prover runs on its own stream
+    if (!p->tail) { // built once per handle: the same products over U borrowed G-entry tables
+        std::vector<uint64_t> coeffs((size_t)p->K * 4);
+        std::vector<uint32_t> offs(1, 0), idx;
+        for (uint32_t q = 0; q < p->K; ++q) {
+            std::memcpy(&coeffs[4 * q], &p->prods[q].coeff, 32);
+            idx.insert(idx.end(), p->prod_indices[q].begin(), p->prod_indices[q].end());
+            offs.push_back((uint32_t)idx.size());
+        }
+        std::vector<const uint64_t *> tabs(U);
+        for (uint32_t u = 0; u < U; ++u) tabs[u] = reinterpret_cast<const uint64_t *>(static_cast<char *>(p->d_tail_tabs) + (size_t)u * G * 32);
+        sc_poly_desc d;
+        std::memset(&d, 0, sizeof(d));
+        d.num_vars = k;
+        d.max_multiplicands = p->max_mult;
+        d.n_products = p->K;
+        d.coeffs = coeffs.data();
+        d.prod_offsets = offs.data();
+        d.prod_indices = idx.data();
+        d.n_tables = U;
+        d.tables = tabs.data();
+        d.flags = SC_TABLES_ON_DEVICE | SC_TABLES_BORROW;
+        const int saved = g_device;
+        g_device = p->device;
+        rc = sc_prover_init(&d, &p->tail);
+        g_device = saved;
+        if (rc) return rc;
+    } else {
+        rc = sc_prover_reset(p->tail, nullptr, 0);
+        if (rc) return rc;
+    }
+    std::vector<sch::Fr> ch(k);
+    rc = sc_internal_run_rounds(p->tail, rng, k, out_proof, ch.data());
+    if (rc) return rc;
+    std::memcpy(out_randomness, ch.data(), (size_t)k * 32);
+    return SC_OK;
+}
+
+extern "C" int sc_ml_prove_sharded(sc_prover *p, sc_comm *comm, sc_rng *rng_or_null, uint32_t nv_total, uint64_t *out_proof, uint64_t *out_randomness) {
+    if (!p || !comm || !out_proof || !out_randomness) return fail(SC_ERR_BAD_ARG, "null argument");
+    const uint32_t G = (uint32_t)comm->nranks;
+    if (G == 0 || (G & (G - 1)) != 0) return fail(SC_ERR_BAD_ARG, "the number of ranks must be a power of two");
+    uint32_t k = 0;
+    while ((1u << k) < G) ++k;
+    if (p->round != 0 || p->nv + k != nv_total) return fail(SC_ERR_BAD_ARG, "handle must be at round 0 and hold a 1/%u shard of %u variables", G, nv_total);
+    sc_rng local;
+    sch::Blake2b512Rng &rng = rng_or_null ? rng_or_null->rng : local.rng;
+    rng.feed_poly_info(p->max_mult, nv_total); // mod.rs:54: the GLOBAL instance's info
+    const uint32_t nl = p->nv;
+    int rc = sharded_rounds(p, comm, rng, nl, out_proof, out_randomness);
+    if (rc) return rc;
+    const uint64_t *last = out_randomness + (size_t)(nl - 1) * 4;
+    if (k == 0) return sc_prover_push_randomness(p, last); // mod.rs:65-67
+    return sharded_tail(p, comm, rng, last, k, out_proof + (size_t)nl * p->D * 4, out_randomness + (size_t)nl * 4);
 }
 
 // ---------------------------------------------------------------------------------------------------

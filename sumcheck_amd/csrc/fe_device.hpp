@@ -1,8 +1,8 @@
-// fe.cuh -- carry-free ("unsaturated") BLS12-381 Fr arithmetic for the big-round kernels on gfx950.
+// fe_device.hpp -- carry-free ("unsaturated") BLS12-381 Fr arithmetic for the big-round kernels on gfx950.
 //
 // Why a second representation.  On gfx950 a v_mad_u64_u32 costs the same issue time as a v_addc_co_u32
 // (profiles/r1_instr_bench.txt: both 1.66x a v_add_u32), and a VALU carry needs two wait states before it can
-// be consumed.  In the saturated 8 x 32-bit Montgomery product (fr.cuh) every one of the 128 multiply-adds
+// be consumed.  In the saturated 8 x 32-bit Montgomery product (fr_device.hpp) every one of the 128 multiply-adds
 // drags a carry instruction behind it, and every modular add/sub is three serial carry chains.  Here an element
 // is 9 signed limbs of 29 bits (radix 2^29, value = sum l_i 2^(29 i)): a column of the schoolbook product is at
 // most 9 products below 2^59 plus 9 reduction products below 2^58, which fits a signed 64-bit accumulator, so
@@ -20,7 +20,7 @@
 // sub), the other <= 2^29 (normalised, or a difference of two normalised values).  Then every column is below
 // 9*2^59 + 9*2^58 + carry < 2^63.  Values (not limbs) stay below 2^259 in magnitude, results below 2^257.
 #pragma once
-#include "fr.cuh"
+#include "fr_device.hpp"
 #include "kernels.h"
 
 namespace scd {

@@ -1,4 +1,4 @@
-// fr.cuh -- BLS12-381 scalar-field arithmetic for gfx950 (CDNA4) device code.
+// fr_device.hpp -- BLS12-381 scalar-field arithmetic for gfx950 (CDNA4) device code.
 //
 // Replaces ark_ff::Fp<MontBackend<FrConfig,4>,4> mul/add/sub as used by the reference at
 // src/ml_sumcheck/protocol/prover.rs:116,120,122,123,127,145.  Elements are 8 x u32 little-endian
@@ -14,7 +14,7 @@
 //
 // fr_mul is the generated Comba/FIPS product (fr_mul_gen.inc, tools/gen_mac.py); fr_mul_cios is kept as
 // the readable restatement it is tested against.  The big-round kernels do not use this file's product:
-// they compute in the carry-free 9 x 29-bit representation of fe.cuh and only convert at the edges.
+// they compute in the carry-free 9 x 29-bit representation of fe_device.hpp and only convert at the edges.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

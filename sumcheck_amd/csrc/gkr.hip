@@ -25,7 +25,7 @@
 #include <rocprim/device/device_reduce_by_key.hpp>
 
 #include "../../include/sumcheck_hip.h"
-#include "fr.cuh"
+#include "fr_device.hpp"
 #include "host_fr.hpp"
 #include "kernels.h"
 #include "transcript.hpp"

@@ -25,7 +25,7 @@ __host__ __device__ constexpr int32_t node_value(int s) {
     return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? kNodeInf : ((s - 3) % 2 == 0 ? -((s - 3) / 2 + 1) : ((s - 3) / 2 + 2));
 }
 
-// The round's challenge, prepared by the host for the bind of the tree kernels (fe.cuh: fe_mul_bind): row i holds the nine
+// The round's challenge, prepared by the host for the bind of the tree kernels (fe_device.hpp: fe_mul_bind): row i holds the nine
 // 29-bit limbs of (r * 2^(29 i + 58)) mod p as a plain integer, r the challenge's standard (non-Montgomery) value.
 struct BindConst {
     int32_t R[9][9];
@@ -67,8 +67,6 @@ struct TreeProd {
 struct RoundArgs {
     TreeProd prod[kMaxRoundProds];
     int n_prod;
-    int rotate; // 0: every block walks the products in order; 1: start product rotated by blockIdx % 8 (dispatch slot = XCD);
-                // 2: rotated by blockIdx
 };
 
 // static per-product record for the finalize kernel (device memory)
@@ -78,7 +76,7 @@ struct FinProd {
     uint64_t partial_off; // offset (in field elements) of this product's partial sums
     uint64_t w_off;       // offset (in field elements) of this product's node->message matrices in d_W:
                           //   [w_off, +D*(M+1))            c_k * W          (partials in the tables' R = 2^256 form)
-                          //   [w_off + D*(M+1), +D*(M+1))  c_k * 2^(5(M-1)) * W  (partials from the 2^261-radix kernels, fe.cuh)
+                          //   [w_off + D*(M+1), +D*(M+1))  c_k * 2^(5(M-1)) * W  (partials from the 2^261-radix kernels, fe_device.hpp)
 };
 
 // table pointers passed by value (kernel argument) for the latency-bound small-round kernels
@@ -102,7 +100,7 @@ constexpr int kFoldMaxLevels = 3;
 struct FoldArgs {
     const uint4 *src[kMaxSmallTables];
     uint4 *dst[kMaxSmallTables];
-    FrHost r32[kFoldMaxLevels]; // challenges of this pass's variables (LSB first), each times 2^5 (fe.cuh radix)
+    FrHost r32[kFoldMaxLevels]; // challenges of this pass's variables (LSB first), each times 2^5 (fe_device.hpp radix)
 };
 // dst[y][i] = fold over `levels` variables of src[y][i << levels ...], i < n_out, y < n_tables (grid.y)
 hipError_t launch_fold_multi(const FoldArgs &args, int levels, int n_tables, uint64_t n_out, hipStream_t stream);
@@ -123,8 +121,10 @@ int grid_for_pairs(uint64_t n_pairs);
 
 // product k of one round: partials[t*grid+blk] = sum over this block's pairs of prod_j line_j(t), t = 0..M (node-major, so the
 // finalize kernel reads each node's partials as one contiguous run)
+#ifdef SC_EXPERIMENTS // saturated-arithmetic cross-check kernel
 hipError_t launch_prod_round(int M, const ProdArgs &args, const FrHost &r, uint64_t n_pairs, FrHost *d_partials, int grid,
                              hipStream_t stream);
+#endif
 // the same in carry-free 29-bit-limb arithmetic; r32 = challenge * 2^5, partials carry 2^(-5(M-1))
 hipError_t launch_prod_round_fe(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
                                 hipStream_t stream);
@@ -134,10 +134,11 @@ hipError_t launch_prod_tree(int M, const ProdArgs &args, const BindConst &rc, ui
                             hipStream_t stream);
 // all products of a round in one launch (see RoundArgs); d_partials is the base of the partial-sum array
 hipError_t launch_round_tree(const RoundArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
-// tiled variant (LDS-staged, one wavefront per node): grid from grid_for_tiles, same partial layout and scaling as _fe
+#ifdef SC_EXPERIMENTS // tiled variant (LDS-staged, one wavefront per node): grid from grid_for_tiles, same partial layout and scaling as _fe
 int grid_for_tiles(uint64_t n_pairs);
 hipError_t launch_round_tile(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
                              hipStream_t stream);
+#endif
 // generic (any M): tables already bound; slot lists in device memory
 hipError_t launch_sum_generic(const uint4 *const *d_cur_tables, const uint32_t *d_slot_table, const uint32_t *d_slot_exp,
                               int n_slots, int M, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
@@ -164,6 +165,8 @@ hipError_t launch_finalize(const FinProd *d_prods, const FinProd *h_prods_or_nul
 hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);
 hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t n, hipStream_t stream);
 hipError_t launch_publish_words(const uint64_t *d_src, uint64_t *h_dst_mapped, int n, uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream);
+// recv[g][u] -> tabs[u][g] (elements of 32 bytes): the all-gathered last entries of G shards become U tables of G entries
+hipError_t launch_gather_to_tables(const uint4 *recv, uint4 *tabs, uint32_t G, uint32_t U, hipStream_t stream);
 // F29 table -> canonical reference layout (state export)
 hipError_t launch_f29_to_sat(const uint4 *src, const int32_t *src_top, uint4 *dst, uint64_t n, hipStream_t stream);
 hipError_t launch_fr_elementwise(int op, const uint4 *a, const uint4 *b, const FrHost &u, uint4 *out, uint64_t n, hipStream_t stream);

@@ -18,18 +18,18 @@
 //
 // Kernels, by role:
 //   k_round_tree       production big-round kernel: ONE launch per round over all products (each <= 4 multiplicands):
-//                      fe.cuh carry-free arithmetic, constant-multiplier bind, evaluation nodes 0,1,inf,-1,2, static
+//                      fe_device.hpp carry-free arithmetic, constant-multiplier bind, evaluation nodes 0,1,inf,-1,2, static
 //                      product tree, running sums in LDS, F29 internal table format.
 //   k_prod_tree<M>     the same pass for one product per launch (SC_MERGE=0, or more than kMaxRoundProds products).
-//   k_prod_round_fe<M> fe.cuh arithmetic node by node (5..8 multiplicands; SC_KERNEL=0 SC_FE=1 as a cross-check).
+//   k_prod_round_fe<M> fe_device.hpp arithmetic node by node (5..8 multiplicands; SC_KERNEL=0 SC_FE=1 as a cross-check).
 //   k_prod_round<M>    saturated 8 x u32 Comba arithmetic (SC_KERNEL=0 SC_FE=0) -- kept as a parity cross-check.
 //   k_round_tile<M>    LDS-tiled variant (SC_KERNEL=2), a measured negative result.
 //   k_fold_multi<L>    evaluation at a point: all tables, L <= 3 variables per pass (sc_poly_evaluate).
 //   k_sum_generic/k_fix  any M, any aliasing pattern; used beyond kMaxFusedM and for > 32 tables.
 //   k_fix_multi + k_sum_combos   latency-oriented pair for rounds with <= 2^16 pairs.
 //   k_finalize         partial sums -> round message (Lagrange matrix, c_k, sum over products).
-#include "fr.cuh"
-#include "fe.cuh"
+#include "fr_device.hpp"
+#include "fe_device.hpp"
 #include "kernels.h"
 
 #include <cstdlib>
@@ -93,6 +93,7 @@ __device__ __forceinline__ Fr block_sum(Fr acc, uint32_t (*sm)[8]) {
     return acc;
 }
 
+#ifdef SC_EXPERIMENTS // cross-check variant: saturated 8 x u32 Comba arithmetic (SC_KERNEL=0 SC_FE=0)
 // ------------------------------------------------------------------------------------------------
 // K4: fused bind + product-sum for one product with M multiplicands (M <= kMaxFusedM)
 // ------------------------------------------------------------------------------------------------
@@ -162,8 +163,10 @@ __global__ __launch_bounds__(kBlock) void k_prod_round(const ProdArgs A, const F
     }
 }
 
+#endif // SC_EXPERIMENTS
+
 // ------------------------------------------------------------------------------------------------
-// K4 in carry-free arithmetic (fe.cuh): the same fused bind + product-sum, 9 x 29-bit signed limbs.
+// K4 in carry-free arithmetic (fe_device.hpp): the same fused bind + product-sum, 9 x 29-bit signed limbs.
 // `r32` is the challenge times 2^5 (host), so fe_mul_u(hi - lo, r32) is r*(hi-lo) in the tables' R = 2^256 form;
 // the M-1 products of a term leave the factor 2^(-5(M-1)), which k_finalize removes through the scaled coefficient.
 // ------------------------------------------------------------------------------------------------
@@ -417,7 +420,8 @@ __global__ __launch_bounds__(kBlock) void k_round_tree(const RoundArgs R, const 
     __shared__ int32_t lacc[9 * 5 * kBlock];
     bind_consts_to_lds(r, rt);
     const int n = R.n_prod;
-    int k = R.rotate == 1 ? (int)((blockIdx.x & 7u) % (uint32_t)n) : R.rotate == 2 ? (int)(blockIdx.x % (uint32_t)n) : 0;
+    // start product rotated by dispatch slot (blockIdx & 7 = XCD): multiplier-bound and HBM-bound products overlap across an XCD's CUs
+    int k = (int)((blockIdx.x & 7u) % (uint32_t)n);
     for (int i = 0; i < n; ++i) {
         const TreeProd &T = R.prod[k];
         uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x);
@@ -431,6 +435,7 @@ __global__ __launch_bounds__(kBlock) void k_round_tree(const RoundArgs R, const 
     }
 }
 
+#ifdef SC_EXPERIMENTS // cross-check variant and measured negative result: LDS-tiled kernel (SC_KERNEL=2)
 // ------------------------------------------------------------------------------------------------
 // K4, tiled: the fused bind + product-sum with fine-grained work items staged through LDS.
 //
@@ -531,6 +536,8 @@ __global__ __launch_bounds__(64 * (M + 1)) void k_round_tile(const ProdArgs A, c
     for (int off = 32; off >= 1; off >>= 1) sum = fr_add(sum, fr_shfl_down(sum, off));
     if (lane == 0) fr_store(partials + 2 * ((uint64_t)node_idx * gridDim.x + blockIdx.x), sum);
 }
+
+#endif // SC_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // Generic product-sum (any number of multiplicands): grid.y = evaluation point t, tables already bound.
@@ -942,13 +949,17 @@ __global__ __launch_bounds__(kBlock) void k_fr_elementwise(const int op, const u
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static int grid_cap() { // SC_GRID: experiment knob, at most kMaxGrid (the partial buffers are sized for that)
+static int grid_cap() {
+#ifdef SC_EXPERIMENTS // SC_GRID: at most kMaxGrid (the partial buffers are sized for that)
     static const int cap = [] {
         const char *e = std::getenv("SC_GRID");
         const int v = e ? std::atoi(e) : kMaxGrid;
         return v >= 1 && v <= kMaxGrid ? v : kMaxGrid;
     }();
     return cap;
+#else
+    return kMaxGrid;
+#endif
 }
 int grid_for_pairs(uint64_t n_pairs) {
     uint64_t g = (n_pairs + kBlock - 1) / kBlock;
@@ -957,12 +968,15 @@ int grid_for_pairs(uint64_t n_pairs) {
     return (int)g;
 }
 
+#ifdef SC_EXPERIMENTS
 template <int M>
 static hipError_t launch_prod_round_t(const ProdArgs &args, const FrHost &r, uint64_t n_pairs, FrHost *d_partials, int grid,
                                       hipStream_t stream) {
     hipLaunchKernelGGL(k_prod_round<M>, dim3(grid), dim3(kBlock), 0, stream, args, r, n_pairs, (uint4 *)d_partials);
     return hipGetLastError();
 }
+
+#endif
 
 template <int M>
 static hipError_t launch_prod_round_fe_t(const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
@@ -1009,6 +1023,7 @@ hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64
     return hipGetLastError();
 }
 
+#ifdef SC_EXPERIMENTS
 template <int M>
 static hipError_t launch_round_tile_t(const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
                                       hipStream_t stream) {
@@ -1052,6 +1067,8 @@ hipError_t launch_prod_round(int M, const ProdArgs &args, const FrHost &r, uint6
     default: return hipErrorInvalidValue;
     }
 }
+
+#endif // SC_EXPERIMENTS
 
 hipError_t launch_sum_generic(const uint4 *const *d_cur_tables, const uint32_t *d_slot_table, const uint32_t *d_slot_exp,
                               int n_slots, int M, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
@@ -1133,6 +1150,20 @@ __global__ void k_publish_words(const uint64_t *__restrict__ src, uint64_t *__re
 }
 hipError_t launch_publish_words(const uint64_t *d_src, uint64_t *h_dst_mapped, int n, uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream) {
     hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, stream, d_src, h_dst_mapped, n, h_flag_mapped, seq);
+    return hipGetLastError();
+}
+
+// tail of a sharded proof: recv[g][u] (rank-major, as an all-gather leaves it) -> tabs[u][g] (one G-entry table per polynomial)
+__global__ void k_gather_to_tables(const uint4 *__restrict__ recv, uint4 *__restrict__ tabs, const uint32_t G, const uint32_t U) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // output element index u * G + g
+    if (i >= G * U) return;
+    const uint32_t u = i / G, g = i % G;
+    tabs[2 * (size_t)i] = recv[2 * ((size_t)g * U + u)];
+    tabs[2 * (size_t)i + 1] = recv[2 * ((size_t)g * U + u) + 1];
+}
+hipError_t launch_gather_to_tables(const uint4 *recv, uint4 *tabs, uint32_t G, uint32_t U, hipStream_t stream) {
+    const uint32_t n = G * U;
+    hipLaunchKernelGGL(k_gather_to_tables, dim3((n + 255) / 256), dim3(256), 0, stream, recv, tabs, G, U);
     return hipGetLastError();
 }
 

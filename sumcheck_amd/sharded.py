@@ -291,40 +291,138 @@ class NativeComm:
             pass
 
 
-def prove_sharded_native(engine: HipShardEngine, ncomm: NativeComm, comm: DistComm, nv_total: int, max_multiplicands: int, tail_factory,
-                         fs_rng: Optional[Blake2b512Rng] = None):
-    """prove_sharded with the local rounds (all but the last log2 G) inside the library: sc_ml_prove_sharded_rounds.  One shard
-    per process.  The tail (bind_final + all_gather + log2 G rounds on a G-entry table) is the same code as prove_sharded."""
+class HostComm:
+    """A HOST-transport communicator (sc_comm_init_host): the library hands the (deg+1) x 8 uint64 lanes of a round, and the
+    tail's U x 32 bytes, to two Python callables that exchange host buffers.  Two transports are provided: torch.distributed
+    (any backend that moves host tensors: gloo) and an in-process one for one-thread-per-GPU use (ThreadExchange)."""
+
+    def __init__(self, rank: int, world: int, allreduce, allgather):
+        self.rank, self.world = rank, world
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t)
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+        def _ar(_ctx, inout, count):
+            try:
+                a = np.ctypeslib.as_array(inout, shape=(count,))
+                a[:] = allreduce(a.copy())
+                return 0
+            except Exception:  # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _ag(_ctx, send, recv, nbytes):
+            try:
+                sbuf = np.frombuffer(C.string_at(send, nbytes), dtype=np.uint8)
+                out = np.ascontiguousarray(allgather(sbuf), dtype=np.uint8).reshape(-1)
+                assert out.shape[0] == nbytes * world
+                C.memmove(recv, out.ctypes.data, nbytes * world)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._ar, self._ag = AR(_ar), AG(_ag)  # keep the trampolines alive as long as the communicator
+        self._h = C.c_void_p()
+        check(lib().sc_comm_init_host(rank, world, C.cast(self._ar, C.c_void_p), C.cast(self._ag, C.c_void_p), None, C.byref(self._h)))
+
+    def selftest(self):
+        """collective: exercises both transport functions with known patterns (sc_comm_selftest)"""
+        check(lib().sc_comm_selftest(self._h))
+
+    @classmethod
+    def over_torch_distributed(cls):
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+
+        def allreduce(a):
+            if world == 1:
+                return a
+            t = torch.from_numpy(a.view(np.int64).copy())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return t.numpy().view(np.uint64)
+
+        def allgather(b):
+            if world == 1:
+                return b
+            t = torch.from_numpy(b.copy())
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            return torch.cat(out).numpy()
+
+        return cls(rank, world, allreduce, allgather)
+
+    def close(self):
+        if self._h:
+            lib().sc_comm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ThreadExchange:
+    """In-process transport for one host thread per shard (the process model a Rust host would use: sc_set_device per thread,
+    one sc_prover per thread): a barrier-synchronised slot array.  comm(rank) -> HostComm for that thread."""
+
+    def __init__(self, world: int):
+        import threading
+        self.world = world
+        self._slots = [None] * world
+        self._bar = threading.Barrier(world)
+
+    def _exchange(self, rank, value):
+        self._slots[rank] = value
+        self._bar.wait(timeout=120)
+        got = list(self._slots)
+        self._bar.wait(timeout=120)  # nobody overwrites a slot before everybody has read it
+        return got
+
+    def comm(self, rank: int) -> HostComm:
+        def allreduce(a):
+            parts = self._exchange(rank, a)
+            tot = np.zeros_like(a)
+            for x in parts:
+                tot += x
+            return tot
+
+        def allgather(b):
+            return np.concatenate(self._exchange(rank, b))
+
+        return HostComm(rank, self.world, allreduce, allgather)
+
+
+def prove_sharded_library(engine: HipShardEngine, comm, nv_total: int, fs_rng: Optional[Blake2b512Rng] = None):
+    """The whole sharded proof as ONE library call (sc_ml_prove_sharded): local rounds with the per-round all-reduce, bind_final,
+    all-gather and the log2 G tail rounds all run inside libsumcheck_hip.so.  `comm` is a NativeComm (RCCL) or a HostComm.
+    -> (proof (nv_total, D, 4), randomness (nv_total, 4)), identical on every rank."""
     import torch
-    G = comm.world
-    k = _log2(G)
-    nv_local = nv_total - k
-    assert nv_local == engine.nv and nv_local >= 1
-    rng = fs_rng or Blake2b512Rng.setup()
-    D = max_multiplicands + 1
+    D = engine.D
     proof = np.empty((nv_total, D, 4), dtype=np.uint64)
     rand = np.empty((nv_total, 4), dtype=np.uint64)
-    lp = np.empty((nv_local, D, 4), dtype=np.uint64)
-    lr = np.empty((nv_local, 4), dtype=np.uint64)
     # The library loop runs on the handle's own non-blocking stream: its pipelined late rounds park a polling wait kernel on the
     # stream, which must not be torch's (possibly legacy-default, implicitly synchronising) stream.  Both switches synchronise.
     torch.cuda.current_stream(engine.device).synchronize()
     check(lib().sc_prover_set_stream(engine._h, None, 1))
     try:
-        check(lib().sc_ml_prove_sharded_rounds(engine._h, ncomm._h, rng._h, nv_total, nv_local, C.c_void_p(lp.ctypes.data),
-                                               C.c_void_p(lr.ctypes.data)))
+        check(lib().sc_ml_prove_sharded(engine._h, comm._h, fs_rng._h if fs_rng is not None else None, nv_total, C.c_void_p(proof.ctypes.data),
+                                        C.c_void_p(rand.ctypes.data)))
     finally:
         check(lib().sc_prover_set_stream(engine._h, C.c_void_p(torch.cuda.current_stream(engine.device).cuda_stream), 0))
-    proof[:nv_local] = lp
-    rand[:nv_local] = lr
-    if k > 0:
-        local = engine.bind_final(lr[-1]).unsqueeze(0)              # (1, U, 4)
-        allsh = comm.all_gather(local)                                # (world, 1, U, 4)
-        U = local.shape[1]
-        tables = allsh.reshape(G, U, 4).permute(1, 0, 2).contiguous()
-        tail = tail_factory(k, tables)
-        _run_tail(tail, rng, k, proof[nv_local:], rand[nv_local:])
     return proof, rand
+
+
+def prove_sharded_native(engine: HipShardEngine, ncomm, comm: DistComm, nv_total: int, max_multiplicands: int, tail_factory=None,
+                         fs_rng: Optional[Blake2b512Rng] = None):
+    """kept name of the round-1 driver: now a thin caller of sc_ml_prove_sharded (the tail no longer runs in Python)"""
+    assert max_multiplicands + 1 == engine.D
+    return prove_sharded_library(engine, ncomm, nv_total, fs_rng)
 
 
 def prove_logical_shards(nv: int, shapes, tables: Sequence[np.ndarray], coeffs: np.ndarray, G: int, device):

@@ -18,7 +18,7 @@ def _last_json(out: str):
 
 
 def test_bench_line_single_gpu():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--nv-local", "19"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--nv", "19"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
@@ -32,18 +32,29 @@ def test_bench_line_single_gpu():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    # one thread, all cores, all cores with the improved bind, and the CPU model, side by side
+    assert cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0 and cb["all_cores_improved_bind"]["value"] > 0 and cb["cpu_model"]
+    assert d["scaling"] == "strong" and "config 3" in d["config"]["workload"] and d["config"]["round_loop"] == "library"
 
 
-def test_bench_line_two_ranks_one_gpu():
+def _two_ranks(extra):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, SC_BENCH_ONE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--nv-local", "15"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["cpu_baseline"] is None
-    assert d["config"]["nv"] == 16 and d["config"]["nv_per_gpu"] == 15
+    return _last_json(r.stdout)
+
+
+def test_bench_line_two_ranks_one_gpu():
+    """the driver's N>1 launch line on a one-GPU box: the whole sharded proof inside the library (sc_ml_prove_sharded) over its
+    host transport; strong scaling = the same global instance split over the ranks"""
+    d = _two_ranks(["--nv", "16"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["cpu_baseline"] is None
+    assert d["config"]["nv"] == 16 and d["config"]["nv_per_gpu"] == 15 and d["config"]["round_loop"].startswith("library")
+    d = _two_ranks(["--config", "4", "--nv", "17"])
+    assert d["config"]["tables"] == 3 and d["config"]["nv_per_gpu"] == 16 and "config 4" in d["config"]["workload"]

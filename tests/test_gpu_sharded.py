@@ -1,0 +1,195 @@
+"""GPU tests of the multi-GPU proof behind the C ABI (sc_ml_prove_sharded): local rounds, per-round all-reduce, bind + all-gather
+and the log2 G tail rounds all inside libsumcheck_hip.so.  On a one-GPU box the G shards share the GPU and meet through the
+library's HOST transport (threads of one process, or processes over gloo); with N visible GPUs the same entry point runs over
+RCCL, one rank per GPU, as processes and as threads.  Every proof is compared bit for bit with the unsharded oracle proof."""
+import ctypes as C
+import os
+import socket
+import threading
+
+import numpy as np
+import pytest
+
+import sumcheck_amd as sc
+from oracle import cref
+from sumcheck_amd import _lib, sharded
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _n_gpus():
+    return sc.lib().sc_device_count()
+
+
+def _oracle(nv, shapes, nt, seed):
+    tabs = [cref.synth_table(seed, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(seed, 1000, len(shapes))
+    want, wrand = cref.ml_prove(H.desc_from(nv, shapes, tabs, coefs), threads=cref.max_threads())
+    return tabs, coefs, want, wrand
+
+
+def _thread_rank(rank, G, nv, shapes, tabs, coefs, make_comm, device, out, n_proofs=2):
+    """one host thread = one rank: its own device selection, prover handle and communicator"""
+    try:
+        import torch
+        _lib.check(sc.lib().sc_set_device(device))
+        n_loc = (1 << nv) // G
+        with torch.cuda.device(device):
+            eng = sharded.HipShardEngine(nv - (G.bit_length() - 1), shapes, coefs, [t[rank * n_loc:(rank + 1) * n_loc] for t in tabs],
+                                         f"cuda:{device}", borrow=True)
+            comm = make_comm(rank)
+            res = []
+            for _ in range(n_proofs):  # the second proof reuses the handle, the tail prover and every buffer
+                eng.reset()
+                res.append(sharded.prove_sharded_library(eng, comm, nv))
+            comm.close()
+            eng.close()
+        out[rank] = res
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        out[rank] = RuntimeError(f"rank {rank}: {e}\n{traceback.format_exc()}")
+
+
+@pytest.mark.parametrize("G,nv,nt,shapes", [
+    (2, 13, 4, [[0, 1, 2], [3, 3], [1]]),
+    (4, 19, 10, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]),   # config-3 shape; 2^17 entries per shard: no big rounds
+    (2, 20, 3, [[0, 1, 2]]),                               # config-4 shape; 2^19 per shard: two big rounds (merged kernel, F29) per shard
+    (8, 6, 2, [[0, 1], [1]]),                              # tail as long as the local part
+])
+def test_sharded_proof_threads_on_one_gpu(G, nv, nt, shapes):
+    """single process, one thread per rank (sc_set_device per thread -- how a Rust host drives it), all on GPU 0, meeting through
+    the in-process host transport"""
+    tabs, coefs, want, wrand = _oracle(nv, shapes, nt, 4100 + nv)
+    ex = sharded.ThreadExchange(G)
+    out = [None] * G
+    ts = [threading.Thread(target=_thread_rank, args=(r, G, nv, shapes, tabs, coefs, ex.comm, 0, out)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    for r in range(G):
+        assert not isinstance(out[r], Exception), out[r]
+        for proof, rand in out[r]:
+            assert np.array_equal(proof, want), f"rank {r}"
+            assert np.array_equal(rand, wrand), f"rank {r}"
+
+
+def test_sharded_proof_world1_is_the_unsharded_proof():
+    """one rank: no exchange, no tail; with the host transport and (next test) with RCCL"""
+    nv, shapes, nt = 18, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10
+    tabs, coefs, want, wrand = _oracle(nv, shapes, nt, 66)
+    out = [None]
+    _thread_rank(0, 1, nv, shapes, tabs, coefs, lambda r: sharded.HostComm(0, 1, lambda a: a, lambda b: b), 0, out)
+    assert not isinstance(out[0], Exception), out[0]
+    for proof, rand in out[0]:
+        assert np.array_equal(proof, want) and np.array_equal(rand, wrand)
+
+
+def test_sharded_proof_world1_rccl():
+    nv, shapes, nt = 18, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10
+    tabs, coefs, want, wrand = _oracle(nv, shapes, nt, 67)
+    out = [None]
+
+    def mk(_rank):
+        c = sharded.NativeComm("cuda:0")
+        _lib.check(sc.lib().sc_comm_selftest(c._h))
+        return c
+    _thread_rank(0, 1, nv, shapes, tabs, coefs, mk, 0, out)
+    assert not isinstance(out[0], Exception), out[0]
+    for proof, rand in out[0]:
+        assert np.array_equal(proof, want) and np.array_equal(rand, wrand)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _proc_rank(rank, world, port, backend, nv, shapes, nt, seed, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    device = rank if backend == "nccl" else 0
+    torch.cuda.set_device(device)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tabs = [cref.synth_table(seed, s, 1 << nv) for s in range(nt)]
+        coefs = cref.synth_table(seed, 1000, len(shapes))
+        out = [None] * world
+        mk = (lambda r: sharded.NativeComm(f"cuda:{device}")) if backend == "nccl" else (lambda r: sharded.HostComm.over_torch_distributed())
+        _thread_rank(rank, world, nv, shapes, tabs, coefs, mk, device, out)
+        q.put((rank, out[rank] if not isinstance(out[rank], Exception) else repr(out[rank])))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_procs(world, backend, nv, shapes, nt, seed):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_proc_rank, args=(r, world, port, backend, nv, shapes, nt, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    _, _, want, wrand = _oracle(nv, shapes, nt, seed)
+    for r in range(world):
+        assert not isinstance(res[r], str), res[r]
+        for proof, rand in res[r]:
+            assert np.array_equal(proof, want), f"rank {r}"
+            assert np.array_equal(rand, wrand), f"rank {r}"
+
+
+def test_sharded_proof_two_processes_one_gpu_over_gloo():
+    """one process per rank as under torchrun; both ranks on this box's GPU, the library's host transport over gloo"""
+    _run_procs(2, "gloo", 15, [[0, 1, 2], [3, 3], [1]], 4, 93)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_proof_rccl_one_process_per_gpu(world):
+    """the production multi-GPU path: one process per GPU, RCCL all-reduce / all-gather on the provers' streams"""
+    if _n_gpus() < world:
+        pytest.skip(f"needs {world} visible GPUs (RCCL refuses two ranks on one device)")
+    _run_procs(world, "nccl", 21, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10, 95)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_proof_rccl_one_thread_per_gpu(world):
+    """single process, one thread per GPU, RCCL communicator created from the threads (ncclCommInitRank per thread)"""
+    if _n_gpus() < world:
+        pytest.skip(f"needs {world} visible GPUs")
+    nv, shapes, nt = 21, [[0, 1, 2]], 3
+    tabs, coefs, want, wrand = _oracle(nv, shapes, nt, 96)
+    idb = (C.c_uint8 * 128)()
+    _lib.check(sc.lib().sc_comm_unique_id(C.cast(idb, C.c_void_p)))
+
+    class _Comm:
+        def __init__(self, rank):
+            self._h = C.c_void_p()
+            _lib.check(sc.lib().sc_comm_init(C.cast(idb, C.c_void_p), rank, world, C.byref(self._h)))
+
+        def close(self):
+            sc.lib().sc_comm_free(self._h)
+
+    out = [None] * world
+    ts = [threading.Thread(target=lambda r=r: _thread_rank(r, world, nv, shapes, tabs, coefs, _Comm, r, out)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    for r in range(world):
+        assert not isinstance(out[r], Exception), out[r]
+        for proof, rand in out[r]:
+            assert np.array_equal(proof, want) and np.array_equal(rand, wrand)

@@ -1,6 +1,6 @@
-"""GPU parity of the alternative kernel variants (selected by environment at prover creation): the production path is the
-product-tree kernel over internal F29 tables; the saturated Comba kernel, the node-by-node carry-free kernel, the tiled
-LDS-staged kernel and the F29-off mode are kept as cross-checks and must produce the same bits."""
+"""GPU parity of the alternative kernel variants: the production path is the product-tree kernel over internal F29 tables; the
+saturated Comba kernel, the node-by-node carry-free kernel, the tiled LDS-staged kernel and the F29-off mode are kept as
+cross-checks in the -DSC_EXPERIMENTS build (libsumcheck_hip_exp.so, selected by environment there) and must produce the same bits."""
 import os
 
 import numpy as np
@@ -13,35 +13,22 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("env", [
-    {"SC_KERNEL": "3", "SC_F29": "1"},   # production: one launch per big round, products rotated by dispatch slot
-    {"SC_KERNEL": "3", "SC_ROTATE": "0"},  # ... every block walks the products in the same order
-    {"SC_KERNEL": "3", "SC_ROTATE": "2"},  # ... rotated per block
-    {"SC_KERNEL": "3", "SC_MERGE": "0"},  # one launch per product
-    {"SC_PIPELINE": "0"},                 # late rounds launched after their challenge (no wait kernel)
-    {"SC_PIPELINE": "2"},                 # late rounds behind a command-processor wait + copy kernel
-    {"SC_KERNEL": "3", "SC_F29": "0"},   # product tree, canonical tables
-    {"SC_KERNEL": "0", "SC_FE": "1"},    # node-by-node, carry-free arithmetic
-    {"SC_KERNEL": "0", "SC_FE": "0"},    # node-by-node, saturated Comba (inline asm)
-    {"SC_KERNEL": "2"},                  # tiled, LDS-staged
-])
-@pytest.mark.parametrize("nv,nt,shapes", [
-    (19, 10, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]),       # BASELINE config-3 shape, three big rounds
-    (18, 5, [[2, 3, 0, 1], [1, 4, 4], [3, 2, 1], [0, 0]]),  # shared tables, repeated factors
-    (18, 6, [[0, 1, 2, 3, 4], [5, 5], [2]]),                # five multiplicands: outside the tree, no F29
-])
-def test_variant_matches_oracle(env, nv, nt, shapes, monkeypatch):
-    for k in ("SC_KERNEL", "SC_F29", "SC_FE", "SC_MERGE", "SC_ROTATE", "SC_PIPELINE"):
-        monkeypatch.delenv(k, raising=False)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+VARIANT_WORKER = r'''
+import json, sys
+import numpy as np
+import sumcheck_amd as sc
+from oracle import cref
+from sumcheck_amd import _lib
+from tests import helpers as H
+assert _lib.SO_PATH.endswith("libsumcheck_hip_exp.so")
+for nv, nt, shapes in json.loads(sys.argv[1]):
     tabs = [cref.synth_table(4242 + nv, s, 1 << nv) for s in range(nt)]
     coefs = cref.synth_table(4242 + nv, 1000, len(shapes))
     d = H.desc_from(nv, shapes, tabs, coefs)
     want, wrand = cref.ml_prove(d, threads=cref.max_threads())
     poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs)
     proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly)
-    assert np.array_equal(np.stack([m.evaluations for m in proof]), want)
+    assert np.array_equal(np.stack([m.evaluations for m in proof]), want), (nv, shapes)
     assert np.array_equal(state.randomness, wrand)
     # interactive flow with a mid-proof state export while the tables are in the internal format (round 2)
     st = sc.IPForMLSumcheck.prover_init(poly)
@@ -50,11 +37,63 @@ def test_variant_matches_oracle(env, nv, nt, shapes, monkeypatch):
     v = None
     for i in range(3):
         got = sc.IPForMLSumcheck.prove_round(st, v).evaluations
-        assert np.array_equal(got, op.prove_round(None if v is None else v.randomness))
+        assert np.array_equal(got, op.prove_round(None if v is None else v.randomness)), (nv, shapes, i)
         v = sc.VerifierMsg(chal[i])
     _, otabs, _ = op.state()
     for u, t in enumerate(st.flattened_ml_extensions):
         assert np.array_equal(t.evaluations, otabs[u])
+print("VARIANT-OK")
+'''
+
+VARIANT_SHAPES = [
+    (19, 10, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]),       # BASELINE config-3 shape, three big rounds
+    (18, 5, [[2, 3, 0, 1], [1, 4, 4], [3, 2, 1], [0, 0]]),  # shared tables, repeated factors
+    (18, 6, [[0, 1, 2, 3, 4], [5, 5], [2]]),                # five multiplicands: outside the tree, no F29
+    (18, 6, [[0, 1, 2, 3, 4], [5, 5, 1], [2, 3, 4, 0]]),    # products of <= 4 and of 5..8 multiplicands in one round
+]
+
+
+@pytest.mark.parametrize("env", [
+    {},                                   # the experiments build's default = the production path
+    {"SC_KERNEL": "3", "SC_MERGE": "0"},  # one launch per product
+    {"SC_PIPELINE": "0"},                 # late rounds launched after their challenge (no wait kernel)
+    {"SC_KERNEL": "3", "SC_F29": "0"},    # product tree, canonical tables
+    {"SC_KERNEL": "0", "SC_FE": "1"},     # node-by-node, carry-free arithmetic
+    {"SC_KERNEL": "0", "SC_FE": "0"},     # node-by-node, saturated Comba (inline asm)
+    {"SC_FE": "0"},                       # saturated arithmetic with the default kernel family: every fused product of a round on ONE arithmetic
+    {"SC_KERNEL": "2"},                   # tiled, LDS-staged
+    {"SC_SMALL_LOG2": "13", "SC_GRID": "256"},  # other big/small boundary and grid cap
+], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
+def test_variant_matches_oracle(env):
+    """The cross-check kernels live in the -DSC_EXPERIMENTS build (libsumcheck_hip_exp.so); each knob setting runs in its own
+    process (the knobs are read when a prover is created, the library is chosen when it is first loaded)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if not k.startswith("SC_")}
+    e.update(env, SC_LIB_VARIANT="exp")
+    r = subprocess.run([sys.executable, "-c", VARIANT_WORKER, json.dumps(VARIANT_SHAPES)], capture_output=True, text=True, timeout=900, cwd=root, env=e)
+    assert r.returncode == 0 and "VARIANT-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_production_library_ignores_the_experiment_knobs(monkeypatch):
+    """the shipped library has one production path: SC_KERNEL / SC_FE / SC_F29 / SC_MERGE in the environment change nothing"""
+    from sumcheck_amd import _lib
+    assert _lib.SO_PATH.endswith("libsumcheck_hip.so")
+    for k, v in {"SC_KERNEL": "0", "SC_FE": "0", "SC_F29": "0", "SC_MERGE": "0", "SC_GRID": "7"}.items():
+        monkeypatch.setenv(k, v)
+    nv, nt, shapes = 18, 10, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]
+    tabs = [cref.synth_table(31, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(31, 1000, len(shapes))
+    want, _ = cref.ml_prove(H.desc_from(nv, shapes, tabs, coefs), threads=cref.max_threads())
+    poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs)
+    st = sc.IPForMLSumcheck.prover_init(poly)
+    st.set_timing(True)
+    got = st.prove()
+    assert np.array_equal(got, want)
+    ms, launches, _ = st.get_timing()
+    assert launches[0] > 0 and all(x == 0 for x in launches[1:]), "big rounds must run as the merged k_round_tree launch"
 
 
 def test_more_products_than_one_launch_takes():

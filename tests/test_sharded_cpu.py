@@ -85,3 +85,73 @@ def test_gloo_world2_matches_unsharded_oracle(nv, shapes, nt, L):
     for rank, proof, rand in res:
         assert np.array_equal(proof, want), f"rank {rank}"
         assert np.array_equal(rand, wrand), f"rank {rank}"
+
+
+def _transport_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sumcheck_amd import sharded
+        comm = sharded.HostComm.over_torch_distributed()
+        comm.selftest()
+        comm.selftest()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_library_host_transport_over_gloo_world2():
+    """the library's host-transport communicator (sc_comm_init_host), the path sc_ml_prove_sharded takes without RCCL, driven
+    through the C ABI by two gloo ranks: its all-reduce and all-gather callbacks deliver what the library expects"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_transport_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: "ok", 1: "ok"}
+
+
+def test_library_host_transport_between_threads():
+    """the same with one thread per rank inside one process (the process model a Rust host would use)"""
+    import threading
+    from sumcheck_amd import sharded
+    world = 4
+    ex = sharded.ThreadExchange(world)
+    errs = []
+
+    def run(rank):
+        try:
+            c = ex.comm(rank)
+            c.selftest()
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errs, errs
+
+
+def test_sharded_entry_point_validates_before_touching_a_device():
+    import ctypes as C
+    import sumcheck_amd as sc
+    from sumcheck_amd import _lib, sharded
+    c = sharded.HostComm(0, 1, lambda a: a, lambda b: b)
+    out = np.zeros((4, 4), np.uint64)
+    rc = sc.lib().sc_ml_prove_sharded(None, c._h, None, 4, C.c_void_p(out.ctypes.data), C.c_void_p(out.ctypes.data))
+    assert rc == _lib.SC_ERR_BAD_ARG
+    h = C.c_void_p()
+    assert sc.lib().sc_comm_init_host(2, 2, None, None, None, C.byref(h)) == _lib.SC_ERR_BAD_ARG  # rank out of range
+    assert sc.lib().sc_comm_init_host(0, 2, None, None, None, C.byref(h)) == _lib.SC_ERR_BAD_ARG  # transports required for > 1 rank
