@@ -1628,6 +1628,11 @@ static int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, 
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_wide_dev), p->h_wide, 0));
     }
     const bool on_stream = comm->comm != nullptr; // RCCL: the reduction is a stream operation between the round and its publication
+    // Pipelined late rounds park a polling kernel on the stream until THIS rank's host has the next challenge -- which needs every
+    // rank's lanes.  RCCL ranks sit on distinct devices.  Host-transport ranks may share one GPU (tests; threads of one process), where
+    // streams share hardware queues: rank A's polling kernel could then sit in front of rank B's round kernels, and A's host would
+    // wait for B forever.  So the rounds are only pipelined where no other rank's work can queue behind the wait.
+    const bool may_defer = on_stream || comm->nranks == 1;
     sch::Fr vm = sch::zero();
     bool have = false, enqueued = false;
     uint32_t want = 0;
@@ -1649,7 +1654,7 @@ static int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, 
         if (!enqueued && (rc = enqueue(have ? vm.l : nullptr, false, &want))) return rc;
         uint32_t want_next = 0;
         bool next_enqueued = false;
-        if (i + 1 < n_rounds && can_defer_next(p)) {
+        if (i + 1 < n_rounds && may_defer && can_defer_next(p)) {
             if ((rc = enqueue(nullptr, true, &want_next))) {
                 abandon_deferred(p);
                 return rc;
@@ -1763,6 +1768,8 @@ static int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, co
         rc = sc_prover_reset(p->tail, nullptr, 0);
         if (rc) return rc;
     }
+    // (same reasoning as in sharded_rounds: no polling kernels on a GPU that other ranks of a host transport may share)
+    if (!comm->comm && comm->nranks > 1) p->tail->pipeline_ok = false;
     std::vector<sch::Fr> ch(k);
     rc = sc_internal_run_rounds(p->tail, rng, k, out_proof, ch.data());
     if (rc) return rc;
