@@ -351,7 +351,7 @@ inline std::pair<DenseMultilinearExtension, SparseMultilinearExtension> initiali
     SparseMultilinearExtension f1g{2 * dim, std::vector<uint64_t>(std::max<size_t>(f1.indices.size(), 1)), std::vector<Fr>(std::max<size_t>(f1.indices.size(), 1))};
     uint64_t n1 = 0;
     check(sc_gkr_phase_one(f1.indices.data(), f1.values.empty() ? nullptr : f1.values[0].l, f1.indices.size(), (uint32_t)dim, f3.evaluations[0].l,
-                           g[0].l, hg.evaluations[0].l, f1g.indices.data(), f1g.values[0].l, &n1));
+                           g[0].l, 0, hg.evaluations[0].l, f1g.indices.data(), f1g.values[0].l, &n1));
     f1g.indices.resize(n1);
     f1g.values.resize(n1);
     return {std::move(hg), std::move(f1g)};
@@ -361,7 +361,7 @@ inline DenseMultilinearExtension initialize_phase_two(const SparseMultilinearExt
     if (u.size() * 2 != f1_g.num_vars) throw Panic(SC_ERR_BAD_ARG, "assertion failed: u.len() * 2 == f1_g.num_vars");
     DenseMultilinearExtension out{u.size(), std::vector<Fr>(size_t(1) << u.size())};
     check(sc_gkr_phase_two(f1_g.indices.data(), f1_g.values.empty() ? nullptr : f1_g.values[0].l, f1_g.indices.size(), (uint32_t)u.size(), u[0].l,
-                           out.evaluations[0].l));
+                           0, out.evaluations[0].l));
     return out;
 }
 
@@ -421,7 +421,7 @@ struct GKRRoundSumcheck {
         if (f1.num_vars != 3 * dim || f3.num_vars != dim || g.size() != dim) throw Panic(SC_ERR_BAD_ARG, "assertion failed: dimensions");
         std::vector<Fr> flat(2 * std::max<size_t>(dim, 1) * 3);
         check(sc_gkr_prove(rng.raw(), f1.indices.data(), f1.values.empty() ? nullptr : f1.values[0].l, f1.indices.size(), (uint32_t)dim,
-                           f2.evaluations[0].l, f3.evaluations[0].l, g[0].l, flat[0].l, nullptr));
+                           f2.evaluations[0].l, f3.evaluations[0].l, g[0].l, 0, flat[0].l, nullptr));
         GKRProof pr;
         for (size_t i = 0; i < dim; ++i) {
             pr.phase1_sumcheck_msgs.push_back(ProverMsg{std::vector<Fr>(flat.begin() + 3 * i, flat.begin() + 3 * i + 3)});

@@ -183,18 +183,25 @@ SC_API int sc_ml_verify(uint32_t num_vars, uint32_t max_multiplicands, const uin
 
 /* ---- GKR round sumcheck (reference src/gkr_round_sumcheck/mod.rs) ---------------------------- */
 /* f1 is a SparseMultilinearExtension over 3*dim variables given as nnz (index, value) pairs with
- * distinct indices (index layout z | x<<dim | y<<2dim, mod.rs:34-35); f2,f3,g host arrays.
+ * distinct indices (index layout z | x<<dim | y<<2dim, mod.rs:34-35); g / u are host arrays (dim x 4 limbs).
+ * flags: SC_TABLES_ON_DEVICE => every table-sized argument (f1_idx, f1_vals, f2, f3 and, for the two initialisation
+ * calls, the outputs h_g, f1g_idx, f1g_vals, f1_gu) is a DEVICE pointer: inputs are read in place (never written), outputs
+ * are produced in place; without it they are host arrays that the call stages through HBM.  The proof itself, u, v and
+ * *f1g_nnz always land on the host.
  * initialize_phase_one (mod.rs:22-42): h_g = 2^dim x 4 out; f1_g out as sorted (index,value) pairs,
  * capacity nnz, *f1g_nnz = count. */
 SC_API int sc_gkr_phase_one(const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim, const uint64_t *f3,
-                     const uint64_t *g, uint64_t *h_g, uint64_t *f1g_idx, uint64_t *f1g_vals, uint64_t *f1g_nnz);
+                     const uint64_t *g, uint32_t flags, uint64_t *h_g, uint64_t *f1g_idx, uint64_t *f1g_vals, uint64_t *f1g_nnz);
 /* initialize_phase_two (mod.rs:57-63): f1_gu = 2^dim x 4 out */
 SC_API int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_vals, uint64_t nnz, uint32_t dim, const uint64_t *u,
-                     uint64_t *f1_gu);
+                     uint32_t flags, uint64_t *f1_gu);
 /* GKRRoundSumcheck::prove (mod.rs:93-139).  out_proof: 2 x dim x 3 x 4 limbs (phase1 then phase2
  * messages); out_uv_or_null: 2 x dim x 4 (u then v). */
 SC_API int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim,
-                 const uint64_t *f2, const uint64_t *f3, const uint64_t *g, uint64_t *out_proof, uint64_t *out_uv_or_null);
+                 const uint64_t *f2, const uint64_t *f3, const uint64_t *g, uint32_t flags, uint64_t *out_proof, uint64_t *out_uv_or_null);
+/* out[i] = scalar * in[i], i < n: `DenseMultilinearExtension::zero() += (f2(u), &f3)` of start_phase2_sumcheck (mod.rs:71-75).
+ * flags: SC_TABLES_ON_DEVICE => in / out are device pointers.  scalar: 4 limbs (host). */
+SC_API int sc_dense_scale(const uint64_t *in, uint64_t n, const uint64_t *scalar, uint64_t *out, uint32_t flags);
 
 /* ListOfProductsOfPolynomials::evaluate (src/ml_sumcheck/data_structures.rs:99-109): sum_k c_k prod_j T_j(point),
  * the oracle query every reference test ends with (test.rs:71-74) and GKR's f2.evaluate(u) (gkr_round_sumcheck/

@@ -83,9 +83,10 @@ SIGNATURES = {
     "sc_ml_prove_handle": (C.c_int, [_V, _V, _V]),
     "sc_interpolate_uni_poly": (C.c_int, [_V, C.c_uint32, _V, _V]),
     "sc_ml_verify": (C.c_int, [C.c_uint32, C.c_uint32, _V, _V, C.c_uint64, _V, _V, _V]),
-    "sc_gkr_phase_one": (C.c_int, [_V, _V, C.c_uint64, C.c_uint32, _V, _V, _V, _V, _V, u64p]),
-    "sc_gkr_phase_two": (C.c_int, [_V, _V, C.c_uint64, C.c_uint32, _V, _V]),
-    "sc_gkr_prove": (C.c_int, [_V, _V, _V, C.c_uint64, C.c_uint32, _V, _V, _V, _V, _V]),
+    "sc_gkr_phase_one": (C.c_int, [_V, _V, C.c_uint64, C.c_uint32, _V, _V, C.c_uint32, _V, _V, _V, u64p]),
+    "sc_gkr_phase_two": (C.c_int, [_V, _V, C.c_uint64, C.c_uint32, _V, C.c_uint32, _V]),
+    "sc_gkr_prove": (C.c_int, [_V, _V, _V, C.c_uint64, C.c_uint32, _V, _V, _V, C.c_uint32, _V, _V]),
+    "sc_dense_scale": (C.c_int, [_V, C.c_uint64, _V, _V, C.c_uint32]),
     "sc_synth_table_device": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _V]),
     "sc_prover_last_round_ms": (C.c_int, [_V, C.POINTER(C.c_float)]),
     "sc_prover_set_timing": (C.c_int, [_V, C.c_int]),

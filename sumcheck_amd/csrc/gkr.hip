@@ -14,6 +14,7 @@
 // arithmetic is exact, hence the result is the same canonical table whatever the summation order.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -60,26 +61,44 @@ __device__ __forceinline__ FrU fru(const FrHost &h) {
 __device__ __forceinline__ Fr fr_ld(const Fr *p) { return scd::fr_load(reinterpret_cast<const uint4 *>(p)); }
 __device__ __forceinline__ void fr_st(Fr *p, const Fr &a) { scd::fr_store(reinterpret_cast<uint4 *>(p), a); }
 
-// precompute_eq (ark-poly): level i doubles the table: dp[b + 2^i] = dp[b] * g_i ; dp[b] -= dp[b + 2^i]
-__global__ __launch_bounds__(kBlock) void k_eq_init(Fr *dp, const FrHost g0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+// precompute_eq (ark-poly): eq[b] = prod_i (b_i ? g_i : 1 - g_i), built there by doubling: dp[b + 2^i] = dp[b] * g_i ; dp[b] -= dp[b + 2^i].
+// Exact field arithmetic, so any evaluation order gives the same canonical table.  Here: the low kl <= 11 variables and the high
+// kh <= 11 variables are doubled by one block each (2 blocks, one launch; levels separated by block barriers), and the table is
+// their outer product (one Montgomery product per entry, fully parallel): 2 launches instead of k.
+constexpr int kEqMaxVars = 22, kEqHalfMax = 11, kEqBlock = 1024;
+struct EqPoint {
+    FrHost g[kEqMaxVars];
+};
+__device__ __forceinline__ void eq_double_block(Fr *dp, const EqPoint &P, const int first, const int n) { // n >= 1 variables
+    if (threadIdx.x == 0) {
         Fr g;
-        const FrU gu = fru(g0);
+        const FrU gu = fru(P.g[first]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) g.v[i] = gu.v[i];
         fr_st(dp + 0, scd::fr_sub(scd::fr_one(), g));
         fr_st(dp + 1, g);
     }
-}
-__global__ __launch_bounds__(kBlock) void k_eq_level(Fr *dp, const uint64_t half, const FrHost gi) {
-    const FrU g = fru(gi);
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < half; b += stride) {
-        const Fr prev = fr_ld(dp + b);
-        const Fr hi = scd::fr_mul_u(prev, g);
-        fr_st(dp + b + half, hi);
-        fr_st(dp + b, scd::fr_sub(prev, hi));
+    for (int i = 1; i < n; ++i) {
+        __syncthreads();
+        const FrU g = fru(P.g[first + i]);
+        const uint32_t half = 1u << i;
+        for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
+            const Fr prev = fr_ld(dp + b);
+            const Fr hi = scd::fr_mul_u(prev, g);
+            fr_st(dp + b + half, hi);
+            fr_st(dp + b, scd::fr_sub(prev, hi));
+        }
     }
+}
+// block 0: low kl variables -> lo (2^kl entries); block 1 (if kh > 0): the next kh variables -> hi (2^kh entries)
+__global__ __launch_bounds__(kEqBlock) void k_eq_halves(Fr *lo, Fr *hi, const EqPoint P, const int kl, const int kh) {
+    if (blockIdx.x == 0) eq_double_block(lo, P, 0, kl);
+    else eq_double_block(hi, P, kl, kh);
+}
+__global__ __launch_bounds__(kBlock) void k_eq_outer(const Fr *__restrict__ lo, const Fr *__restrict__ hi, const int kl, const uint64_t n, Fr *__restrict__ eq) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t mask = (1ULL << kl) - 1;
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n; b += stride) fr_st(eq + b, scd::fr_mul(fr_ld(hi + (b >> kl)), fr_ld(lo + (b & mask))));
 }
 // w[i] = eq[idx[i] & mask] * vals[perm ? perm[i] : i] ; key[i] = idx[i] >> k
 __global__ __launch_bounds__(kBlock) void k_sparse_scale(const uint64_t *__restrict__ idx, const Fr *__restrict__ vals,
@@ -138,6 +157,14 @@ __global__ __launch_bounds__(kBlock) void k_scatter_dense(const uint64_t *__rest
     const uint64_t n = *count;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) fr_st(dense + key[i], fr_ld(val + i));
+}
+
+// flag |= 1 if any idx[i] has a bit at or above `bits` (index range check of device-resident inputs)
+__global__ __launch_bounds__(kBlock) void k_idx_range(const uint64_t *__restrict__ idx, const uint64_t n, const uint32_t bits, unsigned int *__restrict__ flag) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) bad |= (idx[i] >> bits) != 0;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
 #define G_TRY(expr)                                                                                                      \
@@ -278,17 +305,27 @@ int sparse_fix(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_t n,
     Fr *w = nullptr;
     G_TRY(mem.alloc(&key, n));
     G_TRY(mem.alloc(&w, n));
-    const bool use_table = k >= 1 && k <= 26 && (1ULL << k) <= 8 * n + 1024;
+    const bool use_table = k >= 1 && k <= (uint32_t)kEqMaxVars && (1ULL << k) <= 8 * n + 1024;
     if (k == 0) {
         G_TRY(hipMemcpyAsync(key, d_idx, n * 8, hipMemcpyDeviceToDevice, s));
         G_TRY(hipMemcpyAsync(w, d_vals, n * 32, hipMemcpyDeviceToDevice, s));
     } else if (use_table) {
         Fr *eq = nullptr;
         G_TRY(mem.alloc(&eq, (size_t)1 << k));
-        hipLaunchKernelGGL(k_eq_init, dim3(1), dim3(kBlock), 0, s, eq, hostfr(point[0]));
-        for (uint32_t i = 1; i < k; ++i) {
-            const uint64_t half = 1ULL << i;
-            hipLaunchKernelGGL(k_eq_level, dim3(grid_for(half)), dim3(kBlock), 0, s, eq, half, hostfr(point[i]));
+        {
+            EqPoint P;
+            std::memset(&P, 0, sizeof(P));
+            for (uint32_t i = 0; i < k; ++i) P.g[i] = hostfr(point[i]);
+            const int kl = (int)std::min<uint32_t>(k, kEqHalfMax), kh = (int)k - kl;
+            if (kh == 0) {
+                hipLaunchKernelGGL(k_eq_halves, dim3(1), dim3(kEqBlock), 0, s, eq, (Fr *)nullptr, P, kl, 0);
+            } else {
+                Fr *lo = nullptr, *hi = nullptr;
+                G_TRY(mem.alloc(&lo, (size_t)1 << kl));
+                G_TRY(mem.alloc(&hi, (size_t)1 << kh));
+                hipLaunchKernelGGL(k_eq_halves, dim3(2), dim3(kEqBlock), 0, s, lo, hi, P, kl, kh);
+                hipLaunchKernelGGL(k_eq_outer, dim3(grid_for(1ULL << k)), dim3(kBlock), 0, s, lo, hi, kl, 1ULL << k, eq);
+            }
         }
         hipLaunchKernelGGL(k_sparse_scale, dim3(grid_for(n)), dim3(kBlock), 0, s, d_idx, d_vals, (const uint32_t *)nullptr, eq, k, n, key, w);
     } else {
@@ -386,45 +423,80 @@ int check_points(const uint64_t *pt, uint32_t n, const char *what) {
     return SC_OK;
 }
 
+// inputs: host arrays are staged into the call's scratch, device arrays (flags & SC_TABLES_ON_DEVICE) are used where they are
+template <typename T>
+int stage_in(DevBuf &mem, const void *src, uint64_t n, bool on_device, const T **out, hipStream_t s) {
+    if (on_device || n == 0) {
+        *out = static_cast<const T *>(src);
+        return SC_OK;
+    }
+    T *d = nullptr;
+    G_TRY(mem.alloc(&d, n));
+    G_TRY(hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+    *out = d;
+    return SC_OK;
+}
+// every index below 2^bits (bits < 64); host arrays are checked on the host, device arrays by a kernel
+int check_index_range(DevBuf &mem, const uint64_t *idx, uint64_t n, uint32_t bits, bool on_device, const char *what, hipStream_t s) {
+    if (bits >= 64 || n == 0) return SC_OK;
+    if (!on_device) {
+        for (uint64_t i = 0; i < n; ++i)
+            if ((idx[i] >> bits) != 0) return sc_internal_fail(SC_ERR_BAD_ARG, "%s index %llu out of range", what, (unsigned long long)i);
+        return SC_OK;
+    }
+    unsigned int *d_flag = nullptr, h = 0;
+    G_TRY(mem.alloc(&d_flag, 1));
+    G_TRY(hipMemsetAsync(d_flag, 0, sizeof(unsigned int), s));
+    hipLaunchKernelGGL(k_idx_range, dim3(grid_for(n)), dim3(kBlock), 0, s, idx, n, bits, d_flag);
+    G_TRY(hipMemcpyAsync(&h, d_flag, sizeof(h), hipMemcpyDeviceToHost, s));
+    G_TRY(hipStreamSynchronize(s));
+    if (h) return sc_internal_fail(SC_ERR_BAD_ARG, "%s has an index out of range", what);
+    return SC_OK;
+}
+
 } // namespace
 
 extern "C" int sc_gkr_phase_one(const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim, const uint64_t *f3,
-                                const uint64_t *g, uint64_t *h_g, uint64_t *f1g_idx, uint64_t *f1g_vals, uint64_t *f1g_nnz) {
+                                const uint64_t *g, uint32_t flags, uint64_t *h_g, uint64_t *f1g_idx, uint64_t *f1g_vals, uint64_t *f1g_nnz) {
     if ((nnz && (!f1_idx || !f1_vals)) || !f3 || !g || !h_g || !f1g_nnz || (nnz && (!f1g_idx || !f1g_vals)))
         return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
     int rc = check_gkr_args(nnz, dim);
     if (rc) return rc;
     if ((rc = check_points(g, dim, "g"))) return rc;
-    for (uint64_t i = 0; i < nnz; ++i)
-        if (dim < 21 && (f1_idx[i] >> (3 * dim)) != 0) return sc_internal_fail(SC_ERR_BAD_ARG, "f1 index %llu out of range", (unsigned long long)i);
+    const bool dev = flags & SC_TABLES_ON_DEVICE;
     hipStream_t s = nullptr;
     DevBuf mem;
     const uint64_t N = 1ULL << dim;
     (void)mem.reserve(gkr_scratch_estimate(nnz, N));
-    uint64_t *d_idx = nullptr, *d_idx_s = nullptr, *d_gi = nullptr;
-    Fr *d_vals = nullptr, *d_vals_s = nullptr, *d_f3 = nullptr, *d_hg = nullptr, *d_gv = nullptr;
+    if ((rc = check_index_range(mem, f1_idx, nnz, 3 * dim, dev, "f1", s))) return rc;
+    const uint64_t *d_idx = nullptr;
+    const Fr *d_vals = nullptr, *d_f3 = nullptr;
+    uint64_t *d_idx_s = nullptr, *d_gi = nullptr;
+    Fr *d_vals_s = nullptr, *d_hg = nullptr, *d_gv = nullptr;
     unsigned int *d_n1 = nullptr;
-    G_TRY(mem.alloc(&d_idx, nnz));
+    if ((rc = stage_in(mem, f1_idx, nnz, dev, &d_idx, s)) || (rc = stage_in(mem, f1_vals, nnz, dev, &d_vals, s)) || (rc = stage_in(mem, f3, N, dev, &d_f3, s)))
+        return rc;
     G_TRY(mem.alloc(&d_idx_s, nnz));
-    G_TRY(mem.alloc(&d_vals, nnz));
     G_TRY(mem.alloc(&d_vals_s, nnz));
-    G_TRY(mem.alloc(&d_f3, N));
-    G_TRY(mem.alloc(&d_hg, N));
-    G_TRY(mem.alloc(&d_gi, nnz));
-    G_TRY(mem.alloc(&d_gv, nnz));
     G_TRY(mem.alloc(&d_n1, 1));
-    if (nnz) {
-        G_TRY(hipMemcpyAsync(d_idx, f1_idx, nnz * 8, hipMemcpyHostToDevice, s));
-        G_TRY(hipMemcpyAsync(d_vals, f1_vals, nnz * 32, hipMemcpyHostToDevice, s));
+    if (dev) { // results are produced in place
+        d_hg = reinterpret_cast<Fr *>(h_g);
+        d_gi = f1g_idx;
+        d_gv = reinterpret_cast<Fr *>(f1g_vals);
+    } else {
+        G_TRY(mem.alloc(&d_hg, N));
+        G_TRY(mem.alloc(&d_gi, nnz));
+        G_TRY(mem.alloc(&d_gv, nnz));
     }
-    G_TRY(hipMemcpyAsync(d_f3, f3, N * 32, hipMemcpyHostToDevice, s));
     if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 3 * dim, d_idx_s, d_vals_s, s))) return rc;
     uint64_t n1 = 0;
     if ((rc = phase_one_device(mem, d_idx_s, d_vals_s, nnz, dim, d_f3, reinterpret_cast<const sch::Fr *>(g), d_hg, d_gi, d_gv, d_n1, &n1, s))) return rc;
-    G_TRY(hipMemcpyAsync(h_g, d_hg, N * 32, hipMemcpyDeviceToHost, s));
-    if (n1) {
-        G_TRY(hipMemcpyAsync(f1g_idx, d_gi, n1 * 8, hipMemcpyDeviceToHost, s));
-        G_TRY(hipMemcpyAsync(f1g_vals, d_gv, n1 * 32, hipMemcpyDeviceToHost, s));
+    if (!dev) {
+        G_TRY(hipMemcpyAsync(h_g, d_hg, N * 32, hipMemcpyDeviceToHost, s));
+        if (n1) {
+            G_TRY(hipMemcpyAsync(f1g_idx, d_gi, n1 * 8, hipMemcpyDeviceToHost, s));
+            G_TRY(hipMemcpyAsync(f1g_vals, d_gv, n1 * 32, hipMemcpyDeviceToHost, s));
+        }
     }
     G_TRY(hipStreamSynchronize(s));
     *f1g_nnz = n1;
@@ -432,31 +504,56 @@ extern "C" int sc_gkr_phase_one(const uint64_t *f1_idx, const uint64_t *f1_vals,
 }
 
 extern "C" int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_vals, uint64_t nnz, uint32_t dim, const uint64_t *u,
-                                uint64_t *f1_gu) {
+                                uint32_t flags, uint64_t *f1_gu) {
     if ((nnz && (!f1g_idx || !f1g_vals)) || !u || !f1_gu) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
     int rc = check_gkr_args(nnz, dim);
     if (rc) return rc;
     if ((rc = check_points(u, dim, "u"))) return rc;
-    for (uint64_t i = 0; i < nnz; ++i)
-        if ((f1g_idx[i] >> (2 * dim)) != 0) return sc_internal_fail(SC_ERR_BAD_ARG, "f1_g index %llu out of range", (unsigned long long)i);
+    const bool dev = flags & SC_TABLES_ON_DEVICE;
     hipStream_t s = nullptr;
     DevBuf mem;
     const uint64_t N = 1ULL << dim;
     (void)mem.reserve(gkr_scratch_estimate(nnz, N));
-    uint64_t *d_idx = nullptr, *d_idx_s = nullptr;
-    Fr *d_vals = nullptr, *d_vals_s = nullptr, *d_out = nullptr;
-    G_TRY(mem.alloc(&d_idx, nnz));
+    if ((rc = check_index_range(mem, f1g_idx, nnz, 2 * dim, dev, "f1_g", s))) return rc;
+    const uint64_t *d_idx = nullptr;
+    const Fr *d_vals = nullptr;
+    uint64_t *d_idx_s = nullptr;
+    Fr *d_vals_s = nullptr, *d_out = nullptr;
+    if ((rc = stage_in(mem, f1g_idx, nnz, dev, &d_idx, s)) || (rc = stage_in(mem, f1g_vals, nnz, dev, &d_vals, s))) return rc;
     G_TRY(mem.alloc(&d_idx_s, nnz));
-    G_TRY(mem.alloc(&d_vals, nnz));
     G_TRY(mem.alloc(&d_vals_s, nnz));
-    G_TRY(mem.alloc(&d_out, N));
-    if (nnz) {
-        G_TRY(hipMemcpyAsync(d_idx, f1g_idx, nnz * 8, hipMemcpyHostToDevice, s));
-        G_TRY(hipMemcpyAsync(d_vals, f1g_vals, nnz * 32, hipMemcpyHostToDevice, s));
-    }
+    if (dev) d_out = reinterpret_cast<Fr *>(f1_gu);
+    else G_TRY(mem.alloc(&d_out, N));
     if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 2 * dim, d_idx_s, d_vals_s, s))) return rc;
     if ((rc = phase_two_device(mem, d_idx_s, d_vals_s, nnz, dim, reinterpret_cast<const sch::Fr *>(u), d_out, s))) return rc;
-    G_TRY(hipMemcpyAsync(f1_gu, d_out, N * 32, hipMemcpyDeviceToHost, s));
+    if (!dev) G_TRY(hipMemcpyAsync(f1_gu, d_out, N * 32, hipMemcpyDeviceToHost, s));
+    G_TRY(hipStreamSynchronize(s));
+    return SC_OK;
+}
+
+extern "C" int sc_dense_scale(const uint64_t *in, uint64_t n, const uint64_t *scalar, uint64_t *out, uint32_t flags) {
+    if ((n && (!in || !out)) || !scalar) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    int rc = check_points(scalar, 1, "scalar");
+    if (rc) return rc;
+    if (n == 0) return SC_OK;
+    if (sc_device_count() <= 0) return sc_internal_fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    G_TRY(hipSetDevice(sc_internal_device()));
+    const bool dev = flags & SC_TABLES_ON_DEVICE;
+    hipStream_t s = nullptr;
+    sch::Fr sv;
+    std::memcpy(&sv, scalar, 32);
+    if (dev) {
+        G_TRY(scd::launch_scale(reinterpret_cast<const uint4 *>(in), reinterpret_cast<uint4 *>(out), hostfr(sv), n, s));
+        G_TRY(hipStreamSynchronize(s));
+        return SC_OK;
+    }
+    DevBuf mem;
+    Fr *d_in = nullptr, *d_out = nullptr;
+    G_TRY(mem.alloc(&d_in, n));
+    G_TRY(mem.alloc(&d_out, n));
+    G_TRY(hipMemcpyAsync(d_in, in, n * 32, hipMemcpyHostToDevice, s));
+    G_TRY(scd::launch_scale(reinterpret_cast<const uint4 *>(d_in), reinterpret_cast<uint4 *>(d_out), hostfr(sv), n, s));
+    G_TRY(hipMemcpyAsync(out, d_out, n * 32, hipMemcpyDeviceToHost, s));
     G_TRY(hipStreamSynchronize(s));
     return SC_OK;
 }
@@ -562,16 +659,16 @@ struct ProverGuard { // declared AFTER the DevBuf it pairs with, so it is destro
 } // namespace
 
 extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim, const uint64_t *f2,
-                            const uint64_t *f3, const uint64_t *g, uint64_t *out_proof, uint64_t *out_uv_or_null) {
+                            const uint64_t *f3, const uint64_t *g, uint32_t flags, uint64_t *out_proof, uint64_t *out_uv_or_null) {
     if (!rng || (nnz && (!f1_idx || !f1_vals)) || !f2 || !f3 || !g || !out_proof) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
     int rc = check_gkr_args(nnz, dim);
     if (rc) return rc;
     if ((rc = check_points(g, dim, "g"))) return rc;
-    for (uint64_t i = 0; i < nnz; ++i)
-        if (dim < 21 && (f1_idx[i] >> (3 * dim)) != 0) return sc_internal_fail(SC_ERR_BAD_ARG, "f1 index %llu out of range", (unsigned long long)i);
+    const bool dev = flags & SC_TABLES_ON_DEVICE;
     hipStream_t s = nullptr;
     DevBuf mem;
     (void)mem.reserve(gkr_scratch_estimate(nnz, 1ULL << dim));
+    if ((rc = check_index_range(mem, f1_idx, nnz, 3 * dim, dev, "f1", s))) return rc;
     const bool trace = std::getenv("SC_GKR_TRACE") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -582,28 +679,24 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
         t_last = now;
     };
     const uint64_t N = 1ULL << dim;
-    uint64_t *d_idx = nullptr, *d_idx_s = nullptr, *d_gi = nullptr;
-    Fr *d_vals = nullptr, *d_vals_s = nullptr, *d_f2 = nullptr, *d_f3 = nullptr, *d_hg = nullptr, *d_gv = nullptr, *d_f1gu = nullptr, *d_f3s = nullptr;
+    const uint64_t *d_idx = nullptr;
+    const Fr *d_vals = nullptr, *d_f2 = nullptr, *d_f3 = nullptr;
+    uint64_t *d_idx_s = nullptr, *d_gi = nullptr;
+    Fr *d_vals_s = nullptr, *d_hg = nullptr, *d_gv = nullptr, *d_f1gu = nullptr, *d_f3s = nullptr, *d_tmp = nullptr;
     unsigned int *d_n1 = nullptr;
-    G_TRY(mem.alloc(&d_idx, nnz));
     G_TRY(mem.alloc(&d_idx_s, nnz));
-    G_TRY(mem.alloc(&d_vals, nnz));
     G_TRY(mem.alloc(&d_vals_s, nnz));
-    G_TRY(mem.alloc(&d_f2, N));
-    G_TRY(mem.alloc(&d_f3, N));
     G_TRY(mem.alloc(&d_hg, N));
     G_TRY(mem.alloc(&d_gi, nnz));
     G_TRY(mem.alloc(&d_gv, nnz));
     G_TRY(mem.alloc(&d_f1gu, N));
     G_TRY(mem.alloc(&d_f3s, N));
+    G_TRY(mem.alloc(&d_tmp, (N >> 3) + 1));
     G_TRY(mem.alloc(&d_n1, 1));
-    if (nnz) {
-        G_TRY(hipMemcpyAsync(d_idx, f1_idx, nnz * 8, hipMemcpyHostToDevice, s));
-        G_TRY(hipMemcpyAsync(d_vals, f1_vals, nnz * 32, hipMemcpyHostToDevice, s));
-    }
     lap("alloc");
-    G_TRY(hipMemcpyAsync(d_f2, f2, N * 32, hipMemcpyHostToDevice, s));
-    G_TRY(hipMemcpyAsync(d_f3, f3, N * 32, hipMemcpyHostToDevice, s));
+    if ((rc = stage_in(mem, f1_idx, nnz, dev, &d_idx, s)) || (rc = stage_in(mem, f1_vals, nnz, dev, &d_vals, s)) ||
+        (rc = stage_in(mem, f2, N, dev, &d_f2, s)) || (rc = stage_in(mem, f3, N, dev, &d_f3, s)))
+        return rc;
     lap("h2d");
     if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 3 * dim, d_idx_s, d_vals_s, s))) return rc;
     lap("sort f1");
@@ -618,17 +711,30 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     lap("phase one sumcheck");
     if ((rc = phase_two_device(mem, d_gi, d_gv, n1, dim, u.data(), d_f1gu, s))) return rc; // mod.rs:121
     lap("phase two init");
-    // f2.evaluate(&u) (mod.rs:122): bind all dim variables on the device
+    // f2.evaluate(&u) (mod.rs:122): all dim variables bound on the device, three per pass (8 entries in, 1 out), ping-ponging between
+    // two buffers that are free at this point (h_g is spent, d_tmp holds an eighth of it)
     sch::Fr f2_u;
     G_TRY(hipStreamSynchronize(s));
-    { // bind all dim variables of f2, ping-ponging between two buffers that are free at this point (h_g is spent, f3*f2(u) not yet built)
+    {
         const uint4 *cur = reinterpret_cast<const uint4 *>(d_f2);
-        uint4 *pp[2] = {reinterpret_cast<uint4 *>(d_hg), reinterpret_cast<uint4 *>(d_f3s)};
+        uint4 *pp[2] = {reinterpret_cast<uint4 *>(d_hg), reinterpret_cast<uint4 *>(d_tmp)};
         uint64_t m = N;
-        for (uint32_t i = 0; i < dim; ++i) {
-            m >>= 1;
-            G_TRY(scd::launch_fix(cur, pp[i & 1], hostfr(u[i]), m, s));
-            cur = pp[i & 1];
+        uint32_t var = 0;
+        for (int pass = 0; var < dim; ++pass) {
+            const int L = (dim - var) >= 3 ? 3 : (int)(dim - var);
+            m >>= L;
+            scd::FoldArgs fa;
+            std::memset(&fa, 0, sizeof(fa));
+            fa.src[0] = cur;
+            fa.dst[0] = pp[pass & 1];
+            for (int l = 0; l < L; ++l) {
+                sch::Fr r32v = u[var + l]; // r * 2^5 for the 2^261-radix arithmetic of the fold kernel
+                for (int dbl = 0; dbl < 5; ++dbl) r32v = sch::add(r32v, r32v);
+                fa.r32[l] = hostfr(r32v);
+            }
+            G_TRY(scd::launch_fold_multi(fa, L, 1, m, s));
+            cur = pp[pass & 1];
+            var += L;
         }
         G_TRY(hipMemcpyAsync(&f2_u, cur, 32, hipMemcpyDeviceToHost, s));
         G_TRY(hipStreamSynchronize(s));

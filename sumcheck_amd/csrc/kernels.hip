@@ -1019,7 +1019,15 @@ hipError_t launch_prod_tree(int M, const ProdArgs &args, const BindConst &r32, u
 }
 
 hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL(k_round_tree, dim3(grid), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
+    size_t extra_lds = 0;
+#ifdef SC_EXPERIMENTS // SC_EXTRA_LDS: unused dynamic LDS per block, to lower the number of resident blocks per CU (occupancy experiments)
+    static const size_t env_lds = [] {
+        const char *e = std::getenv("SC_EXTRA_LDS");
+        return e ? (size_t)std::strtoul(e, nullptr, 10) : (size_t)0;
+    }();
+    extra_lds = env_lds;
+#endif
+    hipLaunchKernelGGL(k_round_tree, dim3(grid), dim3(kBlock), extra_lds, stream, args, r32, n_pairs, (uint4 *)d_partials);
     return hipGetLastError();
 }
 

@@ -17,19 +17,43 @@ from typing import List, Sequence
 import numpy as np
 
 from . import field
-from ._lib import check, lib
+from ._lib import SC_TABLES_ON_DEVICE, check, lib
 from .ml_sumcheck import (Blake2b512Rng, DenseMultilinearExtension, IPForMLSumcheck, ListOfProductsOfPolynomials, ProverMsg,
                           ProverState, SumcheckError, _np64, _ptr, interpolate_uni_poly)
 
 
+def _is_cuda(x) -> bool:
+    return type(x).__module__.startswith("torch") and x.is_cuda
+
+
 class SparseMultilinearExtension:
-    """ark_poly::SparseMultilinearExtension: `indices` (nnz,) uint64 distinct, `values` (nnz, 4) Montgomery limbs."""
+    """ark_poly::SparseMultilinearExtension: `indices` (nnz,) uint64 distinct, `values` (nnz, 4) Montgomery limbs -- numpy arrays
+    (host) or torch int64 tensors on the GPU (HBM-resident; the library then reads them in place)."""
 
     def __init__(self, num_vars: int, indices, values):
         self.num_vars = num_vars
-        self.indices = np.ascontiguousarray(indices, dtype=np.uint64).reshape(-1)
-        self.values = _np64(values).reshape(-1, 4)
-        assert self.indices.shape[0] == self.values.shape[0]
+        self.on_device = _is_cuda(indices) and _is_cuda(values)
+        if self.on_device:
+            assert indices.is_contiguous() and values.is_contiguous() and values.numel() == 4 * indices.numel()
+            self.indices, self.values = indices, values
+        else:
+            self.indices = np.ascontiguousarray(indices, dtype=np.uint64).reshape(-1)
+            self.values = _np64(values).reshape(-1, 4)
+            assert self.indices.shape[0] == self.values.shape[0]
+
+    @property
+    def nnz(self) -> int:
+        return int(self.indices.shape[0])
+
+    def _ptrs(self):
+        if self.on_device:
+            return C.c_void_p(self.indices.data_ptr()), C.c_void_p(self.values.data_ptr())
+        return _ptr(self.indices), _ptr(self.values)
+
+    def to_host(self) -> "SparseMultilinearExtension":
+        if not self.on_device:
+            return self
+        return SparseMultilinearExtension(self.num_vars, self.indices.cpu().numpy().view(np.uint64), self.values.cpu().numpy().view(np.uint64))
 
     @classmethod
     def from_evaluations(cls, num_vars: int, evaluations):
@@ -40,27 +64,44 @@ class SparseMultilinearExtension:
     def evaluate(self, point) -> np.ndarray:
         """ark-poly SparseMultilinearExtension::evaluate on the GPU (sc_sparse_evaluate): the verifier's oracle query
         f1(g, u, v) of verify_subclaim (data_structures.rs:53)"""
+        h = self.to_host()
         pt = np.ascontiguousarray(np.asarray(point, dtype=np.uint64).reshape(-1, 4))
         assert pt.shape[0] == self.num_vars
         out = np.zeros(4, dtype=np.uint64)
-        check(lib().sc_sparse_evaluate(_ptr(self.indices), _ptr(self.values), self.indices.shape[0], self.num_vars,
+        check(lib().sc_sparse_evaluate(_ptr(h.indices), _ptr(h.values), h.indices.shape[0], self.num_vars,
                                        _ptr(pt) if pt.size else None, _ptr(out)))
         return out
 
 
+def _dense_ptr(m: DenseMultilinearExtension):
+    return C.c_void_p(m.data_ptr()) if m.on_device else _ptr(m.evaluations)
+
+
 def initialize_phase_one(f1: SparseMultilinearExtension, f3: DenseMultilinearExtension, g):
-    """mod.rs:22-42 -> (h_g dense, f1_at_g sparse)"""
+    """mod.rs:22-42 -> (h_g dense, f1_at_g sparse).  Device-resident inputs (f1 and f3 both on the GPU) give device-resident
+    outputs, produced in place by the library."""
     dim = f3.num_vars
     assert f1.num_vars == dim * 3
     g = _np64(g).reshape(-1, 4)
     assert g.shape[0] == dim
-    nnz = f1.indices.shape[0]
+    nnz = f1.nnz
+    dev = f1.on_device and f3.on_device
+    assert dev or not (f1.on_device or f3.on_device), "mixing host and device inputs is not supported"
+    n1 = C.c_uint64()
+    i_ptr, v_ptr = f1._ptrs()
+    if dev:
+        import torch
+        h_g = torch.empty((1 << dim, 4), dtype=torch.int64, device=f3.evaluations.device)
+        oi = torch.empty(max(nnz, 1), dtype=torch.int64, device=h_g.device)
+        ov = torch.empty((max(nnz, 1), 4), dtype=torch.int64, device=h_g.device)
+        torch.cuda.current_stream(h_g.device).synchronize()  # the library works on its own stream
+        check(lib().sc_gkr_phase_one(i_ptr, v_ptr, nnz, dim, _dense_ptr(f3), _ptr(g), SC_TABLES_ON_DEVICE, C.c_void_p(h_g.data_ptr()),
+                                     C.c_void_p(oi.data_ptr()), C.c_void_p(ov.data_ptr()), C.byref(n1)))
+        return DenseMultilinearExtension(dim, h_g), SparseMultilinearExtension(2 * dim, oi[: n1.value].contiguous(), ov[: n1.value].contiguous())
     h_g = np.empty((1 << dim, 4), dtype=np.uint64)
     oi = np.empty(max(nnz, 1), dtype=np.uint64)
     ov = np.empty((max(nnz, 1), 4), dtype=np.uint64)
-    n1 = C.c_uint64()
-    f3e = _np64(f3.evaluations)
-    check(lib().sc_gkr_phase_one(_ptr(f1.indices), _ptr(f1.values), nnz, dim, _ptr(f3e), _ptr(g), _ptr(h_g), _ptr(oi), _ptr(ov), C.byref(n1)))
+    check(lib().sc_gkr_phase_one(i_ptr, v_ptr, nnz, dim, _dense_ptr(f3), _ptr(g), 0, _ptr(h_g), _ptr(oi), _ptr(ov), C.byref(n1)))
     return DenseMultilinearExtension(dim, h_g), SparseMultilinearExtension(2 * dim, oi[: n1.value].copy(), ov[: n1.value].copy())
 
 
@@ -78,17 +119,38 @@ def initialize_phase_two(f1_g: SparseMultilinearExtension, u) -> DenseMultilinea
     u = _np64(u).reshape(-1, 4)
     assert u.shape[0] * 2 == f1_g.num_vars
     dim = u.shape[0]
+    i_ptr, v_ptr = f1_g._ptrs()
+    if f1_g.on_device:
+        import torch
+        out = torch.empty((1 << dim, 4), dtype=torch.int64, device=f1_g.values.device)
+        torch.cuda.current_stream(out.device).synchronize()
+        check(lib().sc_gkr_phase_two(i_ptr, v_ptr, f1_g.nnz, dim, _ptr(u), SC_TABLES_ON_DEVICE, C.c_void_p(out.data_ptr())))
+        return DenseMultilinearExtension(dim, out)
     out = np.empty((1 << dim, 4), dtype=np.uint64)
-    check(lib().sc_gkr_phase_two(_ptr(f1_g.indices), _ptr(f1_g.values), f1_g.indices.shape[0], dim, _ptr(u), _ptr(out)))
+    check(lib().sc_gkr_phase_two(i_ptr, v_ptr, f1_g.nnz, dim, _ptr(u), 0, _ptr(out)))
     return DenseMultilinearExtension(dim, out)
 
 
+def scale(m: DenseMultilinearExtension, scalar) -> DenseMultilinearExtension:
+    """`DenseMultilinearExtension::zero() += (scalar, &m)` (mod.rs:71-75) on the GPU: every evaluation times one field element"""
+    sv = _np64(scalar).reshape(4)
+    n = 1 << m.num_vars
+    if m.on_device:
+        import torch
+        out = torch.empty_like(m.evaluations)
+        torch.cuda.current_stream(out.device).synchronize()
+        check(lib().sc_dense_scale(_dense_ptr(m), n, _ptr(sv), C.c_void_p(out.data_ptr()), SC_TABLES_ON_DEVICE))
+    else:
+        out = np.empty((n, 4), dtype=np.uint64)
+        check(lib().sc_dense_scale(_dense_ptr(m), n, _ptr(sv), _ptr(out), 0))
+    return DenseMultilinearExtension(m.num_vars, out)
+
+
 def start_phase2_sumcheck(f1_gu: DenseMultilinearExtension, f3: DenseMultilinearExtension, f2_u) -> ProverState:
-    """mod.rs:66-82: f3 scaled by the scalar f2(u), then one product of two tables"""
+    """mod.rs:66-82: f3 scaled by the scalar f2(u) (on the GPU), then one product of two tables"""
     dim = f1_gu.num_vars
     assert f3.num_vars == dim
-    s = field.to_int(f2_u)
-    f3_f2u = DenseMultilinearExtension(dim, field.from_ints([s * x % field.P for x in field.to_ints(_np64(f3.evaluations))]))
+    f3_f2u = scale(f3, f2_u)
     poly = ListOfProductsOfPolynomials.new(dim)
     poly.add_product([f1_gu, f3_f2u], field.ONE)
     return IPForMLSumcheck.prover_init(poly)
@@ -132,7 +194,11 @@ def _verify_phase(rng: Blake2b512Rng, msgs: Sequence[ProverMsg], dim: int, asser
         ev = msgs[i].evaluations
         if ev.shape[0] != 3:
             raise SumcheckError(5, "incorrect number of evaluations")
-        if (field.to_int(ev[0]) + field.to_int(ev[1])) % field.P != expected:
+        try:  # field.to_int refuses limbs >= p: a proof element must be a canonical field element
+            s01 = (field.to_int(ev[0]) + field.to_int(ev[1])) % field.P
+        except ValueError:
+            raise SumcheckError(5, "proof element is not a canonical field element")
+        if s01 != expected:
             raise SumcheckError(8, "Prover message is not consistent with the claim.")
         expected = field.to_int(interpolate_uni_poly(ev, rs[i]))
     return np.stack(rs) if rs else np.zeros((0, 4), np.uint64), field.from_int(expected)
@@ -148,9 +214,14 @@ class GKRRoundSumcheck:
         g = _np64(g).reshape(-1, 4)
         assert g.shape[0] == dim
         proof = np.empty((2, max(dim, 1), 3, 4), dtype=np.uint64)
-        f2e, f3e = _np64(f2.evaluations), _np64(f3.evaluations)
-        check(lib().sc_gkr_prove(rng._h, _ptr(f1.indices), _ptr(f1.values), f1.indices.shape[0], dim, _ptr(f2e), _ptr(f3e), _ptr(g),
-                                 _ptr(proof), None))
+        dev = f1.on_device and f2.on_device and f3.on_device
+        assert dev or not (f1.on_device or f2.on_device or f3.on_device), "mixing host and device inputs is not supported"
+        if dev:
+            import torch
+            torch.cuda.current_stream(f2.evaluations.device).synchronize()  # the library works on its own stream
+        i_ptr, v_ptr = f1._ptrs()
+        check(lib().sc_gkr_prove(rng._h, i_ptr, v_ptr, f1.nnz, dim, _dense_ptr(f2), _dense_ptr(f3), _ptr(g),
+                                 SC_TABLES_ON_DEVICE if dev else 0, _ptr(proof), None))
         return GKRProof([ProverMsg(proof[0, i].copy()) for i in range(dim)], [ProverMsg(proof[1, i].copy()) for i in range(dim)])
 
     @staticmethod

@@ -350,6 +350,61 @@ def test_gkr_config5_dim20():
     assert np.array_equal(np.stack([m.evaluations for m in proof.phase2_sumcheck_msgs]), want[1])
 
 
+def test_gkr_device_resident_inputs_and_interactive_phases():
+    """sc_gkr_* with SC_TABLES_ON_DEVICE (inputs read in place from HBM, the initialisation outputs produced in place), and the
+    reference's interactive pieces around them: initialize_phase_one -> start_phase1_sumcheck -> dim rounds -> initialize_phase_two
+    -> f2.evaluate(u) -> start_phase2_sumcheck -> dim rounds (mod.rs:100-133), every message against the fused proof and the oracle"""
+    import torch
+    dev = _torch_dev()
+    dim = 11
+    idx, vals, f2, f3, g = _random_gkr(dim, 777, collide=True)
+    td = lambda a: torch.from_numpy(a.view(np.int64)).to(dev)
+    f1d = sc.SparseMultilinearExtension(3 * dim, td(idx), td(vals))
+    f2d, f3d = sc.DenseMultilinearExtension(dim, td(f2)), sc.DenseMultilinearExtension(dim, td(f3))
+    want, wuv = cref.gkr_prove(idx, vals, dim, f2, f3, g, threads=cref.max_threads())
+    proof = sc.GKRRoundSumcheck.prove(sc.Blake2b512Rng.setup(), f1d, f2d, f3d, g)
+    assert np.array_equal(np.stack([m.evaluations for m in proof.phase1_sumcheck_msgs]), want[0])
+    assert np.array_equal(np.stack([m.evaluations for m in proof.phase2_sumcheck_msgs]), want[1])
+    for t, h in ((f1d.values, vals), (f2d.evaluations, f2), (f3d.evaluations, f3)):  # inputs are only read
+        assert np.array_equal(t.cpu().numpy().view(np.uint64), h)
+    # interactive flow on device-resident tables
+    h_g, f1_g = sc.initialize_phase_one(f1d, f3d, g)
+    wh, wi, wv = cref.gkr_phase_one(idx, vals, dim, f3, g)
+    assert h_g.on_device and f1_g.on_device
+    assert np.array_equal(h_g.evaluations.cpu().numpy().view(np.uint64), wh)
+    assert np.array_equal(f1_g.indices.cpu().numpy().view(np.uint64), wi) and np.array_equal(f1_g.values.cpu().numpy().view(np.uint64), wv)
+    rng = sc.Blake2b512Rng.setup()
+    st, u, v_msg = sc.start_phase1_sumcheck(h_g, f2d), [], None
+    for i in range(dim):
+        m = sc.IPForMLSumcheck.prove_round(st, v_msg)
+        assert np.array_equal(m.evaluations, want[0][i]), f"phase 1 round {i + 1}"
+        rng.feed(m)
+        v_msg = sc.IPForMLSumcheck.sample_round(rng)
+        u.append(v_msg.randomness)
+    u = np.stack(u)
+    assert np.array_equal(u, wuv[0])
+    f1_gu = sc.initialize_phase_two(f1_g, u)
+    assert np.array_equal(f1_gu.evaluations.cpu().numpy().view(np.uint64), cref.gkr_phase_two(wi, wv, dim, u))
+    f2_u = f2d.evaluate(u)
+    assert np.array_equal(f2_u, cref.fix_variables(f2, u).reshape(4))
+    scaled = sc.gkr_round_sumcheck.scale(f3d, f2_u)
+    f2u_int = field.to_int(f2_u)
+    assert field.to_ints(scaled.evaluations.cpu().numpy().view(np.uint64)[:50]) == [x * f2u_int % field.P for x in field.to_ints(f3[:50])]
+    assert np.array_equal(sc.gkr_round_sumcheck.scale(sc.DenseMultilinearExtension(dim, f3), f2_u).evaluations,
+                          scaled.evaluations.cpu().numpy().view(np.uint64))  # host-array flavour of sc_dense_scale
+    st2, v_msg = sc.start_phase2_sumcheck(f1_gu, f3d, f2_u), None  # mod.rs:66-82, 122-133
+    for i in range(dim):
+        m = sc.IPForMLSumcheck.prove_round(st2, v_msg)
+        assert np.array_equal(m.evaluations, want[1][i]), f"phase 2 round {i + 1}"
+        rng.feed(m)
+        v_msg = sc.IPForMLSumcheck.sample_round(rng)
+    # a device-resident index out of range is caught by the device-side check
+    bad = td(idx).clone()
+    bad[3] = 1 << 62
+    with pytest.raises(sc.SumcheckError, match="out of range"):
+        sc.GKRRoundSumcheck.prove(sc.Blake2b512Rng.setup(), sc.SparseMultilinearExtension(3 * dim, bad, td(vals)), f2d, f3d, g)
+
+
 def test_config4_shard_shape_nv25():
     """BASELINE config 4 is nv=28 over 8 GPUs: every GPU holds an nv=25 shard of the 3 tables (3 GiB).  One such shard as a
     stand-alone instance, checked through the size-independent relations (the sharded protocol itself is covered by the gloo
