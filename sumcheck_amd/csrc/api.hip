@@ -172,8 +172,11 @@ struct sc_prover {
     FrHost *h_mail = nullptr;       // host-mapped, two slots (+ the word above)
     FrHost *h_mail_dev = nullptr;
     FrHost *d_mail = nullptr;       // device-memory copy of the slot in use (two slots), filled by the wait kernel
+    uint32_t *d_tail_sync = nullptr; // persistent tail kernel: 4 sync words + 2 challenge slots (device)
+    int tail_max_blocks = 0;        // blocks of it the device holds at once (its grid never exceeds that)
     bool pipeline_ok = true;        // cleared when the wait-value path is unavailable (or SC_PIPELINE=0)
     bool deferred_pending = false;  // a round is enqueued behind the wait and still needs its challenge
+    bool use_tail = true;           // sc_ml_prove* / GKR: the latency-bound rounds run in the persistent tail kernel (SC_TAIL=0: pipelined launches)
     bool merge_rounds = false; // big rounds run as ONE launch over all products (k_round_tree): <= kMaxRoundProds products of <= 4 multiplicands
     bool use_f29 = false; // bound tables of big rounds kept in the internal 9 x 29-bit format (all products <= 4 multiplicands)
     // The production path is fixed: product tree, carry-free arithmetic.  A -DSC_EXPERIMENTS build (libsumcheck_hip_exp.so, used by
@@ -217,6 +220,7 @@ static void prover_destroy(sc_prover *p) {
     if (p->d_combos) (void)hipFree(p->d_combos);
     if (p->h_mail) (void)hipHostFree(p->h_mail);
     if (p->d_mail) (void)hipFree(p->d_mail);
+    if (p->d_tail_sync) (void)hipFree(p->d_tail_sync);
     if (p->d_cur_tables) (void)hipFree(p->d_cur_tables);
     if (p->h_cur_tables) (void)hipHostFree(p->h_cur_tables);
     if (p->d_slot_table) (void)hipFree(p->d_slot_table);
@@ -322,6 +326,7 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
         if (d->prod_offsets[k + 1] - d->prod_offsets[k] > 4) p->merge_rounds = false;
 #ifdef SC_EXPERIMENTS
     if (const char *e = std::getenv("SC_MERGE")) p->merge_rounds = p->merge_rounds && std::atoi(e) != 0;
+    if (const char *e = std::getenv("SC_TAIL")) p->use_tail = std::atoi(e) != 0; // 0: late rounds as pipelined launches (the path sharded RCCL proofs take)
 #endif
 
     // products: distinct tables + multiplicities
@@ -513,8 +518,12 @@ static bool launches_are_async(sc_prover *p) {
                     hipMalloc(reinterpret_cast<void **>(&dm), sizeof(FrHost)) == hipSuccess;
         if (good) {
             std::memset(h, 0, 256);
+            // (a first launch of the process also loads the code object: milliseconds that say nothing about the launch mode)
+            good = scd::launch_wait_challenge(d, 0xffffffffu, reinterpret_cast<const FrHost *>(d + 16), dm, p->stream, 1) == hipSuccess &&
+                   hipStreamSynchronize(p->stream) == hipSuccess;
+            __atomic_store_n(h + 1, 0u, __ATOMIC_RELEASE);
             const auto t0 = std::chrono::steady_clock::now();
-            good = scd::launch_wait_challenge(d, 0xffffffffu, reinterpret_cast<const FrHost *>(d + 16), dm, p->stream, 1u << 11) == hipSuccess;
+            good = good && scd::launch_wait_challenge(d, 0xffffffffu, reinterpret_cast<const FrHost *>(d + 16), dm, p->stream, 1u << 11) == hipSuccess;
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             (void)hipStreamSynchronize(p->stream);
             good = good && ms < 1.0; // 2^11 polls take a few milliseconds; an asynchronous launch call a few microseconds
@@ -527,41 +536,49 @@ static bool launches_are_async(sc_prover *p) {
     return ok;
 }
 
-// Pipelined late rounds.  can_defer_next: the NEXT round is a latency-bound one and the wait-value machinery is available.
+// The host-mapped mailbox (two challenge slots + the signal word the device polls) of the pipelined rounds and of the persistent
+// tail kernel.  First use sets it up; any failure -- or a runtime that serialises launches, or SC_PIPELINE=0 -- switches both off
+// for this handle.
+static bool ensure_mailbox(sc_prover *p) {
+    if (!p->pipeline_ok) return false;
+    if (p->sig) return true;
+    const char *env = std::getenv("SC_PIPELINE"); // read per handle, at its first late round
+    bool env_off = env && std::atoi(env) == 0;
+    // a runtime that makes every launch wait for its kernel would block on the waiting kernel until its bound expires
+    for (const char *name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"}) {
+        const char *v = std::getenv(name);
+        if (v && std::atoi(v) != 0) env_off = true;
+    }
+    bool ok = !env_off && hipSetDevice(p->device) == hipSuccess && launches_are_async(p);
+    // layout: [0, 64) two challenge slots (k_wait_challenge) | [64, 128) signal word + give-up marker | [128, 256) two slots of eight
+    // tagged 64-bit words (k_tail_rounds)
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->h_mail), 256, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    if (ok) std::memset(p->h_mail, 0, 256);
+    ok = ok && hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_mail_dev), p->h_mail, 0) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void **>(&p->d_mail), 2 * sizeof(FrHost)) == hipSuccess;
+    if (ok) {
+        p->sig = reinterpret_cast<uint32_t *>(p->h_mail + 2);
+        p->sig_dev = reinterpret_cast<uint32_t *>(p->h_mail_dev + 2);
+        __atomic_store_n(p->sig, 0u, __ATOMIC_RELEASE);
+        __atomic_store_n(p->sig + 1, 0u, __ATOMIC_RELEASE); // give-up marker of the waiting kernel
+        p->sig_seq = 0;
+        return true;
+    }
+    (void)hipGetLastError();
+    if (p->h_mail) (void)hipHostFree(p->h_mail);
+    if (p->d_mail) (void)hipFree(p->d_mail);
+    p->sig = nullptr;
+    p->h_mail = nullptr;
+    p->d_mail = nullptr;
+    p->pipeline_ok = false;
+    return false;
+}
+// Pipelined late rounds.  can_defer_next: the NEXT round is a latency-bound one and the mailbox machinery is available.
 static bool can_defer_next(sc_prover *p) {
     if (!p->pipeline_ok || p->exhausted || p->round == 0 || p->round >= p->nv) return false;
     const uint64_t n_pairs_next = 1ULL << (p->nv - (p->round + 1));
     if (!(n_pairs_next <= small_pairs_limit() && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0)) return false;
-    if (!p->sig) { // first use: signal word + mailbox; any failure switches pipelining off for this handle
-        const char *env = std::getenv("SC_PIPELINE"); // read per handle, at its first late round
-        bool env_off = env && std::atoi(env) == 0;
-        // a runtime that makes every launch wait for its kernel would block on the wait kernel until its bound expires
-        for (const char *name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"}) {
-            const char *v = std::getenv(name);
-            if (v && std::atoi(v) != 0) env_off = true;
-        }
-        bool ok = !env_off && hipSetDevice(p->device) == hipSuccess && launches_are_async(p);
-        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->h_mail), 2 * sizeof(FrHost) + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
-        ok = ok && hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_mail_dev), p->h_mail, 0) == hipSuccess;
-        ok = ok && hipMalloc(reinterpret_cast<void **>(&p->d_mail), 2 * sizeof(FrHost)) == hipSuccess;
-        if (ok) {
-            p->sig = reinterpret_cast<uint32_t *>(p->h_mail + 2);
-            p->sig_dev = reinterpret_cast<uint32_t *>(p->h_mail_dev + 2);
-            __atomic_store_n(p->sig, 0u, __ATOMIC_RELEASE);
-            __atomic_store_n(p->sig + 1, 0u, __ATOMIC_RELEASE); // give-up marker of the wait kernel
-            p->sig_seq = 0;
-        } else {
-            (void)hipGetLastError();
-            if (p->h_mail) (void)hipHostFree(p->h_mail);
-            if (p->d_mail) (void)hipFree(p->d_mail);
-            p->sig = nullptr;
-            p->h_mail = nullptr;
-            p->d_mail = nullptr;
-            p->pipeline_ok = false;
-            return false;
-        }
-    }
-    return true;
+    return ensure_mailbox(p);
 }
 // the challenge of the round enqueued with deferred = true: mailbox first, then the signal the stream is waiting on
 static void provide_challenge(sc_prover *p, const sch::Fr &r) {
@@ -893,6 +910,142 @@ static int await_round(sc_prover *p, uint64_t *out_evals, const uint32_t want) {
     return SC_OK;
 }
 
+// ---- the persistent tail: every remaining latency-bound round in ONE kernel launch (kernels.hip: k_tail_rounds) -------------
+// Usable when the round metadata fits kernel arguments (tail_shape_ok), the next round is a small one, and launches are
+// asynchronous (the kernel waits for the host; SC_PIPELINE=0 switches it off together with the pipelined rounds).
+constexpr size_t kTailSyncBytes = 4 * (16 + (size_t)scd::kTailMaxGrid);
+static bool tail_shape_ok(const sc_prover *p) {
+    return p->use_tail && p->K > 0 && p->U <= (uint32_t)scd::kMaxSmallTables && p->has_meta && p->K <= (uint32_t)scd::kMetaProds &&
+           (size_t)p->K * p->D * (p->D + 2) * 32 <= 48 * 1024;
+}
+static bool tail_possible(sc_prover *p) {
+    if (!tail_shape_ok(p) || p->exhausted || p->round >= p->nv || p->deferred_pending) return false;
+    if ((1ULL << (p->nv - (p->round + 1))) > std::min<uint64_t>(small_pairs_limit(), scd::kTailMaxPairs)) return false;
+    if (!ensure_mailbox(p)) return false;
+    if (!p->d_tail_sync) {
+        // 16 sync words + one arrival flag per block | 2 challenge slots | K * D node sums
+        if (hipMalloc(reinterpret_cast<void **>(&p->d_tail_sync), kTailSyncBytes + 64 + (size_t)p->K * p->D * 32) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        p->tail_max_blocks = scd::tail_max_resident_blocks(p->device);
+    }
+    return p->tail_max_blocks > 0;
+}
+
+// n_rounds rounds (prove_round, feed, sample) starting at the handle's next round; r_or_null = the challenge that round binds
+static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, const sch::Fr *r_or_null, uint64_t *out_msgs, sch::Fr *out_challenges) {
+    HIP_TRY(hipSetDevice(p->device));
+    int rc_t = collect_timing(p);
+    if (rc_t) return rc_t;
+    const uint32_t D = p->D;
+    scd::TailArgs A;
+    std::memset(&A, 0, sizeof(A));
+    for (uint32_t u = 0; u < p->U; ++u) {
+        Table &t = p->tabs[u];
+        A.t.cur0[u] = t.cur;
+        A.t.cur0_top[u] = t.cur_top;
+        A.t.b0[u] = t.buf[t.next];
+        A.t.b1[u] = t.buf[t.next ^ 1];
+    }
+    A.n_tables = (int)p->U;
+    A.n_rounds = (int)n_rounds;
+    A.first_has_bind = r_or_null ? 1 : 0;
+    A.first_pairs = 1ULL << (p->nv - (p->round + 1));
+    if (r_or_null) A.r0 = to_dev(*r_or_null);
+    A.n_combos = p->n_combos;
+    A.K = (int)p->K;
+    A.D = (int)D;
+    A.Wm = reinterpret_cast<const uint4 *>(p->d_W);
+    A.partials = reinterpret_cast<uint4 *>(p->d_partials);
+    A.sync = p->d_tail_sync;
+    A.chal = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(p->d_tail_sync) + kTailSyncBytes);
+    A.sums = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(p->d_tail_sync) + kTailSyncBytes + 64);
+    A.h_out = reinterpret_cast<uint4 *>(p->h_out_dev);
+    A.h_flag = p->h_flag_dev;
+    A.seq0 = p->seq + 1;
+    A.sig = p->sig_dev;
+    A.mail_host = reinterpret_cast<const uint64_t *>(p->h_mail_dev) + 16; // the tagged slots (byte offset 128)
+    A.sig0 = p->sig_seq;
+    A.max_spins = scd::wait_spins_default();
+    scd::FinMeta fm;
+    std::memset(&fm, 0, sizeof(fm));
+    std::memcpy(fm.prod, p->h_finprods.data(), (size_t)p->K * sizeof(FinProd));
+    int grid = 1; // (the kernel's tail_active_blocks for the first round)
+    if (A.first_pairs > (uint64_t)scd::kTailFlatPairs) {
+        const uint64_t bind_blocks = (2 * A.first_pairs * p->U + scd::kBlock - 1) / scd::kBlock;
+        const uint64_t sum_blocks = ((A.first_pairs + scd::kBlock - 1) / scd::kBlock) * (uint64_t)p->n_combos;
+        grid = (int)std::min<uint64_t>((uint64_t)p->tail_max_blocks, std::max(bind_blocks, sum_blocks));
+    }
+    HIP_TRY(hipMemsetAsync(p->d_tail_sync, 0, kTailSyncBytes + 64, p->stream));
+    HIP_TRY(scd::launch_tail_rounds(A, p->meta, fm, grid, p->stream));
+    p->seq += n_rounds;
+    p->sig_seq += n_rounds - 1;
+    if (r_or_null) p->randomness.push_back(*r_or_null); // bound by the first of these rounds (prover.rs:84)
+    // the host's half: wait for a message, hash, answer
+    static const bool trace = std::getenv("SC_HOST_TRACE") != nullptr; // stderr: arrival time of every tail message
+    auto t_prev = std::chrono::steady_clock::now();
+    int rc = SC_OK;
+    for (uint32_t j = 0; j < n_rounds; ++j) {
+        uint64_t *pm = out_msgs + (size_t)j * D * 4;
+        if (rc == SC_OK) {
+            uint64_t spins = 0;
+            bool seen = false;
+            const auto t_start = std::chrono::steady_clock::now();
+            while (!(seen = (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) == A.seq0 + j))) {
+                if ((++spins & 0xfff) == 0) {
+                    if (wait_gave_up(p)) break;
+                    if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) break;
+                }
+            }
+            if (!seen || wait_gave_up(p))
+                rc = fail(SC_ERR_HIP, wait_gave_up(p) ? "the host took longer than the wait kernel's bound to deliver a challenge; the proof is void"
+                                                      : "a tail round did not publish its message within 20 s");
+        }
+        if (trace) {
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[sc] tail round %u (%llu pairs): message after %.1f us\n", p->round + j + 1,
+                         (unsigned long long)(A.first_pairs >> j), std::chrono::duration<double, std::micro>(now - t_prev).count());
+            t_prev = now;
+        }
+        sch::Fr vm = sch::zero();
+        if (rc == SC_OK) {
+            std::memcpy(pm, p->h_out, (size_t)D * 32);
+            rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(pm), D); // mod.rs:61
+            vm = rng.sample_fr();                                           // mod.rs:63
+            if (out_challenges) out_challenges[j] = vm;
+        }
+        if (j + 1 < n_rounds) { // (on the error path: a zero challenge, so that the kernel runs to its end and the stream drains)
+            const uint32_t sv = A.sig0 + j + 1;
+            uint64_t *slot = reinterpret_cast<uint64_t *>(p->h_mail) + 16 + 8 * (sv & 1u);
+            for (int i = 0; i < 8; ++i) { // 32-bit limb i, tagged: every word validates itself, the device's poll IS the fetch
+                const uint32_t limb = (uint32_t)(vm.l[i >> 1] >> (32 * (i & 1)));
+                __atomic_store_n(slot + i, ((uint64_t)limb << 32) | sv, __ATOMIC_RELEASE);
+            }
+            if (rc == SC_OK) p->randomness.push_back(vm);
+        }
+    }
+    if (rc != SC_OK) {
+        (void)hipStreamSynchronize(p->stream);
+        p->exhausted = true; // tables are no longer meaningful: the handle must be reset
+        return rc;
+    }
+    // the handle's state after the tail: rounds done, challenges bound, where the tables are
+    p->round += n_rounds;
+    const uint32_t nb = n_rounds - 1 + (r_or_null ? 1 : 0);
+    if (nb > 0) {
+        for (uint32_t u = 0; u < p->U; ++u) {
+            Table &t = p->tabs[u];
+            uint4 *b0 = t.buf[t.next], *b1 = t.buf[t.next ^ 1];
+            t.cur = (nb & 1) ? b0 : b1;
+            t.cur_top = nullptr;
+            if (nb & 1) t.next ^= 1;
+        }
+    }
+    p->timed = false;
+    return SC_OK;
+}
+
 // Rounds first..last-1 (0-based) of the reference's prove loop (mod.rs:57-64): prove_round, feed, sample.  Late rounds are
 // pipelined: while round i runs, round i+1 is already enqueued behind the wait, so hashing round i's message and storing the
 // challenge is all that separates the two on the critical path.  vm/have carry the pending challenge in and out.
@@ -907,6 +1060,8 @@ static int run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, 
         uint64_t *pm = out_msgs + (size_t)i * D * 4;
         const auto t0 = clk::now();
         int rc;
+        if (!enqueued && tail_possible(p)) // from here on every round is latency-bound: one persistent kernel runs them all
+            return run_tail(p, rng, n_rounds - i, have ? &vm : nullptr, pm, out_challenges_or_null ? out_challenges_or_null + i : nullptr);
         if (!enqueued) {
             rc = launch_round(p, have ? vm.l : nullptr, nullptr, true);
             if (rc) return rc;
@@ -914,7 +1069,9 @@ static int run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, 
         }
         uint32_t want_next = 0;
         bool next_enqueued = false;
-        if (i + 1 < n_rounds && can_defer_next(p)) { // round i+1 goes in now, behind the wait
+        // round i+1 goes in now, behind the wait -- unless it is one the persistent tail kernel will take (it starts after round i's challenge)
+        const bool next_is_tail = tail_shape_ok(p) && p->round < p->nv && (1ULL << (p->nv - (p->round + 1))) <= scd::kTailMaxPairs;
+        if (i + 1 < n_rounds && !next_is_tail && can_defer_next(p)) {
             rc = launch_round(p, nullptr, nullptr, true, true);
             if (rc) return rc;
             want_next = p->seq;

@@ -117,6 +117,43 @@ struct ComboMeta {
     uint32_t slot_exp[kMetaSlots];
 };
 
+// The persistent tail kernel (kernels.hip: k_tail_rounds): every latency-bound round of a proof in one launch.
+constexpr uint64_t kTailMaxPairs = 2048; // rounds above this many pairs are throughput- rather than latency-bound: separate (pipelined) launches
+                                         // with full-chip grids beat a resident grid that pays a barrier per phase (measured: 32 vs 54 us at 4096 pairs)
+constexpr int kTailMaxGrid = 1024; // at most 4 resident blocks per CU (120 VGPRs), all co-resident on a 256-CU device
+constexpr int kTailFlatPairs = 16; // rounds with at most this many pairs run in block 0 alone, one lane per (combination, pair)
+struct TailTables {
+    const uint4 *cur0[kMaxSmallTables];       // where each table's evaluations are when the tail starts ...
+    const int32_t *cur0_top[kMaxSmallTables]; // ... non-null: in the internal F29 format (straight from the big rounds)
+    uint4 *b0[kMaxSmallTables];               // the 1st, 3rd, ... bind of the tail writes here
+    uint4 *b1[kMaxSmallTables];               // the 2nd, 4th, ... here
+};
+struct TailArgs {
+    TailTables t;
+    int n_tables;
+    int n_rounds;         // rounds this launch runs
+    int first_has_bind;   // the first of them binds r0 first (0: it is round 1 of the proof)
+    uint64_t first_pairs; // pairs of the first of them (<= kSmallRoundPairs)
+    FrHost r0;
+    int n_combos, K, D;
+    const uint4 *Wm;      // node -> message matrices (FinProd::w_off)
+    uint4 *partials;
+    uint32_t *sync;       // device, zeroed before the launch: [0] barrier generation [2] challenges released [3] stop [16 + b] arrival flag of block b
+    uint4 *sums;          // device, K * D elements: the per-combination sums of a round with many partial blocks
+    uint64_t *chal;       // device, 2 x 4 limbs: the challenge of tail round j in slot j & 1
+    uint4 *h_out;         // host-mapped: the round message ...
+    uint32_t *h_flag;     // ... and its sequence flag (round j publishes seq0 + j)
+    uint32_t seq0;
+    uint32_t *sig;        // host-mapped: sig[1] = give-up marker of the device-side poll
+    const uint64_t *mail_host; // host-mapped, 2 slots x 8 words: the challenge of tail round j, 32-bit limb i as (limb << 32 | sig0 + j) in
+                               // word i of slot (sig0 + j) & 1 -- the tag makes every word self-validating, one poll fetches the challenge
+    uint32_t sig0;
+    uint32_t max_spins;
+};
+int tail_max_resident_blocks(int device); // co-resident blocks of the tail kernel (0: unknown -> the tail kernel is not used)
+uint32_t wait_spins_default(); // bound of the device-side polls for a challenge (SC_WAIT_SPINS overrides it: tests)
+hipError_t launch_tail_rounds(const TailArgs &args, const ComboMeta &meta, const FinMeta &fin, int grid, hipStream_t stream);
+
 int grid_for_pairs(uint64_t n_pairs);
 
 // product k of one round: partials[t*grid+blk] = sum over this block's pairs of prod_j line_j(t), t = 0..M (node-major, so the

@@ -32,6 +32,7 @@
 #include "fe_device.hpp"
 #include "kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -654,13 +655,16 @@ __global__ void k_wait_challenge(uint32_t *__restrict__ flag, const uint32_t wan
     __syncthreads();
     if (threadIdx.x < 4) mail_dev[threadIdx.x] = __hip_atomic_load(mail_host + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-hipError_t launch_wait_challenge(uint32_t *flag_dev, uint32_t want, const FrHost *mail_host_dev, FrHost *mail_dev, hipStream_t stream,
-                                 uint32_t spins_override) {
-    static const uint32_t env_spins = [] { // SC_WAIT_SPINS: tests shorten the bound to exercise the give-up path
+uint32_t wait_spins_default() { // SC_WAIT_SPINS: tests shorten the bound to exercise the give-up path
+    static const uint32_t env_spins = [] {
         const char *e = std::getenv("SC_WAIT_SPINS");
         return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (1u << 22);
     }();
-    const uint32_t max_spins = spins_override ? spins_override : env_spins;
+    return env_spins;
+}
+hipError_t launch_wait_challenge(uint32_t *flag_dev, uint32_t want, const FrHost *mail_host_dev, FrHost *mail_dev, hipStream_t stream,
+                                 uint32_t spins_override) {
+    const uint32_t max_spins = spins_override ? spins_override : wait_spins_default();
     hipLaunchKernelGGL(k_wait_challenge, dim3(1), dim3(64), 0, stream, flag_dev, want, max_spins, reinterpret_cast<const uint64_t *>(mail_host_dev),
                        reinterpret_cast<uint64_t *>(mail_dev));
     return hipGetLastError();
@@ -696,20 +700,22 @@ __global__ __launch_bounds__(kBlock) void k_f29_to_sat(const uint4 *__restrict__
         fr_store(dst + 2 * i, fe_to_fr(fe_load_f29(src, i, stop[i])));
 }
 
-// one (product, node) combination over the block's pairs; the metadata comes from device memory or from a kernel argument
-template <typename SlotsT>
-__device__ __forceinline__ void sum_combo_body(const TablePtrs &tp, const Combo c, const SlotsT slot_table, const SlotsT slot_exp,
-                                               const uint64_t n_pairs, uint4 *__restrict__ partials, uint32_t (*sm)[8]) {
+// one (product, node) combination over the block's pairs; the metadata comes from device memory or from a kernel argument.
+// `tab(u)` gives table u's current evaluations; (vbx, vgx) = this block's index and the block count along the pair axis (the
+// launch's blockIdx.x / gridDim.x, or the virtual ones of the persistent tail kernel).
+template <typename SlotsT, typename TabFn>
+__device__ __forceinline__ void sum_combo_body(const TabFn &tab, const Combo c, const SlotsT slot_table, const SlotsT slot_exp,
+                                               const uint64_t n_pairs, uint4 *__restrict__ partials, uint32_t (*sm)[8], const uint32_t vbx, const uint32_t vgx) {
     const uint32_t t = c.t;
     const int32_t nv = node_value((int)t);
     const Fr tf = node_constant(nv);
     Fr acc = fr_zero();
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_pairs; b += stride) {
+    const uint64_t stride = (uint64_t)vgx * kBlock;
+    for (uint64_t b = (uint64_t)vbx * kBlock + threadIdx.x; b < n_pairs; b += stride) {
         Fr prod;
         bool first = true;
         for (uint32_t s = 0; s < c.n_slots; ++s) {
-            const uint4 *p = tp.src[slot_table[c.slot_off + s]] + 4 * b;
+            const uint4 *p = tab(slot_table[c.slot_off + s]) + 4 * b;
             Fr val;
             if (nv == 0) val = fr_load(p);
             else if (nv == 1) val = fr_load(p + 2);
@@ -727,19 +733,19 @@ __device__ __forceinline__ void sum_combo_body(const TablePtrs &tp, const Combo 
         acc = fr_add(acc, prod);
     }
     const Fr s = block_sum(acc, sm);
-    if (threadIdx.x == 0) fr_store(partials + 2 * (c.partial_off + (uint64_t)t * gridDim.x + blockIdx.x), s);
+    if (threadIdx.x == 0) fr_store(partials + 2 * (c.partial_off + (uint64_t)t * vgx + vbx), s);
 }
 
 __global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const Combo *__restrict__ combos,
                                                        const uint32_t *__restrict__ slot_table, const uint32_t *__restrict__ slot_exp,
                                                        const uint64_t n_pairs, uint4 *__restrict__ partials) {
     __shared__ uint32_t sm[kBlock / 64][8];
-    sum_combo_body(tp, combos[blockIdx.y], slot_table, slot_exp, n_pairs, partials, sm);
+    sum_combo_body([&](uint32_t u) { return tp.src[u]; }, combos[blockIdx.y], slot_table, slot_exp, n_pairs, partials, sm, blockIdx.x, gridDim.x);
 }
 __global__ __launch_bounds__(kBlock) void k_sum_combos_meta(const TablePtrs tp, const ComboMeta meta, const uint64_t n_pairs,
                                                             uint4 *__restrict__ partials) {
     __shared__ uint32_t sm[kBlock / 64][8];
-    sum_combo_body(tp, meta.combo[blockIdx.y], meta.slot_table, meta.slot_exp, n_pairs, partials, sm);
+    sum_combo_body([&](uint32_t u) { return tp.src[u]; }, meta.combo[blockIdx.y], meta.slot_table, meta.slot_exp, n_pairs, partials, sm, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -752,23 +758,27 @@ __global__ __launch_bounds__(kBlock) void k_sum_combos_meta(const TablePtrs tp, 
 // ------------------------------------------------------------------------------------------------
 constexpr int kFinBlock = 1024; // 16 wavefronts: one per (product, point) combination for typical shapes
 constexpr size_t kFinLdsMax = 48 * 1024;
-template <bool kLds, bool kMeta>
-__global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restrict__ prods, const FinMeta meta, const uint4 *__restrict__ Wm, const int K, const int D,
-                                                        const int nblocks, const uint4 *__restrict__ partials, uint4 *__restrict__ scratch,
-                                                        uint4 *__restrict__ out, uint64_t *__restrict__ out_wide,
-                                                        uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag, const uint32_t seq,
-                                                        const int scaled) {
-    constexpr int kBlock = kFinBlock; // shadows the 256-thread constant inside this kernel
-    extern __shared__ uint4 fin_lds[];
-    if constexpr (kLds) scratch = fin_lds;
-    // the per-product records come from the kernel argument when they fit (kMeta): no global load in front of the partial loads
-    auto prod_of = [&](int k) -> FinProd {
-        if constexpr (kMeta) return meta.prod[k];
-        else return prods[k];
-    };
+// the body, for a block of BLOCK threads (k_finalize: 1024; the persistent tail kernel: its own block size); `scratch` holds
+// K * D * (D + 2) elements (LDS when it fits); prod_of(k) returns the k-th FinProd
+// phase 1: S_k[t] = sum over blocks of partial_k[t][blk] -> scratch[k * D + t]
+template <int BLOCK, typename ProdFn>
+__device__ __forceinline__ void finalize_sums(const ProdFn &prod_of, const int K, const int D, const int nblocks, const uint4 *__restrict__ partials,
+                                              uint4 *__restrict__ scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // phase 1: one wave per (product, node) combination, eight independent loads in flight per lane
-    for (int combo = wave; combo < K * D; combo += kBlock / 64) {
+    if (nblocks <= 8) { // a handful of partials per combination: one lane adds them up, no cross-lane reduction (late rounds)
+        for (int combo = threadIdx.x; combo < K * D; combo += BLOCK) {
+            const int k = combo / D, t = combo % D;
+            if (t > (int)prod_of(k).M) continue;
+            const uint4 *base = partials + 2 * (prod_of(k).partial_off + (uint64_t)t * nblocks);
+            Fr acc = fr_load(base);
+            for (int b = 1; b < nblocks; ++b) acc = fr_add(acc, fr_load(base + 2 * b));
+            fr_store(scratch + 2 * combo, acc);
+        }
+        __syncthreads();
+        return;
+    }
+    // one wave per (product, node) combination, eight independent loads in flight per lane
+    for (int combo = wave; combo < K * D; combo += BLOCK / 64) {
         const int k = combo / D, t = combo % D;
         const int M = (int)prod_of(k).M;
         if (t > M) continue;
@@ -793,9 +803,15 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
         if (lane == 0) fr_store(scratch + 2 * (k * D + t), acc);
     }
     __syncthreads();
+}
+// phases 2 and 3: the node sums in scratch[k * D + t] -> the round message
+template <int BLOCK, typename ProdFn>
+__device__ __forceinline__ void finalize_message(const ProdFn &prod_of, const uint4 *__restrict__ Wm, const int K, const int D, uint4 *__restrict__ scratch,
+                                                 uint4 *__restrict__ out, uint64_t *__restrict__ out_wide, uint4 *__restrict__ h_out,
+                                                 uint32_t *__restrict__ h_flag, const uint32_t seq, const int scaled) {
     // phase 2: message point t of product k = sum_s (c_k W_k)[t][s] * S_k[s].  One thread per (k, t, s) does the single
     // Montgomery product (a lone lane needs ~1 us per product, so the M+1 products of a point must not be chained) ...
-    for (int idx = threadIdx.x; idx < K * D * D; idx += kBlock) {
+    for (int idx = threadIdx.x; idx < K * D * D; idx += BLOCK) {
         const int k = idx / (D * D), t = (idx / D) % D, sN = idx % D;
         const int M = (int)prod_of(k).M;
         if (sN > M) continue;
@@ -806,7 +822,7 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
     }
     __syncthreads();
     // ... and one thread per (k, t) adds them up
-    for (int combo = threadIdx.x; combo < K * D; combo += kBlock) {
+    for (int combo = threadIdx.x; combo < K * D; combo += BLOCK) {
         const int k = combo / D;
         const int M = (int)prod_of(k).M;
         Fr acc = fr_zero();
@@ -815,7 +831,7 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
     }
     __syncthreads();
     // phase 3b: sum over products
-    for (int t = threadIdx.x; t < D; t += kBlock) {
+    for (int t = threadIdx.x; t < D; t += BLOCK) {
         Fr acc = fr_zero();
         for (int k = 0; k < K; ++k) acc = fr_add(acc, fr_load(scratch + 2 * ((K + k) * D + t)));
         if (out) fr_store(out + 2 * t, acc);
@@ -832,6 +848,282 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
             __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+template <int BLOCK, typename ProdFn>
+__device__ __forceinline__ void finalize_body(const ProdFn &prod_of, const uint4 *__restrict__ Wm, const int K, const int D, const int nblocks,
+                                              const uint4 *__restrict__ partials, uint4 *__restrict__ scratch, uint4 *__restrict__ out,
+                                              uint64_t *__restrict__ out_wide, uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag, const uint32_t seq,
+                                              const int scaled) {
+    finalize_sums<BLOCK>(prod_of, K, D, nblocks, partials, scratch);
+    finalize_message<BLOCK>(prod_of, Wm, K, D, scratch, out, out_wide, h_out, h_flag, seq, scaled);
+}
+
+template <bool kLds, bool kMeta>
+__global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restrict__ prods, const FinMeta meta, const uint4 *__restrict__ Wm, const int K, const int D,
+                                                        const int nblocks, const uint4 *__restrict__ partials, uint4 *__restrict__ scratch,
+                                                        uint4 *__restrict__ out, uint64_t *__restrict__ out_wide,
+                                                        uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag, const uint32_t seq,
+                                                        const int scaled) {
+    extern __shared__ uint4 fin_lds[];
+    if constexpr (kLds) scratch = fin_lds;
+    // the per-product records come from the kernel argument when they fit (kMeta): no global load in front of the partial loads
+    auto prod_of = [&](int k) -> FinProd {
+        if constexpr (kMeta) return meta.prod[k];
+        else return prods[k];
+    };
+    finalize_body<kFinBlock>(prod_of, Wm, K, D, nblocks, partials, scratch, out, out_wide, h_out, h_flag, seq, scaled);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The persistent tail kernel: ALL latency-bound rounds of a proof (<= kSmallRoundPairs pairs) in ONE launch.
+// Between dependent kernel launches the command processor needs ~5 us; a late round is three or four of them for a few
+// microseconds of arithmetic.  Here a resident grid walks the rounds itself:
+//   bind every table with the round's challenge        (all blocks; the lane-per-entry body of k_fix_multi)
+//   -- grid barrier --
+//   every (product, node) combination over the pairs   (all blocks, as virtual blocks of k_sum_combos with the same partial layout)
+//   -- grid barrier --
+//   block 0: finalize_body -> the message, straight into host-mapped memory, sequence flag; then it polls the host-mapped
+//   word for the next challenge (bounded, as k_wait_challenge), stores it in device memory and releases the other blocks.
+// The host only hashes and answers.  Grid barrier: a monotone arrival counter and a generation word, agent-scope
+// release / acquire (the L2s of the eight XCDs are not coherent with each other for plain accesses; the fences write back and
+// invalidate).  All blocks are co-resident by construction (at most one small block per CU).
+// ------------------------------------------------------------------------------------------------
+// Grid barrier over the first n_blocks blocks.  A counter that every block increments serialises at the memory side (device-scope
+// atomics on one address: ~0.1 us each, 25 us for 256 blocks), so every block raises its OWN flag word instead (plain stores to
+// distinct addresses), block 0's lanes watch one flag each, and the others watch the generation word block 0 then publishes.
+// sync layout (uint32): [0] generation [1] -- [2] challenges released [3] stop [16 ...] one flag per block
+__device__ __forceinline__ void grid_barrier(uint32_t *sync, uint32_t &gen, const uint32_t n_blocks) {
+    __syncthreads();
+    gen += 1;
+    if (blockIdx.x == 0) {
+        for (uint32_t f = 1 + threadIdx.x; f < n_blocks; f += kBlock)
+            while (__hip_atomic_load(sync + 16 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            __hip_atomic_store(sync, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // this block's writes (every thread's: ordered by the barrier above) reach the device
+        __hip_atomic_store(sync + 16 + blockIdx.x, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // relaxed polls (an acquire per poll would invalidate caches every time), one acquire fence at the end
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+// blocks a round of `n_pairs` pairs can use: one per 256 bind outputs, and at least one per (combination, 256 pairs) tile
+__device__ __forceinline__ uint32_t tail_active_blocks(const uint64_t n_pairs, const int n_tables, const int n_combos, const uint32_t G) {
+    if (n_pairs <= (uint64_t)kTailFlatPairs) return 1; // one block does the whole round (flat mode below)
+    const uint64_t bind_blocks = (2 * n_pairs * (uint64_t)n_tables + kBlock - 1) / kBlock;
+    const uint64_t sum_blocks = ((n_pairs + kBlock - 1) / kBlock) * (uint64_t)n_combos;
+    return (uint32_t)min((uint64_t)G, max(bind_blocks, sum_blocks));
+}
+
+__device__ __forceinline__ Fr combo_term(const uint4 *p, const int32_t nv, const Fr &tf) { // the line through (lo, hi) at node nv
+    if (nv == 0) return fr_load(p);
+    if (nv == 1) return fr_load(p + 2);
+    const Fr lo = fr_load(p), hi = fr_load(p + 2);
+    if (nv == kNodeInf) return fr_sub(hi, lo);
+    if (nv == -1) return fr_sub(fr_add(lo, lo), hi);
+    if (nv == 2) return fr_sub(fr_add(hi, hi), lo);
+    return fr_add(lo, fr_mul(fr_sub(hi, lo), tf));
+}
+
+__global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const ComboMeta meta, const FinMeta fin) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    __shared__ uint64_t r_sh[4];
+    __shared__ uint32_t stop_sh;
+    extern __shared__ uint4 fin_lds[];
+    const uint32_t G = gridDim.x;
+    uint32_t gen = 0;
+    uint64_t n_pairs = A.first_pairs;
+    int binds = 0; // binds done so far: table u's current evaluations are cur0 (0), b0 (odd), b1 (even > 0)
+    auto tab = [&](uint32_t u) -> const uint4 * { return binds == 0 ? A.t.cur0[u] : (binds & 1) ? A.t.b0[u] : A.t.b1[u]; };
+    auto prod_of = [&](int k) -> FinProd { return fin.prod[k]; };
+    if (threadIdx.x == 0) stop_sh = 0;
+    for (int j = 0; j < A.n_rounds; ++j, n_pairs >>= 1) {
+        // The rounds shrink: blocks beyond what this round can use retire for good (the count never grows again), so the barriers of
+        // the later rounds synchronise a handful of blocks instead of one per CU, and the last rounds run in block 0 alone.
+        const uint32_t Gj = tail_active_blocks(n_pairs, A.n_tables, A.n_combos, G);
+        if (blockIdx.x >= Gj) return;
+        const bool solo = Gj == 1; // no other block left: block barriers are enough
+        if (j > 0 || A.first_has_bind) {
+            // ---- this round's challenge: round 0's came with the launch; block 0 fetched the later ones from the host itself (below)
+            // and the other blocks read them from device memory once block 0 has released them
+            if (j == 0) {
+                if (threadIdx.x < 4) r_sh[threadIdx.x] = A.r0.l[threadIdx.x];
+            } else if (blockIdx.x != 0) {
+                if (threadIdx.x == 0) {
+                    while (__hip_atomic_load(A.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)j) __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    stop_sh = __hip_atomic_load(A.sync + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if (threadIdx.x < 4) r_sh[threadIdx.x] = __hip_atomic_load(A.chal + 4 * (j & 1) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (stop_sh) return; // the host never answered: block 0 has told it (give-up marker); nothing more is published
+            FrHost rh;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rh.l[i] = r_sh[i];
+            const FrU r = fru_from_host(rh);
+            // ---- bind: out[b] = in[2b] + r (in[2b+1] - in[2b]), 2 n_pairs outputs per table ------------------------------------
+            const uint64_t n_out = 2 * n_pairs; // a power of two
+            const int sh = 63 - __builtin_clzll(n_out);
+            const uint64_t total = n_out * (uint64_t)A.n_tables;
+            for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)Gj * kBlock) {
+                const uint32_t u = (uint32_t)(i >> sh);
+                const uint64_t b = i & (n_out - 1);
+                const uint4 *src = tab(u);
+                uint4 *dst = (binds & 1) ? A.t.b1[u] : A.t.b0[u];
+                Fr lo, hi;
+                const int32_t *stop = binds == 0 ? A.t.cur0_top[u] : nullptr;
+                if (stop) { // the table arrives from the big rounds in F29, leaves canonical
+                    const int2 t = *reinterpret_cast<const int2 *>(stop + 2 * b);
+                    lo = fe_to_fr(fe_load_f29(src, 2 * b, t.x));
+                    hi = fe_to_fr(fe_load_f29(src, 2 * b + 1, t.y));
+                } else {
+                    lo = fr_load(src + 4 * b);
+                    hi = fr_load(src + 4 * b + 2);
+                }
+                fr_store(dst + 2 * b, fr_add(lo, fr_mul_u(fr_sub(hi, lo), r)));
+            }
+            binds += 1;
+            if (solo) {
+                __syncthreads();
+            } else {
+                grid_barrier(A.sync, gen, Gj);
+            }
+        }
+        if (solo) {
+            // ---- flat mode: lane i of the block = (combination i / n_pairs, pair i % n_pairs); the pairs of a combination are
+            // n_pairs adjacent lanes of one wavefront, summed by log2(n_pairs) shuffles; the sums go straight to finalize's scratch
+            const int shp = 63 - __builtin_clzll(n_pairs);
+            const uint32_t items = (uint32_t)A.n_combos << shp;
+            for (uint32_t i0 = 0; i0 < items; i0 += kBlock) { // block-uniform trip count
+                const uint32_t i = i0 + threadIdx.x;
+                const bool live = i < items;
+                const Combo c = meta.combo[live ? (i >> shp) : 0];
+                const uint64_t b = i & (uint32_t)(n_pairs - 1);
+                const int32_t nv = node_value((int)c.t);
+                const Fr tf = node_constant(nv);
+                Fr prod = fr_zero();
+                if (live) {
+                    bool first = true;
+                    for (uint32_t sl = 0; sl < c.n_slots; ++sl) {
+                        const Fr val = combo_term(tab(meta.slot_table[c.slot_off + sl]) + 4 * b, nv, tf);
+                        uint32_t k = 0;
+                        if (first) { prod = val; k = 1; first = false; }
+                        for (; k < meta.slot_exp[c.slot_off + sl]; ++k) prod = fr_mul(prod, val);
+                    }
+                }
+                for (uint32_t off = (uint32_t)n_pairs >> 1; off >= 1; off >>= 1) prod = fr_add(prod, fr_shfl_down(prod, (int)off));
+                if (live && b == 0) { // scratch[k * D + t]: the product index k = position of this combination's product
+                    int k = 0;
+                    while (fin.prod[k].partial_off != c.partial_off) ++k;
+                    fr_store(fin_lds + 2 * (k * A.D + (int)c.t), prod);
+                }
+            }
+            __syncthreads();
+            finalize_message<kBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 0);
+        } else {
+            // ---- sums: virtual blocks (vx, combo) of the k_sum_combos launch this round would have been -------------------------
+            const uint32_t vgx = (uint32_t)((n_pairs + kBlock - 1) / kBlock);
+            const uint32_t n_virtual = vgx * (uint32_t)A.n_combos;
+            for (uint32_t v = blockIdx.x; v < n_virtual; v += Gj) {
+                const uint32_t cy = v / vgx, vx = v % vgx;
+                sum_combo_body(tab, meta.combo[cy], meta.slot_table, meta.slot_exp, n_pairs, A.partials, sm, vx, vgx);
+            }
+            grid_barrier(A.sync, gen, Gj);
+            if (vgx > 8 && Gj >= (uint32_t)(A.K * A.D)) {
+                // many partials per combination: block c adds up combination c's (all its lanes, then one block sum), so that block 0
+                // only has the K * D sums left to combine
+                const int c = blockIdx.x;
+                if (c < A.K * A.D) {
+                    const int k = c / A.D, t = c % A.D;
+                    if (t <= (int)fin.prod[k].M) {
+                        const uint4 *base = A.partials + 2 * (fin.prod[k].partial_off + (uint64_t)t * vgx);
+                        Fr acc = fr_zero();
+                        for (uint32_t bq = threadIdx.x; bq < vgx; bq += kBlock) acc = fr_add(acc, fr_load(base + 2 * bq));
+                        const Fr tot = block_sum(acc, sm);
+                        if (threadIdx.x == 0) fr_store(A.sums + 2 * c, tot);
+                    }
+                }
+                grid_barrier(A.sync, gen, Gj);
+                if (blockIdx.x == 0) {
+                    for (int c2 = threadIdx.x; c2 < A.K * A.D; c2 += kBlock) {
+                        fin_lds[2 * c2] = A.sums[2 * c2];
+                        fin_lds[2 * c2 + 1] = A.sums[2 * c2 + 1];
+                    }
+                    __syncthreads();
+                    finalize_message<kBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 0);
+                }
+            } else if (blockIdx.x == 0) {
+                finalize_body<kBlock>(prod_of, A.Wm, A.K, A.D, (int)vgx, A.partials, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag,
+                                      A.seq0 + (uint32_t)j, 0);
+            }
+        }
+        // ---- block 0: the next challenge.  The host stores, for limb i of the challenge, the 64-bit word (limb << 32 | tag) into
+        // slot word i, tag = the low 32 bits of sig0 + j + 1 xor-ed into nothing else: eight lanes poll one word each until its
+        // tag matches, so the challenge arrives with the poll that sees it (no second trip over PCIe to fetch it).
+        if (blockIdx.x == 0 && j + 1 < A.n_rounds) {
+            const uint32_t want = A.sig0 + (uint32_t)(j + 1);
+            if (threadIdx.x < 64) {
+                const int lane = threadIdx.x;
+                uint64_t w = 0;
+                bool seen = false;
+                for (uint32_t spin = 0; spin < A.max_spins; ++spin) {
+                    if (lane < 8) w = __hip_atomic_load(A.mail_host + 8 * (want & 1u) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const bool mine = lane >= 8 || (uint32_t)w == want;
+                    if (__all(mine)) { seen = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!seen && lane == 0) { // gave up: tell the host (it voids the proof) and let every block leave
+                    __hip_atomic_store(A.sig + 1, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(A.sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    stop_sh = 1;
+                }
+                // limbs 2i, 2i+1 (lanes 2i, 2i+1) -> 64-bit limb i
+                const uint32_t lo32 = (uint32_t)(w >> 32);
+                const uint32_t hi32 = __shfl_down(lo32, 1, 64);
+                if (lane < 8 && (lane & 1) == 0) {
+                    const uint64_t limb = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
+                    r_sh[lane >> 1] = limb;
+                    __hip_atomic_store(A.chal + 4 * ((j + 1) & 1) + (lane >> 1), limb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (lane == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __hip_atomic_store(A.sync + 2, (uint32_t)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+}
+
+// how many blocks of k_tail_rounds the device holds at once (its barriers need every launched block resident): asked of the
+// runtime, for the worst-case dynamic LDS, once per process and device
+int tail_max_resident_blocks(int device) {
+    static int cached_dev = -1, cached = 0;
+    if (cached_dev == device) return cached;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail_rounds, kBlock, kFinLdsMax) != hipSuccess || per_cu < 1 ||
+        hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount < 1) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    cached = std::min(per_cu * prop.multiProcessorCount, kTailMaxGrid);
+    cached_dev = device;
+    return cached;
+}
+
+hipError_t launch_tail_rounds(const TailArgs &args, const ComboMeta &meta, const FinMeta &fin, int grid, hipStream_t stream) {
+    const size_t lds = (size_t)args.K * args.D * (args.D + 2) * 32;
+    if (lds > kFinLdsMax) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tail_rounds, dim3(grid), dim3(kBlock), lds, stream, args, meta, fin);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
