@@ -199,6 +199,25 @@ SC_API int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_vals, u
  * messages); out_uv_or_null: 2 x dim x 4 (u then v). */
 SC_API int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim,
                  const uint64_t *f2, const uint64_t *f3, const uint64_t *g, uint32_t flags, uint64_t *out_proof, uint64_t *out_uv_or_null);
+/* f4 -- the same two initialisations with f1's non-zeros SPREAD OVER SEVERAL GPUs (worth it from dim ~ 24).
+ * Every rank passes a disjoint subset of f1's (index, value) pairs -- any partition -- and all of f3 / g.  A rank's scatter is a
+ * partial sum of a_hg, so the ranks' dense tables are added with ONE table-sized integer all-reduce of the widened limbs
+ * (2^dim x 8 uint64 lanes, 64 bytes per entry) and folded back mod p on the device (sc_wide_reduce_table).  f1(g,.,.) stays
+ * distributed: f1g_* receive the fold of THIS rank's entries (a key may occur on several ranks; its true value is the sum) and
+ * are what the rank passes to sc_gkr_phase_two_sharded.
+ *   comm_or_null + h_g (lanes_or_null == NULL): the library all-reduces over `comm` (RCCL or host transport; NULL or one rank =
+ *       the unsharded call) and writes the finished table;
+ *   lanes_or_null != NULL: no communication -- the rank's contribution is left as lanes for the CALLER's all-reduce (then
+ *       sc_wide_reduce_table); h_g_or_null, if given, receives the rank's own partial table.
+ * flags: SC_TABLES_ON_DEVICE as for sc_gkr_phase_one (lanes_or_null follows it too). */
+SC_API int sc_gkr_phase_one_sharded(sc_comm *comm_or_null, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz_local, uint32_t dim,
+                                    const uint64_t *f3, const uint64_t *g, uint32_t flags, uint64_t *h_g_or_null, uint64_t *lanes_or_null,
+                                    uint64_t *f1g_idx, uint64_t *f1g_vals, uint64_t *f1g_nnz);
+SC_API int sc_gkr_phase_two_sharded(sc_comm *comm_or_null, const uint64_t *f1g_idx, const uint64_t *f1g_vals, uint64_t nnz_local, uint32_t dim,
+                                    const uint64_t *u, uint32_t flags, uint64_t *f1_gu_or_null, uint64_t *lanes_or_null);
+/* n elements of 8 summed uint64 lanes -> canonical Montgomery limbs, on the GPU (sc_wide_reduce is the host twin for a handful
+ * of elements).  flags: SC_TABLES_ON_DEVICE => lanes / out are device pointers. */
+SC_API int sc_wide_reduce_table(const uint64_t *lanes, uint64_t n, uint64_t *out, uint32_t flags);
 /* out[i] = scalar * in[i], i < n: `DenseMultilinearExtension::zero() += (f2(u), &f3)` of start_phase2_sumcheck (mod.rs:71-75).
  * flags: SC_TABLES_ON_DEVICE => in / out are device pointers.  scalar: 4 limbs (host). */
 SC_API int sc_dense_scale(const uint64_t *in, uint64_t n, const uint64_t *scalar, uint64_t *out, uint32_t flags);

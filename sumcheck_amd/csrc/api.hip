@@ -1766,6 +1766,23 @@ extern "C" int sc_comm_selftest(sc_comm *c) {
     }
     return SC_OK;
 }
+// gkr.hip: sum `n_words` uint64 lanes in device memory over the ranks of `comm`, in place; returns with the result visible on `s`
+int sc_internal_allreduce_lanes(sc_comm *c, uint64_t *d_lanes, size_t n_words, hipStream_t s) {
+    if (!c || c->nranks == 1) return SC_OK;
+    if (c->comm) {
+        NCCL_TRY(g_nccl.AllReduce(d_lanes, d_lanes, n_words, ncclUint64, ncclSum, c->comm, s));
+        return SC_OK;
+    }
+    std::vector<uint64_t> h(n_words);
+    HIP_TRY(hipMemcpyAsync(h.data(), d_lanes, n_words * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (c->h_allreduce(c->ctx, h.data(), n_words) != 0) return fail(SC_ERR_HIP, "the host transport's all-reduce failed");
+    HIP_TRY(hipMemcpyAsync(d_lanes, h.data(), n_words * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s)); // `h` goes out of scope
+    return SC_OK;
+}
+int sc_internal_comm_ranks(sc_comm *c) { return c ? c->nranks : 1; }
+
 extern "C" void sc_comm_free(sc_comm *c) {
     if (!c) return;
     if (c->comm && g_nccl.CommDestroy) (void)g_nccl.CommDestroy(c->comm);

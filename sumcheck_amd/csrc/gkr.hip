@@ -167,6 +167,46 @@ __global__ __launch_bounds__(kBlock) void k_idx_range(const uint64_t *__restrict
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
+// canonical elements -> 8 zero-extended 32-bit limbs in uint64 lanes (summable across ranks with an integer all-reduce) ...
+__global__ __launch_bounds__(kBlock) void k_widen(const Fr *__restrict__ in, const uint64_t n, uint64_t *__restrict__ lanes) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const Fr a = fr_ld(in + i);
+        uint4 *o = reinterpret_cast<uint4 *>(lanes + 8 * i);
+        o[0] = make_uint4(a.v[0], 0u, a.v[1], 0u);
+        o[1] = make_uint4(a.v[2], 0u, a.v[3], 0u);
+        o[2] = make_uint4(a.v[4], 0u, a.v[5], 0u);
+        o[3] = make_uint4(a.v[6], 0u, a.v[7], 0u);
+    }
+}
+// ... and back: V = sum_j lane_j 2^(32 j) (lanes < 2^63) = lo + hi 2^256, V mod p = (lo mod p) + hi * (2^256 mod p).  The device
+// twin of sc_wide_reduce (api.hip).
+__global__ __launch_bounds__(kBlock) void k_wide_fold(const uint64_t *__restrict__ lanes, const uint64_t n, Fr *__restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        Fr lo;
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint64_t t = lanes[8 * i + j] + carry; // < 2^63 + 2^32: no wrap
+            lo.v[j] = (uint32_t)t;
+            carry = t >> 32;
+        }
+        lo = scd::fr_reduce_once(scd::fr_reduce_once(lo)); // lo < 2^256 < 3p
+        // hi = carry (< 2^32 for any sane rank count); hi * 2^256 mod p = mont_mul(hi, R^2)
+        Fr hi = scd::fr_zero(), r2;
+        hi.v[0] = (uint32_t)carry;
+        hi.v[1] = (uint32_t)(carry >> 32);
+        const uint64_t R2[4] = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            r2.v[2 * q] = (uint32_t)R2[q];
+            r2.v[2 * q + 1] = (uint32_t)(R2[q] >> 32);
+        }
+        fr_st(out + i, scd::fr_add(lo, scd::fr_mul(hi, r2)));
+    }
+}
+
 #define G_TRY(expr)                                                                                                      \
     do {                                                                                                                 \
         hipError_t e_ = (expr);                                                                                          \
@@ -527,6 +567,139 @@ extern "C" int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_val
     if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 2 * dim, d_idx_s, d_vals_s, s))) return rc;
     if ((rc = phase_two_device(mem, d_idx_s, d_vals_s, nnz, dim, reinterpret_cast<const sch::Fr *>(u), d_out, s))) return rc;
     if (!dev) G_TRY(hipMemcpyAsync(f1_gu, d_out, N * 32, hipMemcpyDeviceToHost, s));
+    G_TRY(hipStreamSynchronize(s));
+    return SC_OK;
+}
+
+int sc_internal_allreduce_lanes(sc_comm *c, uint64_t *d_lanes, size_t n_words, hipStream_t s); // api.hip
+int sc_internal_comm_ranks(sc_comm *c);
+
+// ---- f4: GKR initialisation with f1's non-zeros spread over several GPUs -------------------------------------------
+// Every rank holds a disjoint subset of f1's (index, value) pairs -- any partition -- and all of f3.  a_hg[x] = sum over ALL
+// non-zeros, so a rank's scatter is a partial sum: the dense tables of the ranks are added with one table-sized integer
+// all-reduce of the widened limbs (64 bytes per entry; no modular all-reduce exists) and folded back mod p on the device.
+// f1(g,.,.) stays distributed: each rank keeps the fold of ITS entries (keys may repeat across ranks; the true value of a key is
+// the sum over ranks), and initialize_phase_two folds and scatters it locally again before the same all-reduce.
+// `lanes_or_null`: when given, the rank's contribution is left there as lanes (2^dim x 8 uint64, host or device per flags) and no
+// communication happens (the caller all-reduces: sumcheck_amd/sharded.py over torch.distributed); otherwise `comm` does it.
+static int gkr_dense_allreduce(DevBuf &mem, sc_comm *comm, Fr *d_table, uint64_t N, uint64_t *lanes_or_null, bool dev, hipStream_t s) {
+    if (!lanes_or_null && sc_internal_comm_ranks(comm) == 1) return SC_OK;
+    uint64_t *d_lanes = nullptr;
+    if (lanes_or_null && dev) d_lanes = lanes_or_null;
+    else G_TRY(mem.alloc(&d_lanes, 8 * N));
+    hipLaunchKernelGGL(k_widen, dim3(grid_for(N)), dim3(kBlock), 0, s, d_table, N, d_lanes);
+    G_TRY(hipGetLastError());
+    if (lanes_or_null) {
+        if (!dev) G_TRY(hipMemcpyAsync(lanes_or_null, d_lanes, N * 64, hipMemcpyDeviceToHost, s));
+        G_TRY(hipStreamSynchronize(s));
+        return SC_OK;
+    }
+    int rc = sc_internal_allreduce_lanes(comm, d_lanes, 8 * N, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_wide_fold, dim3(grid_for(N)), dim3(kBlock), 0, s, d_lanes, N, d_table);
+    G_TRY(hipGetLastError());
+    return SC_OK;
+}
+
+extern "C" int sc_wide_reduce_table(const uint64_t *lanes, uint64_t n, uint64_t *out, uint32_t flags) {
+    if (n && (!lanes || !out)) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    if (n == 0) return SC_OK;
+    if (sc_device_count() <= 0) return sc_internal_fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    G_TRY(hipSetDevice(sc_internal_device()));
+    const bool dev = flags & SC_TABLES_ON_DEVICE;
+    hipStream_t s = nullptr;
+    DevBuf mem;
+    const uint64_t *d_l = lanes;
+    Fr *d_o = reinterpret_cast<Fr *>(out);
+    if (!dev) {
+        uint64_t *tmp = nullptr;
+        G_TRY(mem.alloc(&tmp, 8 * n));
+        G_TRY(mem.alloc(&d_o, n));
+        G_TRY(hipMemcpyAsync(tmp, lanes, n * 64, hipMemcpyHostToDevice, s));
+        d_l = tmp;
+    }
+    hipLaunchKernelGGL(k_wide_fold, dim3(grid_for(n)), dim3(kBlock), 0, s, d_l, n, d_o);
+    G_TRY(hipGetLastError());
+    if (!dev) G_TRY(hipMemcpyAsync(out, d_o, n * 32, hipMemcpyDeviceToHost, s));
+    G_TRY(hipStreamSynchronize(s));
+    return SC_OK;
+}
+
+extern "C" int sc_gkr_phase_one_sharded(sc_comm *comm_or_null, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz_local, uint32_t dim,
+                                        const uint64_t *f3, const uint64_t *g, uint32_t flags, uint64_t *h_g_or_null, uint64_t *lanes_or_null,
+                                        uint64_t *f1g_idx, uint64_t *f1g_vals, uint64_t *f1g_nnz) {
+    if ((nnz_local && (!f1_idx || !f1_vals)) || !f3 || !g || !f1g_nnz || (nnz_local && (!f1g_idx || !f1g_vals)) || (!h_g_or_null && !lanes_or_null))
+        return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    int rc = check_gkr_args(nnz_local, dim);
+    if (rc) return rc;
+    if ((rc = check_points(g, dim, "g"))) return rc;
+    const bool dev = flags & SC_TABLES_ON_DEVICE;
+    hipStream_t s = nullptr;
+    DevBuf mem;
+    const uint64_t N = 1ULL << dim;
+    (void)mem.reserve(gkr_scratch_estimate(nnz_local, N) + 64 * N);
+    if ((rc = check_index_range(mem, f1_idx, nnz_local, 3 * dim, dev, "f1", s))) return rc;
+    const uint64_t *d_idx = nullptr;
+    const Fr *d_vals = nullptr, *d_f3 = nullptr;
+    uint64_t *d_idx_s = nullptr, *d_gi = nullptr;
+    Fr *d_vals_s = nullptr, *d_hg = nullptr, *d_gv = nullptr;
+    unsigned int *d_n1 = nullptr;
+    if ((rc = stage_in(mem, f1_idx, nnz_local, dev, &d_idx, s)) || (rc = stage_in(mem, f1_vals, nnz_local, dev, &d_vals, s)) ||
+        (rc = stage_in(mem, f3, N, dev, &d_f3, s)))
+        return rc;
+    G_TRY(mem.alloc(&d_idx_s, nnz_local));
+    G_TRY(mem.alloc(&d_vals_s, nnz_local));
+    G_TRY(mem.alloc(&d_n1, 1));
+    const bool hg_in_place = dev && h_g_or_null;
+    if (hg_in_place) d_hg = reinterpret_cast<Fr *>(h_g_or_null);
+    else G_TRY(mem.alloc(&d_hg, N));
+    if (dev) {
+        d_gi = f1g_idx;
+        d_gv = reinterpret_cast<Fr *>(f1g_vals);
+    } else {
+        G_TRY(mem.alloc(&d_gi, nnz_local));
+        G_TRY(mem.alloc(&d_gv, nnz_local));
+    }
+    if ((rc = sort_sparse(mem, d_idx, d_vals, nnz_local, 3 * dim, d_idx_s, d_vals_s, s))) return rc;
+    uint64_t n1 = 0;
+    if ((rc = phase_one_device(mem, d_idx_s, d_vals_s, nnz_local, dim, d_f3, reinterpret_cast<const sch::Fr *>(g), d_hg, d_gi, d_gv, d_n1, &n1, s))) return rc;
+    if ((rc = gkr_dense_allreduce(mem, comm_or_null, d_hg, N, lanes_or_null, dev, s))) return rc;
+    if (h_g_or_null && !hg_in_place) G_TRY(hipMemcpyAsync(h_g_or_null, d_hg, N * 32, hipMemcpyDeviceToHost, s));
+    if (!dev && n1) {
+        G_TRY(hipMemcpyAsync(f1g_idx, d_gi, n1 * 8, hipMemcpyDeviceToHost, s));
+        G_TRY(hipMemcpyAsync(f1g_vals, d_gv, n1 * 32, hipMemcpyDeviceToHost, s));
+    }
+    G_TRY(hipStreamSynchronize(s));
+    *f1g_nnz = n1;
+    return SC_OK;
+}
+
+extern "C" int sc_gkr_phase_two_sharded(sc_comm *comm_or_null, const uint64_t *f1g_idx, const uint64_t *f1g_vals, uint64_t nnz_local, uint32_t dim,
+                                        const uint64_t *u, uint32_t flags, uint64_t *f1_gu_or_null, uint64_t *lanes_or_null) {
+    if ((nnz_local && (!f1g_idx || !f1g_vals)) || !u || (!f1_gu_or_null && !lanes_or_null)) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    int rc = check_gkr_args(nnz_local, dim);
+    if (rc) return rc;
+    if ((rc = check_points(u, dim, "u"))) return rc;
+    const bool dev = flags & SC_TABLES_ON_DEVICE;
+    hipStream_t s = nullptr;
+    DevBuf mem;
+    const uint64_t N = 1ULL << dim;
+    (void)mem.reserve(gkr_scratch_estimate(nnz_local, N) + 64 * N);
+    if ((rc = check_index_range(mem, f1g_idx, nnz_local, 2 * dim, dev, "f1_g", s))) return rc;
+    const uint64_t *d_idx = nullptr;
+    const Fr *d_vals = nullptr;
+    uint64_t *d_idx_s = nullptr;
+    Fr *d_vals_s = nullptr, *d_out = nullptr;
+    if ((rc = stage_in(mem, f1g_idx, nnz_local, dev, &d_idx, s)) || (rc = stage_in(mem, f1g_vals, nnz_local, dev, &d_vals, s))) return rc;
+    G_TRY(mem.alloc(&d_idx_s, nnz_local));
+    G_TRY(mem.alloc(&d_vals_s, nnz_local));
+    const bool in_place = dev && f1_gu_or_null;
+    if (in_place) d_out = reinterpret_cast<Fr *>(f1_gu_or_null);
+    else G_TRY(mem.alloc(&d_out, N));
+    if ((rc = sort_sparse(mem, d_idx, d_vals, nnz_local, 2 * dim, d_idx_s, d_vals_s, s))) return rc;
+    if ((rc = phase_two_device(mem, d_idx_s, d_vals_s, nnz_local, dim, reinterpret_cast<const sch::Fr *>(u), d_out, s))) return rc;
+    if ((rc = gkr_dense_allreduce(mem, comm_or_null, d_out, N, lanes_or_null, dev, s))) return rc;
+    if (f1_gu_or_null && !in_place) G_TRY(hipMemcpyAsync(f1_gu_or_null, d_out, N * 32, hipMemcpyDeviceToHost, s));
     G_TRY(hipStreamSynchronize(s));
     return SC_OK;
 }

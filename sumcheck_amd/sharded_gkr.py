@@ -1,0 +1,90 @@
+"""GKR initialisation with f1's non-zeros spread over several GPUs (reference
+src/gkr_round_sumcheck/mod.rs:22-42, 57-63).
+
+Every rank holds a disjoint subset of f1's (index, value) pairs -- any partition -- and all of f3.  a_hg[x] sums over ALL
+non-zeros, so a rank's scatter is a partial sum; the ranks' dense tables are added with one table-sized integer all-reduce of
+the widened limbs (2^dim x 8 uint64 lanes) and folded back mod p.  f1(g,.,.) stays distributed: each rank keeps the fold of its
+own entries and folds / scatters it again in phase two, followed by the same all-reduce.  Exact field arithmetic => the same
+canonical tables as the unsharded initialisation, whatever the partition.
+
+Two drivers: the library does the all-reduce itself over an sc_comm (RCCL or a host transport) -- *_sharded below -- or leaves
+the rank's lanes to the caller (`*_protocol`, over torch.distributed; the per-rank compute is pluggable there only so that the
+collective logic can be tested on CPU with gloo)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import SC_TABLES_ON_DEVICE, check, lib
+from .gkr_round_sumcheck import DenseMultilinearExtension, SparseMultilinearExtension, _dense_ptr, _np64, _ptr
+
+
+def initialize_phase_one_sharded(comm, f1_local: SparseMultilinearExtension, f3: DenseMultilinearExtension, g):
+    """-> (h_g complete on every rank, this rank's part of f1(g,.,.)); `comm`: sharded.NativeComm / HostComm (None = one rank)"""
+    dim = f3.num_vars
+    assert f1_local.num_vars == 3 * dim and not f1_local.on_device and not f3.on_device
+    g = _np64(g).reshape(-1, 4)
+    nnz = f1_local.nnz
+    h_g = np.empty((1 << dim, 4), dtype=np.uint64)
+    oi = np.empty(max(nnz, 1), dtype=np.uint64)
+    ov = np.empty((max(nnz, 1), 4), dtype=np.uint64)
+    n1 = C.c_uint64()
+    i_ptr, v_ptr = f1_local._ptrs()
+    check(lib().sc_gkr_phase_one_sharded(comm._h if comm is not None else None, i_ptr, v_ptr, nnz, dim, _dense_ptr(f3), _ptr(g), 0, _ptr(h_g), None,
+                                         _ptr(oi), _ptr(ov), C.byref(n1)))
+    return DenseMultilinearExtension(dim, h_g), SparseMultilinearExtension(2 * dim, oi[: n1.value].copy(), ov[: n1.value].copy())
+
+
+def initialize_phase_two_sharded(comm, f1_g_local: SparseMultilinearExtension, u) -> DenseMultilinearExtension:
+    u = _np64(u).reshape(-1, 4)
+    dim = u.shape[0]
+    assert f1_g_local.num_vars == 2 * dim
+    out = np.empty((1 << dim, 4), dtype=np.uint64)
+    i_ptr, v_ptr = f1_g_local._ptrs()
+    check(lib().sc_gkr_phase_two_sharded(comm._h if comm is not None else None, i_ptr, v_ptr, f1_g_local.nnz, dim, _ptr(u), 0, _ptr(out), None))
+    return DenseMultilinearExtension(dim, out)
+
+
+class HipGkrEngine:
+    """per-rank compute of the caller-driven protocol: the rank's contribution as lanes (sc_gkr_phase_*_sharded, lanes mode)"""
+
+    def phase_one_partial(self, idx, vals, dim, f3, g):
+        nnz = int(idx.shape[0])
+        lanes = np.empty((1 << dim, 8), dtype=np.uint64)
+        oi = np.empty(max(nnz, 1), dtype=np.uint64)
+        ov = np.empty((max(nnz, 1), 4), dtype=np.uint64)
+        n1 = C.c_uint64()
+        check(lib().sc_gkr_phase_one_sharded(None, _ptr(idx), _ptr(vals), nnz, dim, _ptr(f3), _ptr(g), 0, None, _ptr(lanes), _ptr(oi), _ptr(ov), C.byref(n1)))
+        return lanes, oi[: n1.value].copy(), ov[: n1.value].copy()
+
+    def phase_two_partial(self, idx, vals, dim, u):
+        lanes = np.empty((1 << dim, 8), dtype=np.uint64)
+        check(lib().sc_gkr_phase_two_sharded(None, _ptr(idx), _ptr(vals), int(idx.shape[0]), dim, _ptr(u), 0, None, _ptr(lanes)))
+        return lanes
+
+    def fold(self, lanes):
+        out = np.empty((lanes.shape[0], 4), dtype=np.uint64)
+        check(lib().sc_wide_reduce_table(_ptr(lanes), lanes.shape[0], _ptr(out), 0))
+        return out
+
+
+def _all_reduce_lanes(dist_comm, lanes: np.ndarray) -> np.ndarray:
+    import torch
+    t = torch.from_numpy(lanes.view(np.int64).copy())
+    dist_comm.all_reduce_sum(t)
+    return t.numpy().view(np.uint64)
+
+
+def phase_one_protocol(engine, dist_comm, idx_local, vals_local, dim, f3, g):
+    """caller-driven initialize_phase_one over torch.distributed (sharded.DistComm): -> (h_g, local f1_g idx, vals)"""
+    idx_local = np.ascontiguousarray(idx_local, dtype=np.uint64)
+    vals_local, f3, g = _np64(vals_local).reshape(-1, 4), _np64(f3).reshape(-1, 4), _np64(g).reshape(-1, 4)
+    lanes, oi, ov = engine.phase_one_partial(idx_local, vals_local, dim, f3, g)
+    return engine.fold(_all_reduce_lanes(dist_comm, lanes)), oi, ov
+
+
+def phase_two_protocol(engine, dist_comm, f1g_idx_local, f1g_vals_local, dim, u):
+    f1g_idx_local = np.ascontiguousarray(f1g_idx_local, dtype=np.uint64)
+    lanes = engine.phase_two_partial(f1g_idx_local, _np64(f1g_vals_local).reshape(-1, 4), dim, _np64(u).reshape(-1, 4))
+    return engine.fold(_all_reduce_lanes(dist_comm, lanes))

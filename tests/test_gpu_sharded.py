@@ -12,7 +12,7 @@ import pytest
 
 import sumcheck_amd as sc
 from oracle import cref
-from sumcheck_amd import _lib, sharded
+from sumcheck_amd import _lib, field, sharded
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
@@ -193,3 +193,76 @@ def test_sharded_proof_rccl_one_thread_per_gpu(world):
         assert not isinstance(out[r], Exception), out[r]
         for proof, rand in out[r]:
             assert np.array_equal(proof, want) and np.array_equal(rand, wrand)
+
+
+# ---- f4: sharded GKR initialisation -----------------------------------------------------------------------------------------------
+def _gkr_inputs(dim, seed):
+    rng = np.random.default_rng(seed)
+    n = 1 << dim
+    idx = np.unique((rng.integers(0, 1 << dim, size=3 * n, dtype=np.uint64)) | (rng.integers(0, 1 << dim, size=3 * n, dtype=np.uint64) << np.uint64(dim))
+                    | (rng.integers(0, 4, size=3 * n, dtype=np.uint64) << np.uint64(2 * dim)))[: 2 * n]
+    return idx, cref.synth_table(seed, 1, idx.shape[0]), cref.synth_table(seed, 3, n), cref.synth_table(seed, 4, dim), cref.synth_table(seed, 5, dim)
+
+
+@pytest.mark.parametrize("G,dim,strided", [(1, 9, False), (2, 10, True), (4, 12, False), (8, 7, True)])
+def test_sharded_gkr_initialisation_logical_shards(G, dim, strided):
+    """G logical shards of f1's non-zeros on one GPU, the caller-driven form: every shard's lanes (sc_gkr_phase_*_sharded in lanes
+    mode), summed as integers, folded on the device (sc_wide_reduce_table) == the unsharded oracle tables"""
+    from sumcheck_amd import sharded_gkr
+    idx, vals, f3, g, u = _gkr_inputs(dim, 500 + dim)
+    wh, wi, wv = cref.gkr_phase_one(idx, vals, dim, f3, g)
+    wgu = cref.gkr_phase_two(wi, wv, dim, u)
+    eng = sharded_gkr.HipGkrEngine()
+    parts = [slice(r, None, G) for r in range(G)] if strided else [slice(r * (len(idx) // G), (r + 1) * (len(idx) // G) if r + 1 < G else None) for r in range(G)]
+    tot, locals_ = None, []
+    for sl in parts:
+        lanes, oi, ov = eng.phase_one_partial(np.ascontiguousarray(idx[sl]), np.ascontiguousarray(vals[sl]), dim, f3, g)
+        tot = lanes if tot is None else tot + lanes
+        locals_.append((oi, ov))
+    assert np.array_equal(eng.fold(tot), wh)
+    # the distributed f1(g,.,.): per key, the sum over shards is the oracle's value (and every key the oracle has occurs somewhere)
+    acc = {}
+    for oi, ov in locals_:
+        for k, v in zip(oi.tolist(), field.to_ints(ov)):
+            acc[k] = (acc.get(k, 0) + v) % field.P
+    assert sorted(acc) == wi.tolist() and [acc[k] for k in wi.tolist()] == field.to_ints(wv)
+    tot2 = None
+    for oi, ov in locals_:
+        lanes = eng.phase_two_partial(oi, ov, dim, u)
+        tot2 = lanes if tot2 is None else tot2 + lanes
+    assert np.array_equal(eng.fold(tot2), wgu)
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_sharded_gkr_initialisation_library_collective(G):
+    """the library-driven form: one thread per rank, sc_gkr_phase_one_sharded / _two_sharded over an sc_comm (host transport
+    between the threads; RCCL takes the same path on distinct GPUs): every rank ends with the complete tables"""
+    from sumcheck_amd import sharded_gkr
+    dim = 11
+    idx, vals, f3, g, u = _gkr_inputs(dim, 77)
+    wh, wi, wv = cref.gkr_phase_one(idx, vals, dim, f3, g)
+    wgu = cref.gkr_phase_two(wi, wv, dim, u)
+    ex = sharded.ThreadExchange(G)
+    out = [None] * G
+
+    def run(rank):
+        try:
+            _lib.check(sc.lib().sc_set_device(0))
+            comm = ex.comm(rank)
+            f1 = sc.SparseMultilinearExtension(3 * dim, np.ascontiguousarray(idx[rank::G]), np.ascontiguousarray(vals[rank::G]))
+            h_g, f1_g = sharded_gkr.initialize_phase_one_sharded(comm, f1, sc.DenseMultilinearExtension(dim, f3), g)
+            f1_gu = sharded_gkr.initialize_phase_two_sharded(comm, f1_g, u)
+            comm.close()
+            out[rank] = (h_g.evaluations, f1_gu.evaluations)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            out[rank] = RuntimeError(f"rank {rank}: {e}\n{traceback.format_exc()}")
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    for r in range(G):
+        assert not isinstance(out[r], Exception), out[r]
+        assert np.array_equal(out[r][0], wh) and np.array_equal(out[r][1], wgu), f"rank {r}"

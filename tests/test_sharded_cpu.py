@@ -155,3 +155,70 @@ def test_sharded_entry_point_validates_before_touching_a_device():
     h = C.c_void_p()
     assert sc.lib().sc_comm_init_host(2, 2, None, None, None, C.byref(h)) == _lib.SC_ERR_BAD_ARG  # rank out of range
     assert sc.lib().sc_comm_init_host(0, 2, None, None, None, C.byref(h)) == _lib.SC_ERR_BAD_ARG  # transports required for > 1 rank
+
+
+class OracleGkrEngine:
+    """test double of sharded_gkr.HipGkrEngine: the rank's partial tables from the CPU oracle, widened to lanes; the fold is the
+    product's host routine (sc_wide_reduce)"""
+
+    @staticmethod
+    def _widen(tab):
+        return np.ascontiguousarray(tab.view(np.uint32).reshape(tab.shape[0], 8).astype(np.uint64))
+
+    def phase_one_partial(self, idx, vals, dim, f3, g):
+        h, oi, ov = cref.gkr_phase_one(idx, vals, dim, f3, g)
+        return self._widen(h), oi, ov
+
+    def phase_two_partial(self, idx, vals, dim, u):
+        return self._widen(cref.gkr_phase_two(idx, vals, dim, u))
+
+    def fold(self, lanes):
+        from sumcheck_amd import sharded
+        return sharded.wide_reduce(lanes)
+
+
+def _gkr_inputs(dim, seed):
+    rng = np.random.default_rng(seed)
+    n = 1 << dim
+    idx = np.unique((rng.integers(0, 1 << dim, size=3 * n, dtype=np.uint64)) | (rng.integers(0, 1 << dim, size=3 * n, dtype=np.uint64) << np.uint64(dim))
+                    | (rng.integers(0, 4, size=3 * n, dtype=np.uint64) << np.uint64(2 * dim)))[: 2 * n]  # many (x, y) collisions across z
+    return idx, cref.synth_table(seed, 1, idx.shape[0]), cref.synth_table(seed, 3, n), cref.synth_table(seed, 4, dim), cref.synth_table(seed, 5, dim)
+
+
+def _gkr_worker(rank, world, port, dim, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sumcheck_amd import sharded, sharded_gkr
+        idx, vals, f3, g, u = _gkr_inputs(dim, 321)
+        mine = slice(rank, None, world)  # a strided partition: the keys of f1(g,.,.) overlap across ranks
+        eng, comm = OracleGkrEngine(), sharded.DistComm()
+        h_g, gi, gv = sharded_gkr.phase_one_protocol(eng, comm, idx[mine], vals[mine], dim, f3, g)
+        f1_gu = sharded_gkr.phase_two_protocol(eng, comm, gi, gv, dim, u)
+        q.put((rank, h_g, f1_gu))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_sharded_gkr_initialisation_matches_oracle():
+    """f4: initialize_phase_one / _two with f1's non-zeros split over two ranks (table-sized widened all-reduce) equal the
+    unsharded oracle's tables"""
+    dim = 6
+    idx, vals, f3, g, u = _gkr_inputs(dim, 321)
+    wh, wi, wv = cref.gkr_phase_one(idx, vals, dim, f3, g)
+    wgu = cref.gkr_phase_two(wi, wv, dim, u)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gkr_worker, args=(r, 2, port, dim, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, h_g, f1_gu in res:
+        assert np.array_equal(h_g, wh), f"rank {rank}: h_g"
+        assert np.array_equal(f1_gu, wgu), f"rank {rank}: f1(g,u,.)"
