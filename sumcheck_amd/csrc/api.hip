@@ -138,6 +138,8 @@ struct sc_prover {
     std::vector<Table> tabs;
     void *arena = nullptr;
     FrHost *d_partials = nullptr;
+    FrHost *d_partials2 = nullptr;    // in-kernel finalize of the merged big-round launch: per-group partial sums ...
+    uint32_t *d_fin_counters = nullptr; // ... and its arrival counters (the kernel leaves them at zero)
     FinProd *d_finprods = nullptr;
     FrHost *d_W = nullptr; // node -> message matrices of every product (see FinProd::w_off)
     FrHost *d_scratch = nullptr;
@@ -176,6 +178,7 @@ struct sc_prover {
     int tail_max_blocks = 0;        // blocks of it the device holds at once (its grid never exceeds that)
     bool pipeline_ok = true;        // cleared when the wait-value path is unavailable (or SC_PIPELINE=0)
     bool deferred_pending = false;  // a round is enqueued behind the wait and still needs its challenge
+    bool fused_finalize = false;    // experiments, SC_FUSED_FIN=1: the merged big-round launch finalizes in-kernel (measured: slower than the k_finalize launch)
     bool use_tail = true;           // sc_ml_prove* / GKR: the latency-bound rounds run in the persistent tail kernel (SC_TAIL=0: pipelined launches)
     bool merge_rounds = false; // big rounds run as ONE launch over all products (k_round_tree): <= kMaxRoundProds products of <= 4 multiplicands
     bool use_f29 = false; // bound tables of big rounds kept in the internal 9 x 29-bit format (all products <= 4 multiplicands)
@@ -205,6 +208,8 @@ static void prover_destroy(sc_prover *p) {
     if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
     if (p->arena) (void)hipFree(p->arena);
     if (p->d_partials) (void)hipFree(p->d_partials);
+    if (p->d_partials2) (void)hipFree(p->d_partials2);
+    if (p->d_fin_counters) (void)hipFree(p->d_fin_counters);
     if (p->d_finprods) (void)hipFree(p->d_finprods);
     if (p->d_W) (void)hipFree(p->d_W);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
@@ -326,6 +331,7 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
         if (d->prod_offsets[k + 1] - d->prod_offsets[k] > 4) p->merge_rounds = false;
 #ifdef SC_EXPERIMENTS
     if (const char *e = std::getenv("SC_MERGE")) p->merge_rounds = p->merge_rounds && std::atoi(e) != 0;
+    if (const char *e = std::getenv("SC_FUSED_FIN")) p->fused_finalize = std::atoi(e) != 0;
     if (const char *e = std::getenv("SC_TAIL")) p->use_tail = std::atoi(e) != 0; // 0: late rounds as pipelined launches (the path sharded RCCL proofs take)
 #endif
 
@@ -415,6 +421,9 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     }
 
     HIP_TRY(hipMalloc(&p->d_partials, std::max<uint64_t>(partial_elems, 1) * 32));
+    HIP_TRY(hipMalloc(&p->d_partials2, std::max<uint64_t>(partial_elems, 1) * 32)); // second level of the in-kernel finalize (k_round_tree)
+    HIP_TRY(hipMalloc(&p->d_fin_counters, 4 * (2 + scd::kMaxGrid / 32)));
+    HIP_TRY(hipMemsetAsync(p->d_fin_counters, 0, 4 * (2 + scd::kMaxGrid / 32), p->stream));
     HIP_TRY(hipMalloc(&p->d_finprods, std::max<size_t>(p->K, 1) * sizeof(FinProd)));
     if (p->K) HIP_TRY(hipMemcpyAsync(p->d_finprods, fin.data(), p->K * sizeof(FinProd), hipMemcpyHostToDevice, p->stream));
     p->h_finprods = fin;
@@ -715,6 +724,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     }
     std::vector<uint8_t> bound(p->U, 0);
     bool ptrs_uploaded = false;
+    bool finalized = false; // the merged big-round launch also produced the message
     const bool merged = !small && p->merge_rounds && !p->any_generic;
     if (merged) {
         grid = std::min(grid, scd::kRoundTreeGrid);
@@ -761,10 +771,25 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
                 }
             }
         }
+        // the finalize step runs inside the launch (the blocks that finish last add up the partials and publish the message)
+        p->seq += 1;
+        ra.fin.enabled = p->fused_finalize ? 1 : 0;
+        ra.fin.D = (int)p->D;
+        for (uint32_t k = 0; k < p->K; ++k) ra.fin.w_off[k] = p->h_finprods[k].w_off;
+        ra.fin.Wm = reinterpret_cast<const uint4 *>(p->d_W);
+        ra.fin.partials2 = reinterpret_cast<uint4 *>(p->d_partials2);
+        ra.fin.counters = p->d_fin_counters;
+        ra.fin.out = reinterpret_cast<uint4 *>(p->d_out);
+        ra.fin.out_wide = d_wide;
+        ra.fin.h_out = publish_to_host ? reinterpret_cast<uint4 *>(p->h_out_dev) : nullptr;
+        ra.fin.h_flag = publish_to_host ? p->h_flag_dev : nullptr;
+        ra.fin.seq = p->seq;
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[0], p->stream));
         HIP_TRY(scd::launch_round_tree(ra, rc, n_pairs, p->d_partials, grid, p->stream));
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[1], p->stream));
         scaled = 1;
+        if (p->fused_finalize) finalized = true;
+        else p->seq -= 1;
     }
     for (uint32_t k = 0; k < p->K && !small && !merged; ++k) {
         const Product &pr = p->prods[k];
@@ -858,10 +883,12 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         for (uint32_t u = 0; u < p->U; ++u)
             if (!bound[u]) HIP_TRY(bind_table(u));
     }
+    if (!finalized) {
     p->seq += 1;
     HIP_TRY(scd::launch_finalize(p->d_finprods, p->h_finprods.empty() ? nullptr : p->h_finprods.data(), p->d_W, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide,
                                  publish_to_host ? p->h_out_dev : nullptr, publish_to_host ? p->h_flag_dev : nullptr, p->seq, scaled,
                                  p->stream));
+    }
     if (timed) HIP_TRY(hipEventRecord(p->ev1, p->stream));
     if (!deferred) { // (a pipelined round leaves the previous round's pending event pairs to the next collect_timing)
         p->timed = timed;

@@ -64,9 +64,24 @@ struct TreeProd {
     uint32_t pad;
     uint64_t partial_off; // in field elements, as in FinProd
 };
+// the round's finalize step inside k_round_tree (kernels.hip): what k_finalize would have been given
+struct RoundFin {
+    int enabled;
+    int D;
+    uint64_t w_off[kMaxRoundProds]; // FinProd::w_off of every product
+    const uint4 *Wm;
+    uint4 *partials2;               // second-level partials: the layout of the partial array with one "block" per group of 32
+    uint32_t *counters;             // device, zero at launch: [0] groups completed, [1 + g] blocks of group g arrived
+    uint4 *out;                     // the message: device copy, ...
+    uint64_t *out_wide;             // ... widened lanes for an all-reduce (sharded proofs), ...
+    uint4 *h_out;                   // ... host-mapped copy with its sequence flag
+    uint32_t *h_flag;
+    uint32_t seq;
+};
 struct RoundArgs {
     TreeProd prod[kMaxRoundProds];
     int n_prod;
+    RoundFin fin;
 };
 
 // static per-product record for the finalize kernel (device memory)

@@ -413,29 +413,6 @@ __global__ __launch_bounds__(kBlock) void k_prod_tree(const ProdArgs A, const Bi
     tree_pass<M>(A.slot, rt, n_pairs, partials + 2 * (uint64_t)blockIdx.x, sm, lacc);
 }
 
-// every product of the round in one launch (RoundArgs in kernels.h)
-__global__ __launch_bounds__(kBlock) void k_round_tree(const RoundArgs R, const BindConst r, const uint64_t n_pairs,
-                                                       uint4 *__restrict__ partials) {
-    __shared__ uint32_t sm[kBlock / 64][8];
-    __shared__ int32_t rt[kBindLds];
-    __shared__ int32_t lacc[9 * 5 * kBlock];
-    bind_consts_to_lds(r, rt);
-    const int n = R.n_prod;
-    // start product rotated by dispatch slot (blockIdx & 7 = XCD): multiplier-bound and HBM-bound products overlap across an XCD's CUs
-    int k = (int)((blockIdx.x & 7u) % (uint32_t)n);
-    for (int i = 0; i < n; ++i) {
-        const TreeProd &T = R.prod[k];
-        uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x);
-        switch (T.M) {
-        case 1: tree_pass<1>(T.slot, rt, n_pairs, row, sm, lacc); break;
-        case 2: tree_pass<2>(T.slot, rt, n_pairs, row, sm, lacc); break;
-        case 3: tree_pass<3>(T.slot, rt, n_pairs, row, sm, lacc); break;
-        default: tree_pass<4>(T.slot, rt, n_pairs, row, sm, lacc); break;
-        }
-        if (++k == n) k = 0;
-    }
-}
-
 #ifdef SC_EXPERIMENTS // cross-check variant and measured negative result: LDS-tiled kernel (SC_KERNEL=2)
 // ------------------------------------------------------------------------------------------------
 // K4, tiled: the fused bind + product-sum with fine-grained work items staged through LDS.
@@ -872,6 +849,94 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
         else return prods[k];
     };
     finalize_body<kFinBlock>(prod_of, Wm, K, D, nblocks, partials, scratch, out, out_wide, h_out, h_flag, seq, scaled);
+}
+
+// every product of the round in one launch (RoundArgs in kernels.h).
+// Experiments build only -- R.fin.enabled: the round's finalize step inside the launch.  A separate k_finalize launch costs a dispatch gap (~5 us) plus ~20 us for one block to add up 768 x 14
+// partials.  Here the blocks that finish last do it in two levels: the last block of every group of kFinGroup blocks (by block index;
+// an arrival counter per group) adds the group's partials into one set, and the block that completes the last group combines the
+// ~24 group sets into the message (finalize_body), publishes it and resets the counters for the next launch.  Everything the
+// combining block reads was released (agent scope) by its writer before the counter it acquired was incremented.
+constexpr int kFinGroup = 32;
+__global__ __launch_bounds__(kBlock) void k_round_tree(const RoundArgs R, const BindConst r, const uint64_t n_pairs,
+                                                       uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    __shared__ int32_t rt[kBindLds];
+    __shared__ int32_t lacc[9 * 5 * kBlock];
+#ifdef SC_EXPERIMENTS
+    __shared__ uint32_t role_sh;
+#endif
+    bind_consts_to_lds(r, rt);
+    const int n = R.n_prod;
+    // start product rotated by dispatch slot (blockIdx & 7 = XCD): multiplier-bound and HBM-bound products overlap across an XCD's CUs
+    int k = (int)((blockIdx.x & 7u) % (uint32_t)n);
+    for (int i = 0; i < n; ++i) {
+        const TreeProd &T = R.prod[k];
+        uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x);
+        switch (T.M) {
+        case 1: tree_pass<1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+        case 2: tree_pass<2>(T.slot, rt, n_pairs, row, sm, lacc); break;
+        case 3: tree_pass<3>(T.slot, rt, n_pairs, row, sm, lacc); break;
+        default: tree_pass<4>(T.slot, rt, n_pairs, row, sm, lacc); break;
+        }
+        if (++k == n) k = 0;
+    }
+#ifdef SC_EXPERIMENTS // measured negative result (SC_FUSED_FIN=1): +45 us per launch -- every block's agent-scope release is a write-back of the
+                      // XCD's L2, full of freshly bound table lines in rounds >= 2 -- against the ~25 us of a separate k_finalize launch
+    if (!R.fin.enabled) return;
+    // ---- level 1: the last block of this group adds up the group's partials ---------------------------------------------------
+    const uint32_t G = gridDim.x, n_groups = (G + kFinGroup - 1) / kFinGroup;
+    const uint32_t g = blockIdx.x / kFinGroup, g_first = g * kFinGroup, g_size = min((uint32_t)kFinGroup, G - g_first);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t d = __hip_atomic_fetch_add(R.fin.counters + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        role_sh = d == g_size - 1 ? 1u : 0u;
+        if (role_sh) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!role_sh) return;
+    {
+        // items (product, node, quarter q of the group): one lane adds up to 8 partials, four adjacent lanes combine
+        int n_items = 0;
+        for (int q = 0; q < n; ++q) n_items += (int)R.prod[q].M + 1;
+        for (int it0 = 0; it0 < 4 * n_items; it0 += kBlock) { // block-uniform trip count
+            const int it = it0 + (int)threadIdx.x;
+            const bool live = it < 4 * n_items;
+            int c = live ? it >> 2 : 0, q4 = it & 3, pk = 0;
+            while (c > (int)R.prod[pk].M) { c -= (int)R.prod[pk].M + 1; ++pk; } // c = node of product pk
+            const uint4 *base = partials + 2 * (R.prod[pk].partial_off + (uint64_t)c * G + g_first);
+            Fr acc = fr_zero();
+            if (live)
+                for (uint32_t b = (uint32_t)q4 * 8; b < min((uint32_t)q4 * 8 + 8, g_size); ++b) acc = fr_add(acc, fr_load(base + 2 * b));
+            acc = fr_add(acc, fr_shfl_down(acc, 2));
+            acc = fr_add(acc, fr_shfl_down(acc, 1));
+            if (live && q4 == 0) fr_store(R.fin.partials2 + 2 * (R.prod[pk].partial_off + (uint64_t)c * n_groups + g), acc);
+        }
+    }
+    // ---- level 2: the block that completes the last group writes the message --------------------------------------------------
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t d = __hip_atomic_fetch_add(R.fin.counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        role_sh = d == n_groups - 1 ? 2u : 0u;
+        if (role_sh) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (role_sh != 2u) return;
+    for (uint32_t i = threadIdx.x; i <= n_groups; i += kBlock) // the counters start the next launch at zero
+        __hip_atomic_store(R.fin.counters + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto prod_of = [&](int q) -> FinProd {
+        FinProd f;
+        f.M = R.prod[q].M;
+        f.pad = 0;
+        f.partial_off = R.prod[q].partial_off;
+        f.w_off = R.fin.w_off[q];
+        return f;
+    };
+    finalize_body<kBlock>(prod_of, R.fin.Wm, n, R.fin.D, (int)n_groups, R.fin.partials2, reinterpret_cast<uint4 *>(lacc), R.fin.out, R.fin.out_wide,
+                          R.fin.h_out, R.fin.h_flag, R.fin.seq, 1);
+#endif // SC_EXPERIMENTS
 }
 
 // ------------------------------------------------------------------------------------------------
