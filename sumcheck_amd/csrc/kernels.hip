@@ -857,7 +857,9 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
 // an arrival counter per group) adds the group's partials into one set, and the block that completes the last group combines the
 // ~24 group sets into the message (finalize_body), publishes it and resets the counters for the next launch.  Everything the
 // combining block reads was released (agent scope) by its writer before the counter it acquired was incremented.
+#ifdef SC_EXPERIMENTS
 constexpr int kFinGroup = 32;
+#endif
 __global__ __launch_bounds__(kBlock) void k_round_tree(const RoundArgs R, const BindConst r, const uint64_t n_pairs,
                                                        uint4 *__restrict__ partials) {
     __shared__ uint32_t sm[kBlock / 64][8];
