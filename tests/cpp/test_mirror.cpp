@@ -220,6 +220,57 @@ static void test_gkr_extract(Blake2b512Rng &rng, size_t dim) { // gkr_round_sumc
     EXPECT(!bad.verify_subclaim(f1, f2, f3, g));
 }
 
+// A proof element or claimed sum >= p is not a field element (the reference's Fp cannot hold one): ev0 + p, ev1 + p hash to the honest
+// transcript and, added as raw limbs, wrap past 2^256 -- every verifier entry must refuse the encoding before any arithmetic.
+static void test_verifier_refuses_non_canonical(Blake2b512Rng &rng) {
+    static const uint64_t P[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+    auto plus_p = [](Fr x) {
+        unsigned __int128 c = 0;
+        for (int i = 0; i < 4; ++i) {
+            c += (unsigned __int128)x.l[i] + P[i];
+            x.l[i] = (uint64_t)c;
+            c >>= 64;
+        }
+        return x;
+    };
+    auto refuses = [&](std::function<void()> f) {
+        try {
+            f();
+        } catch (const Panic &e) {
+            return std::string(e.what()).find("canonical") != std::string::npos;
+        } catch (const Reject &) {
+            return false; // must be refused as malformed, not merely rejected
+        }
+        return false;
+    };
+    auto [poly, asserted_sum] = random_list_of_products(5, 2, 4, 2, rng);
+    const Proof proof = MLSumcheck::prove(poly);
+    EXPECT(MLSumcheck::extract_sum(proof) == asserted_sum);
+    Proof bad = proof;
+    bad[0].evaluations[0] = plus_p(bad[0].evaluations[0]);
+    bad[0].evaluations[1] = plus_p(bad[0].evaluations[1]);
+    EXPECT(!bad[0].evaluations[0].is_canonical());
+    EXPECT(refuses([&] { MLSumcheck::verify(poly.info(), asserted_sum, bad); }));
+    EXPECT(refuses([&] { MLSumcheck::verify(poly.info(), plus_p(asserted_sum), proof); }));
+    Proof shortp = proof; // a message one evaluation short: "incorrect number of evaluations" (verifier.rs:60-62)
+    shortp[1].evaluations.pop_back();
+    bool panicked = false;
+    try {
+        MLSumcheck::verify(poly.info(), asserted_sum, shortp);
+    } catch (const Panic &e) {
+        panicked = std::string(e.what()).find("incorrect number of evaluations") != std::string::npos;
+    }
+    EXPECT(panicked);
+    // GKR verify_phase adds raw limbs in the mirror itself
+    GKRProof gp;
+    gp.phase1_sumcheck_msgs = {ProverMsg{{plus_p(Fr::one()), Fr::zero(), Fr::zero()}}};
+    gp.phase2_sumcheck_msgs = {ProverMsg{{Fr::zero(), Fr::zero(), Fr::zero()}}};
+    EXPECT(refuses([&] {
+        Blake2b512Rng vs;
+        GKRRoundSumcheck::verify(vs, 1, gp, Fr::one());
+    }));
+}
+
 int main() {
     if (sc_device_count() <= 0) {
         std::printf("no HIP device: these tests need a GPU\n");
@@ -237,6 +288,7 @@ int main() {
         {"test_extract_sum", [&] { test_extract_sum(rng); }},
         {"test_shared_reference", [&] { test_shared_reference(rng); }},
         {"prover state machine panics", [&] { test_prover_state_machine(rng); }},
+        {"verifier refuses non-canonical encodings and short messages", [&] { test_verifier_refuses_non_canonical(rng); }},
         {"gkr test_extract (dim 6)", [&] { test_gkr_extract(rng, 6); }},
         {"gkr test_small shape (dim 9)", [&] { test_gkr_extract(rng, 9); }},
     };
