@@ -11,6 +11,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # SC_LIB_VARIANT=exp (tests/test_gpu_variants.py only): the -DSC_EXPERIMENTS build with the cross-check kernels and their knobs
 SO_PATH = os.path.join(HERE, "libsumcheck_hip_exp.so" if os.environ.get("SC_LIB_VARIANT") == "exp" else "libsumcheck_hip.so")
+if os.environ.get("SC_LIB_PATH"):  # A/B runs of two builds on one box (tools/): an explicit library file
+    SO_PATH = os.environ["SC_LIB_PATH"]
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
