@@ -324,8 +324,9 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
     uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     // Two and three multiplicands: TWO pairs per iteration (b and b + stride).  The final products of a node only ever feed that
     // node's running sum, so the two pairs' products share one Montgomery reduction (fe_mul2_sum: 234 multiply-adds instead of 306).
-    // The live set of these shapes (at most 2 x 5 elements) fits the kernel's register budget; four multiplicands stay one pair at a
-    // time (two pairs there cost a resident block, measured +8 %).
+    // The live set of these shapes (at most 2 x 5 elements) fits the 168 registers of three resident blocks with 16 spills.  Four
+    // multiplicands stay one pair at a time: twelve quadratic coefficients across two pairs spill 47 registers, and the scratch traffic
+    // costs round 2 more (+75 us) than the shared reductions save in round 1 (-23 us) -- measured, same box.
     if constexpr (M == 2 || M == 3) {
         for (; b + stride < n_pairs; b += 2 * stride, ++iter) {
             Fe P[M + 1];
