@@ -153,7 +153,8 @@ struct sc_prover {
     uint64_t *h_wide = nullptr;      // ... and its host-mapped landing page
     uint64_t *h_wide_dev = nullptr;
     void *d_tail_send = nullptr, *d_tail_recv = nullptr, *d_tail_tabs = nullptr; // sc_ml_prove_sharded: bind_final out, all-gather out, G-entry tables
-    sc_prover *tail = nullptr;       // ... and the log2 G-variable prover over them (built once, rewound per proof)
+    sc_prover *tail = nullptr;       // ... and the prover of the replicated last rounds over them (built once, rewound per proof)
+    uint32_t tail_ranks = 0;
     std::vector<std::vector<uint32_t>> prod_indices; // the descriptor's product lists as given (for the tail's descriptor)
     Combo *d_combos = nullptr;    // (product, point) combinations for the small-round kernel
     std::vector<FinProd> h_finprods; // host copy of d_finprods (kernel-argument path of k_finalize)
@@ -1130,14 +1131,16 @@ extern "C" int sc_prove_round_partial(sc_prover *p, const uint64_t *r_or_null, u
     return launch_round(p, r_or_null, d_wide_out, false);
 }
 
-extern "C" int sc_prover_bind_final(sc_prover *p, const uint64_t *r, uint64_t *d_out) {
-    if (!p || !r || !d_out) return fail(SC_ERR_BAD_ARG, "null argument");
-    if (p->exhausted || p->round != p->nv) return fail(SC_ERR_NOT_ACTIVE, "bind_final needs a prover that has finished its last local round");
+// Bind the challenge `r` into every table once more and write the results back to back (table u at d_out + u * n * 4 limbs, n =
+// 2^(num_vars - round) entries each, canonical form whatever the tables' internal format).  After this the handle is exhausted.
+static int prover_bind_out(sc_prover *p, const uint64_t *r, uint64_t *d_out) {
+    if (p->exhausted || p->round == 0 || p->round > p->nv) return fail(SC_ERR_NOT_ACTIVE, "bind needs a prover that has run at least one round");
     sch::Fr rr;
     std::memcpy(&rr, r, 32);
     if (sch::geq_p(rr)) return fail(SC_ERR_BAD_ARG, "challenge is not a canonical field element");
     HIP_TRY(hipSetDevice(p->device));
     p->randomness.push_back(rr);
+    const uint64_t n_out = 1ULL << (p->nv - p->round);
     for (uint32_t u0 = 0; u0 < p->U; u0 += (uint32_t)scd::kMaxSmallTables) { // one launch per 32 tables
         const uint32_t cnt = std::min<uint32_t>(p->U - u0, (uint32_t)scd::kMaxSmallTables);
         TablePtrs tp;
@@ -1145,12 +1148,18 @@ extern "C" int sc_prover_bind_final(sc_prover *p, const uint64_t *r, uint64_t *d
         for (uint32_t j = 0; j < cnt; ++j) {
             tp.src[j] = p->tabs[u0 + j].cur;
             tp.src_top[j] = p->tabs[u0 + j].cur_top;
-            tp.dst[j] = reinterpret_cast<uint4 *>(d_out + 4 * (size_t)(u0 + j));
+            tp.dst[j] = reinterpret_cast<uint4 *>(d_out + 4 * n_out * (size_t)(u0 + j));
         }
-        HIP_TRY(scd::launch_fix_multi(tp, (int)cnt, to_dev(rr), nullptr, 1, p->stream));
+        HIP_TRY(scd::launch_fix_multi(tp, (int)cnt, to_dev(rr), nullptr, n_out, p->stream));
     }
     p->exhausted = true;
     return SC_OK;
+}
+
+extern "C" int sc_prover_bind_final(sc_prover *p, const uint64_t *r, uint64_t *d_out) {
+    if (!p || !r || !d_out) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (p->exhausted || p->round != p->nv) return fail(SC_ERR_NOT_ACTIVE, "bind_final needs a prover that has finished its last local round");
+    return prover_bind_out(p, r, d_out);
 }
 
 extern "C" int sc_prover_push_randomness(sc_prover *p, const uint64_t *r) {
@@ -1913,33 +1922,49 @@ extern "C" int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *r
     return sharded_rounds(p, comm, rng->rng, n_rounds, out_proof, out_randomness);
 }
 
-// The tail of a sharded proof: after its last local round every shard holds two entries per table; binding the next challenge
-// leaves one, the G ranks' elements are all-gathered, and every rank finishes the last log2 G rounds on the same G-entry tables
-// (no exchange needed any more; the transcripts stay in step because they absorb identical messages).
-static int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, const uint64_t *last_challenge, uint32_t k, uint64_t *out_proof,
+// The tail of a sharded proof.  Sharded rounds pay a collective each; once the GLOBAL instance is down to a latency-bound size
+// (at most 2^14 pairs) it is cheaper to stop sharding: every rank binds the last challenge into what is left of its shard (2^m
+// entries per table), the remainders are all-gathered (U * 2^m * 32 bytes per rank), and every rank finishes the last m + log2 G
+// rounds on the same complete tables -- no exchange any more (the transcripts stay in step: they absorb identical messages), at the
+// single-GPU cost per round, in the persistent tail kernel.  m = 0 (one element per table and rank) is the smallest case.
+static uint32_t sharded_tail_m(uint32_t nv_local, uint32_t k) { // log2 of the entries per table a rank still holds at the gather
+    if (k == 0) return 0;
+    const uint32_t want = k >= 15 ? 0u : 15u - k; // 2^(m + k - 1) pairs <= 2^14 in the first replicated round
+    return std::min(want, nv_local - 1);          // at least one sharded round
+}
+static int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, const uint64_t *last_challenge, uint32_t k, uint32_t m, uint64_t *out_proof,
                         uint64_t *out_randomness) {
-    const uint32_t G = (uint32_t)comm->nranks, U = p->U;
-    const size_t send_bytes = (size_t)U * 32;
+    const uint32_t G = (uint32_t)comm->nranks, U = p->U, per = 1u << m;
+    const size_t send_bytes = (size_t)U * per * 32;
+    if (p->tail && (p->tail->nv != k + m || p->tail_ranks != G)) { // the handle meets a communicator of another size: rebuild the tail
+        prover_destroy(p->tail);
+        p->tail = nullptr;
+        (void)hipFree(p->d_tail_send);
+        (void)hipFree(p->d_tail_recv);
+        (void)hipFree(p->d_tail_tabs);
+        p->d_tail_send = p->d_tail_recv = p->d_tail_tabs = nullptr;
+    }
+    p->tail_ranks = G;
     if (!p->d_tail_send) {
         HIP_TRY(hipMalloc(&p->d_tail_send, send_bytes));
         HIP_TRY(hipMalloc(&p->d_tail_recv, send_bytes * G));
         HIP_TRY(hipMalloc(&p->d_tail_tabs, send_bytes * G));
     }
-    int rc = sc_prover_bind_final(p, last_challenge, reinterpret_cast<uint64_t *>(p->d_tail_send));
+    int rc = prover_bind_out(p, last_challenge, reinterpret_cast<uint64_t *>(p->d_tail_send));
     if (rc) return rc;
     if (comm->comm) {
-        NCCL_TRY(g_nccl.AllGather(p->d_tail_send, p->d_tail_recv, (size_t)U * 4, ncclUint64, comm->comm, p->stream));
+        NCCL_TRY(g_nccl.AllGather(p->d_tail_send, p->d_tail_recv, send_bytes / 8, ncclUint64, comm->comm, p->stream));
     } else {
-        std::vector<uint64_t> send((size_t)U * 4), recv((size_t)U * 4 * G);
+        std::vector<uint64_t> send(send_bytes / 8), recv(send_bytes / 8 * G);
         HIP_TRY(hipMemcpyAsync(send.data(), p->d_tail_send, send_bytes, hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
         if (comm->h_allgather(comm->ctx, send.data(), recv.data(), send_bytes) != 0) return fail(SC_ERR_HIP, "the host transport's all-gather failed");
         HIP_TRY(hipMemcpyAsync(p->d_tail_recv, recv.data(), send_bytes * G, hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream)); // `recv` goes out of scope
     }
-    HIP_TRY(scd::launch_gather_to_tables(static_cast<const uint4 *>(p->d_tail_recv), static_cast<uint4 *>(p->d_tail_tabs), G, U, p->stream));
+    HIP_TRY(scd::launch_gather_to_tables(static_cast<const uint4 *>(p->d_tail_recv), static_cast<uint4 *>(p->d_tail_tabs), G, U, per, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream)); // the tail prover runs on its own stream
-    if (!p->tail) { // built once per handle: the same products over U borrowed G-entry tables
+    if (!p->tail) { // built once per handle: the same products over U borrowed tables of G * 2^m entries
         std::vector<uint64_t> coeffs((size_t)p->K * 4);
         std::vector<uint32_t> offs(1, 0), idx;
         for (uint32_t q = 0; q < p->K; ++q) {
@@ -1948,10 +1973,10 @@ static int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, co
             offs.push_back((uint32_t)idx.size());
         }
         std::vector<const uint64_t *> tabs(U);
-        for (uint32_t u = 0; u < U; ++u) tabs[u] = reinterpret_cast<const uint64_t *>(static_cast<char *>(p->d_tail_tabs) + (size_t)u * G * 32);
+        for (uint32_t u = 0; u < U; ++u) tabs[u] = reinterpret_cast<const uint64_t *>(static_cast<char *>(p->d_tail_tabs) + (size_t)u * G * per * 32);
         sc_poly_desc d;
         std::memset(&d, 0, sizeof(d));
-        d.num_vars = k;
+        d.num_vars = k + m;
         d.max_multiplicands = p->max_mult;
         d.n_products = p->K;
         d.coeffs = coeffs.data();
@@ -1971,10 +1996,10 @@ static int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, co
     }
     // (same reasoning as in sharded_rounds: no polling kernels on a GPU that other ranks of a host transport may share)
     if (!comm->comm && comm->nranks > 1) p->tail->pipeline_ok = false;
-    std::vector<sch::Fr> ch(k);
-    rc = sc_internal_run_rounds(p->tail, rng, k, out_proof, ch.data());
+    std::vector<sch::Fr> ch(k + m);
+    rc = sc_internal_run_rounds(p->tail, rng, k + m, out_proof, ch.data());
     if (rc) return rc;
-    std::memcpy(out_randomness, ch.data(), (size_t)k * 32);
+    std::memcpy(out_randomness, ch.data(), (size_t)(k + m) * 32);
     return SC_OK;
 }
 
@@ -1988,12 +2013,12 @@ extern "C" int sc_ml_prove_sharded(sc_prover *p, sc_comm *comm, sc_rng *rng_or_n
     sc_rng local;
     sch::Blake2b512Rng &rng = rng_or_null ? rng_or_null->rng : local.rng;
     rng.feed_poly_info(p->max_mult, nv_total); // mod.rs:54: the GLOBAL instance's info
-    const uint32_t nl = p->nv;
+    const uint32_t m = sharded_tail_m(p->nv, k), nl = p->nv - m; // nl sharded rounds, then m + k replicated ones
     int rc = sharded_rounds(p, comm, rng, nl, out_proof, out_randomness);
     if (rc) return rc;
     const uint64_t *last = out_randomness + (size_t)(nl - 1) * 4;
     if (k == 0) return sc_prover_push_randomness(p, last); // mod.rs:65-67
-    return sharded_tail(p, comm, rng, last, k, out_proof + (size_t)nl * p->D * 4, out_randomness + (size_t)nl * 4);
+    return sharded_tail(p, comm, rng, last, k, m, out_proof + (size_t)nl * p->D * 4, out_randomness + (size_t)nl * 4);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -217,8 +217,8 @@ hipError_t launch_finalize(const FinProd *d_prods, const FinProd *h_prods_or_nul
 hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);
 hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t n, hipStream_t stream);
 hipError_t launch_publish_words(const uint64_t *d_src, uint64_t *h_dst_mapped, int n, uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream);
-// recv[g][u] -> tabs[u][g] (elements of 32 bytes): the all-gathered last entries of G shards become U tables of G entries
-hipError_t launch_gather_to_tables(const uint4 *recv, uint4 *tabs, uint32_t G, uint32_t U, hipStream_t stream);
+// recv[g][u][e] -> tabs[u][g * per + e] (elements of 32 bytes): the all-gathered remainders of G shards become U tables of G * per entries
+hipError_t launch_gather_to_tables(const uint4 *recv, uint4 *tabs, uint32_t G, uint32_t U, uint32_t per, hipStream_t stream);
 // F29 table -> canonical reference layout (state export)
 hipError_t launch_f29_to_sat(const uint4 *src, const int32_t *src_top, uint4 *dst, uint64_t n, hipStream_t stream);
 hipError_t launch_fr_elementwise(int op, const uint4 *a, const uint4 *b, const FrHost &u, uint4 *out, uint64_t n, hipStream_t stream);

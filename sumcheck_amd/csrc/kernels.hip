@@ -1583,17 +1583,22 @@ hipError_t launch_publish_words(const uint64_t *d_src, uint64_t *h_dst_mapped, i
     return hipGetLastError();
 }
 
-// tail of a sharded proof: recv[g][u] (rank-major, as an all-gather leaves it) -> tabs[u][g] (one G-entry table per polynomial)
-__global__ void k_gather_to_tables(const uint4 *__restrict__ recv, uint4 *__restrict__ tabs, const uint32_t G, const uint32_t U) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // output element index u * G + g
-    if (i >= G * U) return;
-    const uint32_t u = i / G, g = i % G;
-    tabs[2 * (size_t)i] = recv[2 * ((size_t)g * U + u)];
-    tabs[2 * (size_t)i + 1] = recv[2 * ((size_t)g * U + u) + 1];
+// tail of a sharded proof: recv[g][u][e] (rank-major, as an all-gather leaves it; e < per) -> tabs[u][g * per + e]: one table of
+// G * per entries per polynomial, rank g's slice at the high index bits where its shard of the original table was
+__global__ void k_gather_to_tables(const uint4 *__restrict__ recv, uint4 *__restrict__ tabs, const uint32_t G, const uint32_t U, const uint32_t per) {
+    const uint64_t n = (uint64_t)G * U * per;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { // output element index
+        const uint32_t e = (uint32_t)(i % per);
+        const uint64_t ug = i / per;
+        const uint32_t g = (uint32_t)(ug % G), u = (uint32_t)(ug / G);
+        const uint64_t src = ((uint64_t)g * U + u) * per + e;
+        tabs[2 * i] = recv[2 * src];
+        tabs[2 * i + 1] = recv[2 * src + 1];
+    }
 }
-hipError_t launch_gather_to_tables(const uint4 *recv, uint4 *tabs, uint32_t G, uint32_t U, hipStream_t stream) {
-    const uint32_t n = G * U;
-    hipLaunchKernelGGL(k_gather_to_tables, dim3((n + 255) / 256), dim3(256), 0, stream, recv, tabs, G, U);
+hipError_t launch_gather_to_tables(const uint4 *recv, uint4 *tabs, uint32_t G, uint32_t U, uint32_t per, hipStream_t stream) {
+    const uint64_t n = (uint64_t)G * U * per;
+    hipLaunchKernelGGL(k_gather_to_tables, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, stream, recv, tabs, G, U, per);
     return hipGetLastError();
 }
 

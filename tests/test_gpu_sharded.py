@@ -75,6 +75,45 @@ def test_sharded_proof_threads_on_one_gpu(G, nv, nt, shapes):
             assert np.array_equal(rand, wrand), f"rank {r}"
 
 
+def test_sharded_rounds_every_local_round_in_the_library():
+    """sc_ml_prove_sharded stops sharding once the global instance is latency-bound (it gathers early), so most of a small test
+    instance's rounds are replicated.  This drives ALL local rounds through the sharded loop (sc_ml_prove_sharded_rounds: per-round
+    all-reduce, small and big rounds alike) on 4 thread ranks and checks their messages and challenges against the oracle."""
+    G, nv, nt, shapes = 4, 20, 4, [[0, 1, 2], [3, 3], [1]]
+    tabs, coefs, want, wrand = _oracle(nv, shapes, nt, 4242)
+    ex = sharded.ThreadExchange(G)
+    out = [None] * G
+    nl = nv - 2
+
+    def run(rank):
+        try:
+            import torch
+            _lib.check(sc.lib().sc_set_device(0))
+            n_loc = (1 << nv) // G
+            eng = sharded.HipShardEngine(nl, shapes, coefs, [t[rank * n_loc:(rank + 1) * n_loc] for t in tabs], "cuda:0", borrow=True)
+            comm = ex.comm(rank)
+            rng = sc.Blake2b512Rng.setup()
+            lp, lr = np.empty((nl, eng.D, 4), dtype=np.uint64), np.empty((nl, 4), dtype=np.uint64)
+            torch.cuda.current_stream().synchronize()
+            _lib.check(sc.lib().sc_prover_set_stream(eng._h, None, 1))
+            _lib.check(sc.lib().sc_ml_prove_sharded_rounds(eng._h, comm._h, rng._h, nv, nl, C.c_void_p(lp.ctypes.data), C.c_void_p(lr.ctypes.data)))
+            comm.close()
+            eng.close()
+            out[rank] = (lp, lr)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            out[rank] = RuntimeError(f"rank {rank}: {e}\n{traceback.format_exc()}")
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    for r in range(G):
+        assert not isinstance(out[r], Exception), out[r]
+        assert np.array_equal(out[r][0], want[:nl]) and np.array_equal(out[r][1], wrand[:nl]), f"rank {r}"
+
+
 def test_sharded_proof_world1_is_the_unsharded_proof():
     """one rank: no exchange, no tail; with the host transport and (next test) with RCCL"""
     nv, shapes, nt = 18, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10
