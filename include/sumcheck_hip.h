@@ -56,7 +56,8 @@ enum sc_status {
 
 enum sc_flags {
     SC_TABLES_ON_DEVICE = 1u << 0, /* `tables[]` are device pointers (HBM-resident), not host */
-    SC_TABLES_BORROW = 1u << 1     /* with ON_DEVICE: do not copy; tables are only read and must outlive the handle */
+    SC_TABLES_BORROW = 1u << 1,    /* with ON_DEVICE: do not copy; tables are only read and must outlive the handle */
+    SC_TABLES_STREAM = 1u << 2     /* HOST tables too large to copy: see sc_prover_init_streamed (set by it; sc_prover_init accepts it too) */
 };
 
 /* Flattened ListOfProductsOfPolynomials (reference src/ml_sumcheck/data_structures.rs:25-35):
@@ -84,6 +85,16 @@ SC_API int sc_set_device(int ordinal);      /* device used by handles created af
 
 /* ---- IPForMLSumcheck::prover_init / prove_round (prover.rs:49-153) ------------------------- */
 SC_API int sc_prover_init(const sc_poly_desc *desc, sc_prover **out);
+/* Out-of-core tables: the tables stay in HOST memory (pinned memory streams fastest; they are only read and must
+ * stay valid until the second round has returned) and are never resident as a whole.  Rounds 1 and 2 pull them through a two-slot
+ * staging ring, 2^chunk_log2 entries of every table at a time (0 = 2^22; clamped to [2^10, 2^num_vars]), the copy of one chunk
+ * overlapping the kernels of the previous one; from round 2 on the bound tables -- half the input -- are resident and everything
+ * proceeds as usual.  HBM footprint: 0.84 x the tables (bound-table buffers) + 2 x U x 2^chunk_log2 x 32 bytes, instead of 2.7 x.
+ * The input crosses PCIe twice (rounds 1 and 2 both need it and the challenge between them comes from the verifier).
+ * Needs the merged big-round kernel: at most 12 products of at most 4 multiplicands (SC_ERR_BAD_ARG otherwise); below 2^11 entries
+ * per table the handle silently copies instead.  Every other call (sc_prove_round, sc_ml_prove_handle, sc_prover_state,
+ * sc_prover_reset with host tables or NULL) works on the handle unchanged. */
+SC_API int sc_prover_init_streamed(const sc_poly_desc *desc, uint32_t chunk_log2, sc_prover **out);
 /* r_or_null: NULL exactly on the first call, else the previous round's challenge (4 limbs).
  * out_evals: (max_multiplicands+1) x 4 limbs = [P(0), P(1), ..., P(deg)] (ProverMsg, prover.rs:13-17). */
 SC_API int sc_prove_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals);

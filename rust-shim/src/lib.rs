@@ -78,6 +78,7 @@ extern "C" {
     pub fn sc_last_error() -> *const c_char;
     pub fn sc_set_device(ordinal: c_int) -> c_int;
     pub fn sc_prover_init(desc: *const sc_poly_desc, out: *mut *mut sc_prover) -> c_int;
+    pub fn sc_prover_init_streamed(desc: *const sc_poly_desc, chunk_log2: u32, out: *mut *mut sc_prover) -> c_int;
     pub fn sc_prove_round(p: *mut sc_prover, r_or_null: *const u64, out_evals: *mut u64) -> c_int;
     pub fn sc_prover_push_randomness(p: *mut sc_prover, r: *const u64) -> c_int;
     pub fn sc_prover_state(p: *mut sc_prover, randomness: *mut u64, n_randomness: *mut u32, tables_out: *mut u64, round: *mut u32) -> c_int;
@@ -239,6 +240,26 @@ pub fn prover_init<F: Limbs4>(polynomial: &ListOfProductsOfPolynomials<F>) -> Hi
         num_vars: polynomial.num_variables,
         max_multiplicands: polynomial.max_multiplicands,
     }
+}
+
+/// Out-of-core `prover_init` (`sc_prover_init_streamed`): the tables of `polynomial` are NOT copied to HBM as a whole; rounds 1 and 2 stream
+/// them from host memory in chunks of `2^chunk_log2` entries (0 = default).  The borrow of `polynomial` makes the compiler hold the
+/// tables alive and unchanged for as long as the state exists, which covers the two rounds that read them.
+pub fn prover_init_streamed<'a, F: Limbs4>(polynomial: &'a ListOfProductsOfPolynomials<F>, chunk_log2: u32) -> (HipProverState<F>, core::marker::PhantomData<&'a ()>) {
+    let flat = flatten(polynomial);
+    let desc = flat.desc(polynomial.num_variables, polynomial.max_multiplicands, 0);
+    let mut handle = core::ptr::null_mut();
+    check(unsafe { sc_prover_init_streamed(&desc, chunk_log2, &mut handle) });
+    (
+        HipProverState {
+            handle,
+            list_of_products: polynomial.products.clone(),
+            n_tables: polynomial.flattened_ml_extensions.len(),
+            num_vars: polynomial.num_variables,
+            max_multiplicands: polynomial.max_multiplicands,
+        },
+        core::marker::PhantomData,
+    )
 }
 
 /// `IPForMLSumcheck::prove_round` (reference `prover.rs:74-153`), same signature: `&Option<VerifierMsg<F>>` in, `ProverMsg<F>` out.

@@ -30,6 +30,7 @@ SC_ERR_REJECT = 8
 
 SC_TABLES_ON_DEVICE = 1
 SC_TABLES_BORROW = 2
+SC_TABLES_STREAM = 4
 
 
 class PolyDesc(C.Structure):
@@ -54,6 +55,7 @@ SIGNATURES = {
     "sc_device_count": (C.c_int, []),
     "sc_set_device": (C.c_int, [C.c_int]),
     "sc_prover_init": (C.c_int, [C.POINTER(PolyDesc), C.POINTER(_V)]),
+    "sc_prover_init_streamed": (C.c_int, [C.POINTER(PolyDesc), C.c_uint32, C.POINTER(_V)]),
     "sc_prove_round": (C.c_int, [_V, _V, _V]),
     "sc_prover_push_randomness": (C.c_int, [_V, _V]),
     "sc_prover_state": (C.c_int, [_V, _V, u32p, _V, u32p]),

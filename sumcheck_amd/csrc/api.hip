@@ -187,6 +187,16 @@ struct sc_prover {
     // tests/test_gpu_variants.py) lets the environment select the cross-check kernels instead.
     bool use_fe = true;     // experiments: SC_FE=0 selects the saturated (Comba asm) kernels
     int kernel_variant = 3; // experiments: SC_KERNEL 0 = node by node (k_prod_round[_fe]), 2 = tiled LDS-staged (k_round_tile), 3 = product tree
+    // streamed tables (SC_TABLES_STREAM): the inputs stay in HOST memory; rounds 1 and 2 pull them through a two-slot staging ring in
+    // chunks, so HBM only ever holds the bound tables (from round 2 on everything is resident and the ordinary path continues)
+    bool streamed = false;
+    uint32_t stream_chunk_request = 0;    // sc_prover_init_streamed's chunk_log2 (0: default)
+    uint32_t chunk_log2 = 0;              // entries of every table per chunk
+    std::vector<const uint64_t *> host_tabs;
+    void *ring[2] = {nullptr, nullptr};   // U x 2^chunk_log2 x 32 bytes each
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+    FrHost *d_chunk_msg = nullptr;        // a chunk's message, and the running sum over the chunks (2 x D elements)
     // reset support + per-product instrumentation
     bool borrow = false;
     std::vector<const uint4 *> origin; // borrowed table pointers (borrow mode)
@@ -217,6 +227,13 @@ static void prover_destroy(sc_prover *p) {
     if (p->d_out) (void)hipFree(p->d_out);
     if (p->h_out) (void)hipHostFree(p->h_out);
     if (p->h_flag) (void)hipHostFree(p->h_flag);
+    for (int q = 0; q < 2; ++q) {
+        if (p->ring[q]) (void)hipFree(p->ring[q]);
+        if (p->ev_copied[q]) (void)hipEventDestroy(p->ev_copied[q]);
+        if (p->ev_consumed[q]) (void)hipEventDestroy(p->ev_consumed[q]);
+    }
+    if (p->d_chunk_msg) (void)hipFree(p->d_chunk_msg);
+    if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     if (p->tail) prover_destroy(p->tail);
     if (p->d_tail_send) (void)hipFree(p->d_tail_send);
     if (p->d_tail_recv) (void)hipFree(p->d_tail_recv);
@@ -394,8 +411,13 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     const bool on_device = d->flags & SC_TABLES_ON_DEVICE;
     const bool borrow = on_device && (d->flags & SC_TABLES_BORROW);
     const uint64_t n = 1ULL << p->nv;
-    const uint64_t s0 = borrow ? std::max<uint64_t>(n >> 1, 1) : n;
-    const uint64_t s1 = borrow ? std::max<uint64_t>(n >> 2, 1) : std::max<uint64_t>(n >> 1, 1);
+    // streamed: only where it can matter (>= 2^11 entries) and where the merged big-round kernel applies (it is what walks the chunks)
+    const bool streamed = !on_device && (d->flags & SC_TABLES_STREAM) && p->nv >= 11;
+    if (streamed && !(p->merge_rounds && !p->any_generic))
+        return fail(SC_ERR_BAD_ARG, "streamed tables need at most %d products of at most 4 multiplicands", scd::kMaxRoundProds);
+    const bool small_foot = borrow || streamed; // the caller's tables are only read: the handle holds the bound tables alone
+    const uint64_t s0 = small_foot ? std::max<uint64_t>(n >> 1, 1) : n;
+    const uint64_t s1 = small_foot ? std::max<uint64_t>(n >> 2, 1) : std::max<uint64_t>(n >> 1, 1);
     const uint64_t per_table = (s0 + s1) * 36; // 32 B main + 4 B limb-8 array per element (internal F29 format)
     HIP_TRY(hipMalloc(&p->arena, per_table * p->U));
     p->tabs.resize(p->U);
@@ -410,17 +432,35 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
         t.buf[1] = reinterpret_cast<uint4 *>(base + s0 * 32);
         t.buf_top[0] = reinterpret_cast<int32_t *>(base + (s0 + s1) * 32);
         t.buf_top[1] = t.buf_top[0] + s0;
-        if (borrow) {
+        if (streamed) {
+            t.cur = nullptr; // nothing resident before round 2
+            t.next = 0;
+            p->host_tabs.push_back(d->tables[u]);
+        } else if (borrow) {
             t.cur = reinterpret_cast<const uint4 *>(d->tables[u]);
             t.next = 0;
             p->origin.push_back(t.cur);
         } else {
+            if (!on_device && (d->flags & SC_TABLES_STREAM)) p->host_tabs.push_back(d->tables[u]); // too small to stream: copied, but rewound like a streamed handle
             HIP_TRY(hipMemcpyAsync(t.buf[0], d->tables[u], n * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, p->stream));
             t.cur = t.buf[0];
             t.next = 1;
         }
     }
 
+    if (streamed) {
+        p->streamed = true;
+        uint32_t cl = p->stream_chunk_request ? p->stream_chunk_request : 22u; // 2^22 entries = 128 MiB per table and chunk
+        cl = std::max(10u, std::min(cl, p->nv));                               // >= 2^10: the chunk-planar F29 blocks of the bound half stay aligned
+        p->chunk_log2 = cl;
+        for (int q = 0; q < 2; ++q) {
+            HIP_TRY(hipMalloc(&p->ring[q], ((size_t)p->U << cl) * 32));
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_copied[q], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_consumed[q], hipEventDisableTiming));
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc(&p->d_chunk_msg, (size_t)2 * p->D * 32));
+    }
     HIP_TRY(hipMalloc(&p->d_partials, std::max<uint64_t>(partial_elems, 1) * 32));
     HIP_TRY(hipMalloc(&p->d_partials2, std::max<uint64_t>(partial_elems, 1) * 32)); // second level of the in-kernel finalize (k_round_tree)
     HIP_TRY(hipMalloc(&p->d_fin_counters, 4 * (2 + scd::kMaxGrid / 32)));
@@ -469,6 +509,26 @@ extern "C" int sc_prover_init(const sc_poly_desc *desc, sc_prover **out) {
     sc_prover *p = new (std::nothrow) sc_prover();
     if (!p) return fail(SC_ERR_OOM, "host allocation failed");
     rc = prover_build(desc, p);
+    if (rc) {
+        prover_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return SC_OK;
+}
+
+extern "C" int sc_prover_init_streamed(const sc_poly_desc *desc, uint32_t chunk_log2, sc_prover **out) {
+    if (!out) return fail(SC_ERR_BAD_ARG, "null out");
+    *out = nullptr;
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    if (desc->flags & SC_TABLES_ON_DEVICE) return fail(SC_ERR_BAD_ARG, "streamed tables are host tables");
+    sc_prover *p = new (std::nothrow) sc_prover();
+    if (!p) return fail(SC_ERR_OOM, "host allocation failed");
+    p->stream_chunk_request = chunk_log2;
+    sc_poly_desc d2 = *desc;
+    d2.flags |= SC_TABLES_STREAM;
+    rc = prover_build(&d2, p);
     if (rc) {
         prover_destroy(p);
         return rc;
@@ -586,6 +646,7 @@ static bool ensure_mailbox(sc_prover *p) {
 // Pipelined late rounds.  can_defer_next: the NEXT round is a latency-bound one and the mailbox machinery is available.
 static bool can_defer_next(sc_prover *p) {
     if (!p->pipeline_ok || p->exhausted || p->round == 0 || p->round >= p->nv) return false;
+    if (p->streamed && p->round < 2) return false; // round 2 of a streamed handle walks the host tables chunk by chunk
     const uint64_t n_pairs_next = 1ULL << (p->nv - (p->round + 1));
     if (!(n_pairs_next <= small_pairs_limit() && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0)) return false;
     return ensure_mailbox(p);
@@ -611,9 +672,133 @@ static void abandon_deferred(sc_prover *p) {
     }
 }
 
+// rows (r * 2^(29 i + 58)) mod p as plain 29-bit limbs: the challenge as the tree kernels' bind takes it (fe_device.hpp, fe_mul_bind)
+static void make_bind_const(const sch::Fr &r, scd::BindConst &rc) {
+    static const std::array<sch::Fr, 9> pow2 = [] { // Montgomery form of 2^(29 i + 58)
+        std::array<sch::Fr, 9> t;
+        sch::Fr c = sch::kOne;
+        for (int d = 0; d < 58; ++d) c = sch::add(c, c);
+        for (int i = 0; i < 9; ++i) {
+            t[i] = c;
+            for (int d = 0; d < 29; ++d) c = sch::add(c, c);
+        }
+        return t;
+    }();
+    for (int i = 0; i < 9; ++i) {
+        const sch::Fr x = sch::to_canonical(sch::mul(r, pow2[i]));
+        for (int k = 0; k < 9; ++k) {
+            const int bit = 29 * k, w = bit >> 6, sh = bit & 63;
+            uint64_t v = x.l[w] >> sh;
+            if (sh > 35 && w < 3) v |= x.l[w + 1] << (64 - sh);
+            rc.R[i][k] = (int32_t)(v & 0x1fffffffULL);
+        }
+    }
+}
+
+// Rounds 1 and 2 of a handle whose tables stay in host memory (SC_TABLES_STREAM).  The round is the sum of its chunks: chunk c = entries
+// [c 2^L, (c+1) 2^L) of every table goes host -> staging slot c & 1 on the copy stream while the previous chunk computes; the merged
+// big-round kernel runs on the slot (round 1: sums only; round 2: bind + sums, the bound half-chunk written to its place in the
+// resident table), k_finalize turns the chunk's partials into a message and k_msg_accumulate adds it to the round's.  After round 2 the
+// bound tables (half the input) are resident and the ordinary path takes over.
+static int launch_round_streamed(sc_prover *p, const uint64_t *r_or_null, bool publish_to_host) {
+    if (p->exhausted) return fail(SC_ERR_NOT_ACTIVE, "Prover is not active");
+    if (r_or_null && p->round == 0) return fail(SC_ERR_FIRST_ROUND_HAS_MSG, "first round should be prover first.");
+    if (!r_or_null && p->round > 0) return fail(SC_ERR_MISSING_MSG, "verifier message is empty");
+    sch::Fr r = sch::zero();
+    if (r_or_null) {
+        std::memcpy(&r, r_or_null, 32);
+        if (sch::geq_p(r)) return fail(SC_ERR_BAD_ARG, "challenge is not a canonical field element");
+    }
+    HIP_TRY(hipSetDevice(p->device));
+    int rc_t = collect_timing(p);
+    if (rc_t) return rc_t;
+    const bool bind = r_or_null != nullptr;
+    if (bind) p->randomness.push_back(r);
+    p->round += 1;
+    scd::BindConst rc;
+    std::memset(&rc, 0, sizeof(rc));
+    if (bind) make_bind_const(r, rc);
+    const uint64_t C = 1ULL << p->chunk_log2, n = 1ULL << p->nv, n_chunks = n / C;
+    const uint64_t pairs_per_chunk = bind ? C / 4 : C / 2; // round 2 reads four entries per pair of the bound table
+    const int grid = std::min(scd::grid_for_pairs(pairs_per_chunk), scd::kRoundTreeGrid);
+    p->seq += 1;
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        const int q = (int)(c & 1);
+        if (c >= 2) HIP_TRY(hipStreamWaitEvent(p->copy_stream, p->ev_consumed[q], 0)); // the slot's previous chunk has been read
+        for (uint32_t u = 0; u < p->U; ++u)
+            HIP_TRY(hipMemcpyAsync(static_cast<char *>(p->ring[q]) + (((size_t)u << p->chunk_log2) * 32), p->host_tabs[u] + 4 * c * C, C * 32, hipMemcpyHostToDevice,
+                                   p->copy_stream));
+        HIP_TRY(hipEventRecord(p->ev_copied[q], p->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_copied[q], 0));
+        scd::RoundArgs ra;
+        std::memset(&ra, 0, sizeof(ra));
+        ra.n_prod = (int)p->K;
+        std::vector<uint8_t> bound(p->U, 0);
+        for (uint32_t k = 0; k < p->K; ++k) {
+            const Product &pr = p->prods[k];
+            scd::TreeProd &tp = ra.prod[k];
+            tp.M = pr.M;
+            tp.partial_off = pr.partial_off;
+            int f = 0;
+            for (size_t s = 0; s < pr.tables.size(); ++s) {
+                const uint32_t u = pr.tables[s];
+                Table &t = p->tabs[u];
+                for (uint32_t rep = 0; rep < pr.exps[s]; ++rep, ++f) {
+                    scd::Slot &sl = tp.slot[f];
+                    sl.exp = 1;
+                    sl.src = reinterpret_cast<const uint4 *>(static_cast<char *>(p->ring[q]) + (((size_t)u << p->chunk_log2) * 32));
+                    sl.src_top = nullptr;
+                    if (!bind) {
+                        sl.mode = 0;
+                    } else if (!bound[u]) { // this chunk's half of the bound table, in place (F29 blocks of 128 entries stay aligned: C / 2 >= 512)
+                        sl.mode = 1;
+                        sl.dst = t.buf[0] + 2 * (c * (C / 2));
+                        sl.dst_top = p->use_f29 ? t.buf_top[0] + c * (C / 2) : nullptr;
+                        bound[u] = 1;
+                    } else {
+                        sl.mode = 3;
+                        sl.dst_top = p->use_f29 ? t.buf_top[0] : nullptr;
+                    }
+                }
+            }
+        }
+        HIP_TRY(scd::launch_round_tree(ra, rc, pairs_per_chunk, p->d_partials, grid, p->stream));
+        if (bind) { // tables no product refers to still follow the state machine
+            for (uint32_t u = 0; u < p->U; ++u)
+                if (!bound[u])
+                    HIP_TRY(scd::launch_fix(reinterpret_cast<const uint4 *>(static_cast<char *>(p->ring[q]) + (((size_t)u << p->chunk_log2) * 32)),
+                                            p->tabs[u].buf[0] + 2 * (c * (C / 2)), to_dev(r), C / 2, p->stream));
+        }
+        HIP_TRY(scd::launch_finalize(p->d_finprods, p->h_finprods.empty() ? nullptr : p->h_finprods.data(), p->d_W, (int)p->K, (int)p->D, grid, p->d_partials,
+                                     p->d_scratch, p->d_chunk_msg, nullptr, nullptr, nullptr, 0, 1, p->stream));
+        const bool last = c + 1 == n_chunks;
+        HIP_TRY(scd::launch_msg_accumulate(p->d_chunk_msg, p->d_chunk_msg + p->D, (int)p->D, c == 0, last, p->d_out, (last && publish_to_host) ? p->h_out_dev : nullptr,
+                                           (last && publish_to_host) ? p->h_flag_dev : nullptr, p->seq, p->stream));
+        HIP_TRY(hipEventRecord(p->ev_consumed[q], p->stream));
+    }
+    if (bind) { // everything is resident now
+        for (uint32_t u = 0; u < p->U; ++u) {
+            Table &t = p->tabs[u];
+            bool referenced = false;
+            for (const Product &pr : p->prods)
+                for (uint32_t tt : pr.tables) referenced |= tt == u;
+            t.cur = t.buf[0];
+            t.cur_top = (p->use_f29 && referenced) ? t.buf_top[0] : nullptr;
+            t.next = 1;
+        }
+    }
+    p->timed = false;
+    p->timing_pending = false;
+    return SC_OK;
+}
+
 // deferred = true (library-internal): the challenge does not exist yet.  The round is enqueued behind a wait on p->sig and its
 // bind kernel reads the challenge from the mailbox; provide_challenge() supplies it later.  Late (small) rounds only.
 static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool publish_to_host, bool deferred = false) {
+    if (p->streamed && p->round < 2 && !p->exhausted) { // the inputs are still in host memory: the round is computed chunk by chunk
+        if (d_wide || deferred) return fail(SC_ERR_BAD_ARG, "streamed tables: rounds 1 and 2 are neither sharded nor pipelined");
+        return launch_round_streamed(p, r_or_null, publish_to_host);
+    }
     // validation, same precedence as the reference's panics (prover.rs:78-98)
     if (p->exhausted) return fail(SC_ERR_NOT_ACTIVE, "Prover is not active");
     if (p->deferred_pending) return fail(SC_ERR_BAD_ARG, "a pipelined round is waiting for its challenge");
@@ -649,27 +834,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
 #endif
     scd::BindConst rc; // (only the big rounds of the tree kernels pay for it)
     std::memset(&rc, 0, sizeof(rc)); // tree kernels: rows (r * 2^(29 i + 58)) mod p as plain 29-bit limbs (fe_device.hpp, fe_mul_bind)
-    if (bind && !small_round && p->kernel_variant == 3) {
-        static const std::array<sch::Fr, 9> pow2 = [] { // Montgomery form of 2^(29 i + 58)
-            std::array<sch::Fr, 9> t;
-            sch::Fr c = sch::kOne;
-            for (int d = 0; d < 58; ++d) c = sch::add(c, c);
-            for (int i = 0; i < 9; ++i) {
-                t[i] = c;
-                for (int d = 0; d < 29; ++d) c = sch::add(c, c);
-            }
-            return t;
-        }();
-        for (int i = 0; i < 9; ++i) {
-            const sch::Fr x = sch::to_canonical(sch::mul(r, pow2[i]));
-            for (int k = 0; k < 9; ++k) {
-                const int bit = 29 * k, w = bit >> 6, sh = bit & 63;
-                uint64_t v = x.l[w] >> sh;
-                if (sh > 35 && w < 3) v |= x.l[w + 1] << (64 - sh);
-                rc.R[i][k] = (int32_t)(v & 0x1fffffffULL);
-            }
-        }
-    }
+    if (bind && !small_round && p->kernel_variant == 3) make_bind_const(r, rc);
     int grid = scd::grid_for_pairs(n_pairs);
 #ifdef SC_EXPERIMENTS
     if (tiled) grid = scd::grid_for_tiles(n_pairs);
@@ -948,6 +1113,7 @@ static bool tail_shape_ok(const sc_prover *p) {
 }
 static bool tail_possible(sc_prover *p) {
     if (!tail_shape_ok(p) || p->exhausted || p->round >= p->nv || p->deferred_pending) return false;
+    if (p->streamed && p->round < 2) return false;
     if ((1ULL << (p->nv - (p->round + 1))) > std::min<uint64_t>(small_pairs_limit(), scd::kTailMaxPairs)) return false;
     if (!ensure_mailbox(p)) return false;
     if (!p->d_tail_sync) {
@@ -1098,7 +1264,8 @@ static int run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, 
         uint32_t want_next = 0;
         bool next_enqueued = false;
         // round i+1 goes in now, behind the wait -- unless it is one the persistent tail kernel will take (it starts after round i's challenge)
-        const bool next_is_tail = tail_shape_ok(p) && p->round < p->nv && (1ULL << (p->nv - (p->round + 1))) <= scd::kTailMaxPairs;
+        const bool next_is_tail = tail_shape_ok(p) && p->round < p->nv && (1ULL << (p->nv - (p->round + 1))) <= scd::kTailMaxPairs &&
+                                  !(p->streamed && p->round < 2);
         if (i + 1 < n_rounds && !next_is_tail && can_defer_next(p)) {
             rc = launch_round(p, nullptr, nullptr, true, true);
             if (rc) return rc;
@@ -1180,6 +1347,10 @@ extern "C" int sc_prover_state(sc_prover *p, uint64_t *randomness, uint32_t *n_r
         HIP_TRY(hipSetDevice(p->device));
         const uint32_t bound = p->round > 0 ? p->round - 1 : 0;
         const uint64_t n = 1ULL << (p->nv - bound);
+        if (p->streamed && p->round < 2) { // nothing bound yet: the tables are the caller's host arrays
+            for (uint32_t u = 0; u < p->U; ++u) std::memcpy(tables_out + 4 * n * u, p->host_tabs[u], n * 32);
+            return SC_OK;
+        }
         void *tmp = nullptr; // tables in the internal F29 format are converted to the canonical reference layout first
         for (uint32_t u = 0; u < p->U; ++u) {
             const void *src = p->tabs[u].cur;
@@ -1250,7 +1421,19 @@ extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_nu
         if (rc_t) return rc_t;
     }
     const uint64_t n = 1ULL << p->nv;
-    if (p->borrow) {
+    if (p->streamed) {
+        if (flags & SC_TABLES_ON_DEVICE) return fail(SC_ERR_BAD_ARG, "streamed tables are host tables");
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        for (uint32_t u = 0; u < p->U; ++u) {
+            if (tables_or_null) {
+                if (!tables_or_null[u]) return fail(SC_ERR_BAD_ARG, "table %u is null", u);
+                p->host_tabs[u] = tables_or_null[u];
+            }
+            p->tabs[u].cur = nullptr;
+            p->tabs[u].cur_top = nullptr;
+            p->tabs[u].next = 0;
+        }
+    } else if (p->borrow) {
         for (uint32_t u = 0; u < p->U; ++u) {
             if (tables_or_null) {
                 if (!tables_or_null[u]) return fail(SC_ERR_BAD_ARG, "table %u is null", u);
@@ -1261,6 +1444,7 @@ extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_nu
             p->tabs[u].next = 0;
         }
     } else {
+        if (!tables_or_null && p->host_tabs.size() == p->U) tables_or_null = p->host_tabs.data(); // sc_prover_init_streamed below its threshold
         if (!tables_or_null) return fail(SC_ERR_BAD_ARG, "a copying handle needs the tables again to reset");
         const bool on_device = flags & SC_TABLES_ON_DEVICE;
         if (on_device) HIP_TRY(hipDeviceSynchronize()); // the producer of the new tables may still be running on another stream

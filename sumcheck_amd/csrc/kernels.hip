@@ -1602,6 +1602,32 @@ hipError_t launch_gather_to_tables(const uint4 *recv, uint4 *tabs, uint32_t G, u
     return hipGetLastError();
 }
 
+// streamed tables: a round is computed chunk by chunk; every chunk's message (D elements) is added into `acc`, the last one publishes
+__global__ void k_msg_accumulate(const uint4 *__restrict__ in, uint4 *__restrict__ acc, const int D, const int first, const int last,
+                                 uint4 *__restrict__ d_out, uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag, const uint32_t seq) {
+    const int t = threadIdx.x;
+    if (t < D) {
+        Fr a = fr_load(in + 2 * t);
+        if (!first) a = fr_add(a, fr_load(acc + 2 * t));
+        fr_store(acc + 2 * t, a);
+        if (last) {
+            if (d_out) fr_store(d_out + 2 * t, a);
+            if (h_out) fr_store(h_out + 2 * t, a);
+        }
+    }
+    if (last && h_flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+hipError_t launch_msg_accumulate(const FrHost *in, FrHost *acc, int D, bool first, bool last, FrHost *d_out, FrHost *h_out_mapped, uint32_t *h_flag_mapped,
+                                 uint32_t seq, hipStream_t stream) {
+    hipLaunchKernelGGL(k_msg_accumulate, dim3(1), dim3(64), 0, stream, (const uint4 *)in, (uint4 *)acc, D, first ? 1 : 0, last ? 1 : 0, (uint4 *)d_out,
+                       (uint4 *)h_out_mapped, h_flag_mapped, seq);
+    return hipGetLastError();
+}
+
 hipError_t launch_f29_to_sat(const uint4 *src, const int32_t *src_top, uint4 *dst, uint64_t n, hipStream_t stream) {
     hipLaunchKernelGGL(k_f29_to_sat, dim3(grid_for_pairs(n)), dim3(kBlock), 0, stream, src, src_top, dst, n);
     return hipGetLastError();

@@ -305,10 +305,17 @@ class Blake2b512Rng:
 
 class IPForMLSumcheck:
     @staticmethod
-    def prover_init(polynomial: ListOfProductsOfPolynomials, borrow: bool = False) -> ProverState:
-        """prover.rs:49-69.  `borrow=True` (device tables only) skips the deep copy."""
+    def prover_init(polynomial: ListOfProductsOfPolynomials, borrow: bool = False, streamed_chunk_log2: Optional[int] = None) -> ProverState:
+        """prover.rs:49-69.  `borrow=True` (device tables only) skips the deep copy.  `streamed_chunk_log2` (host tables only; 0 = the
+        library's default chunk): out-of-core mode -- the tables stay in host memory and are streamed through HBM in rounds 1 and 2
+        (sc_prover_init_streamed); the caller keeps them alive and unchanged until round 2 has returned."""
         d, keep = polynomial._desc(borrow)
         h = C.c_void_p()
+        if streamed_chunk_log2 is not None:
+            check(lib().sc_prover_init_streamed(C.byref(d), int(streamed_chunk_log2), C.byref(h)))
+            st = ProverState(h, polynomial)
+            st._keep = (keep, list(polynomial.flattened_ml_extensions))  # the streamed host tables must outlive round 2
+            return st
         check(lib().sc_prover_init(C.byref(d), C.byref(h)))
         del keep
         return ProverState(h, polynomial)

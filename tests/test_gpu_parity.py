@@ -575,3 +575,48 @@ def test_gkr_scratch_cache_release_and_reuse():
     assert sc.lib().sc_release_caches() == 0
     assert np.array_equal(run(10), a10) and np.array_equal(run(7), a7) and np.array_equal(run(7), a7)
     assert sc.lib().sc_release_caches() == 0
+
+
+@pytest.mark.parametrize("nv,nt,shapes,chunk", [
+    (14, 10, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10),   # config-3 shape, 16 chunks
+    (15, 5, [[2, 3, 0, 1], [1, 4, 4], [3, 2, 1], [0, 0]], 12),  # shared tables, repeated factors, 8 chunks
+    (13, 2, [[0, 1], [1]], 13),                              # one chunk
+    (18, 3, [[0, 1, 2]], 0),                                 # default chunk (clamped to the table): one chunk, big rounds after it
+    (9, 3, [[0, 1, 2]], 10),                                 # too small to stream: silently the copying handle
+])
+def test_streamed_host_tables_match_oracle(nv, nt, shapes, chunk):
+    """out-of-core mode (sc_prover_init_streamed): the tables stay in host memory and rounds 1 and 2 are computed chunk by chunk
+    through a staging ring; every round message, the bound tables after round 2 and whole Fiat-Shamir proofs (twice on the rewound
+    handle) against the oracle"""
+    tabs = [cref.synth_table(6000 + nv, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(6000 + nv, 1000, len(shapes))
+    chal = cref.synth_table(6000 + nv, 2000, nv)
+    d = H.desc_from(nv, shapes, tabs, coefs)
+    mles = [sc.DenseMultilinearExtension(nv, t) for t in tabs]
+    poly = sc.ListOfProductsOfPolynomials(nv)
+    for k, sh in enumerate(shapes):
+        poly.add_product([mles[i] for i in sh], coefs[k])
+    st = sc.IPForMLSumcheck.prover_init(poly, streamed_chunk_log2=chunk)
+    op = cref.Prover(d, threads=cref.max_threads())
+    v = None
+    for i in range(nv):
+        want = op.prove_round(None if v is None else v.randomness)
+        got = sc.IPForMLSumcheck.prove_round(st, v).evaluations
+        assert np.array_equal(got, want), f"round {i + 1}"
+        v = sc.VerifierMsg(chal[i])
+        if i in (0, 1, 2):
+            _, otabs, _ = op.state()
+            for u, t in enumerate(st.flattened_ml_extensions):
+                assert np.array_equal(t.evaluations, otabs[u]), f"table {u} after round {i + 1}"
+    want, wrand = cref.ml_prove(d, threads=cref.max_threads())
+    for _ in range(2):
+        st.reset()
+        assert np.array_equal(st.prove(sc.Blake2b512Rng.setup()), want)
+    assert np.array_equal(st.randomness, wrand)
+    for m, t in zip(mles, tabs):  # the streamed inputs are only read
+        assert np.array_equal(m.evaluations, t)
+    if nv >= 11:  # longer products than the merged big-round kernel takes are refused, not mis-computed
+        p5 = sc.ListOfProductsOfPolynomials(nv)
+        p5.add_product([mles[0]] * 5, coefs[0])
+        with pytest.raises(sc.SumcheckError, match="streamed tables need"):
+            sc.IPForMLSumcheck.prover_init(p5, streamed_chunk_log2=chunk)

@@ -87,6 +87,39 @@ def gkr(dim, reps=7):
                          "note": "latency-bound: 40 sumcheck rounds over 2^20-entry tables (about 30 us each) and a dozen short initialisation kernels"}}
 
 
+def streamed(nv, shapes, nt, reps=3):
+    """out-of-core mode: tables in PINNED host memory, streamed through HBM in rounds 1 and 2 (sc_prover_init_streamed)"""
+    host = []
+    for u in range(nt):
+        t = torch.empty((1 << nv, 4), dtype=torch.int64, device=dev)
+        _lib.check(sc.lib().sc_synth_table_device(SEED, u, 0, 1 << nv, C.c_void_p(t.data_ptr())))
+        h = torch.empty((1 << nv, 4), dtype=torch.int64, pin_memory=True)
+        h.copy_(t)
+        host.append(h)
+        del t
+    torch.cuda.empty_cache()
+    coefs = cref.synth_table(SEED, 1000, len(shapes))
+    mles = [sc.DenseMultilinearExtension(nv, h) for h in host]
+    poly = sc.ListOfProductsOfPolynomials(nv)
+    for k, sh in enumerate(shapes):
+        poly.add_product([mles[i] for i in sh], coefs[k])
+    st = sc.IPForMLSumcheck.prover_init(poly, streamed_chunk_log2=0)
+    ts = []
+    for i in range(reps + 1):
+        st.reset()
+        t0 = time.perf_counter(); st.prove(); dt = time.perf_counter() - t0
+        if i:
+            ts.append(dt)
+    U, D = nt, max(len(s) for s in shapes) + 1
+    ops = ((1 << nv) - 1) * sum(2 * len(s) * D + len(s) + D for s in shapes) + 3 * U * ((1 << nv) - 2)
+    med = float(np.median(ts))
+    return {"nv": nv, "shapes": shapes, "tables_GiB": U * (1 << nv) * 32 / 2**30, "gpu_ms_median": 1e3 * med, "field_ops_per_s": ops / med,
+            "pcie_GBps": 2 * U * (1 << nv) * 32 / med / 1e9, "note": "the input crosses PCIe twice (rounds 1 and 2); PCIe-bound"}
+
+
+if "--only-streamed" in sys.argv:
+    print(json.dumps({"streamed_nv26_3tables": streamed(26, [[0, 1, 2]], 3)}, indent=1))
+    sys.exit(0)
 if "--only-gkr" in sys.argv:  # for rocprofv3 runs of config 5 alone
     print(json.dumps({"config5_gkr": gkr(20)}, indent=1))
     sys.exit(0)
