@@ -254,10 +254,17 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
 // factor, or a table that an earlier product of the same launch stores).
 // ------------------------------------------------------------------------------------------------
 // factor F of the product at pair b: its line's two end points (lo, hi), binding / storing as the slot's mode says
-template <int F>
+// kR1: round 1 of a proof -- every factor is read from the caller's canonical table, nothing is bound (k_round1_tree)
+template <int F, bool kR1 = false>
 struct LoadFactor {
     static __device__ __forceinline__ void run(const Slot *S, const uint64_t b, const int32_t (&r)[kBindLds], Fe &lo_out, Fe &hi_out) {
         const Slot &sl = S[F];
+        if constexpr (kR1) {
+            const uint4 *p = sl.src + 4 * b;
+            lo_out = fe_from_fr(fr_load(p));
+            hi_out = fe_from_fr(fr_load(p + 2));
+            return;
+        }
         const uint32_t mode = sl.mode;
         const int32_t *stop = sl.src_top; // non-null: the source table is in the internal F29 format
         if (mode == 0) {
@@ -311,7 +318,7 @@ struct LoadFactor {
 };
 
 // one product's pass of a block over its share of the pairs: row = this block's M+1 partial sums of that product
-template <int M>
+template <int M, bool kR1 = false>
 __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBindLds], const uint64_t n_pairs, uint4 *__restrict__ row, uint32_t (*sm)[8],
                                           int32_t *lacc) {
     // The M+1 running sums live in LDS (limb-planar, one column per thread: lacc[(9 t + limb) * kBlock + tid], conflict-free and
@@ -327,16 +334,61 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
     // The live set of these shapes (at most 2 x 5 elements) fits the 168 registers of three resident blocks with 16 spills.  Four
     // multiplicands stay one pair at a time: twelve quadratic coefficients across two pairs spill 47 registers, and the scratch traffic
     // costs round 2 more (+75 us) than the shared reductions save in round 1 (-23 us) -- measured, same box.
-    if constexpr (M == 2 || M == 3) {
+    if constexpr (M == 2 || M == 3 || (M == 4 && kR1)) {
         for (; b + stride < n_pairs; b += 2 * stride, ++iter) {
             Fe P[M + 1];
             const uint64_t b2 = b + stride;
-            if constexpr (M == 2) {
+            if constexpr (M == 4) { // round 1 only: without the bind path the twelve quadratic coefficients of two pairs (nearly) fit
+                Fe a0, a1, ai, b0, b1, bi, c0, c1, ci, d0, d1, di; // a, b: pair b's two quadratics; c, d: pair b2's
+                {
+                    Fe l0, h0, l1, h1;
+                    LoadFactor<0, kR1>::run(S, b, r, l0, h0);
+                    LoadFactor<1, kR1>::run(S, b, r, l1, h1);
+                    a0 = fe_mul(l0, l1);
+                    a1 = fe_mul(h0, h1);
+                    ai = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
+                }
+                fe_pin3(a0, a1, ai);
+                {
+                    Fe l2, h2, l3, h3;
+                    LoadFactor<2, kR1>::run(S, b, r, l2, h2);
+                    LoadFactor<3, kR1>::run(S, b, r, l3, h3);
+                    b0 = fe_mul(l2, l3);
+                    b1 = fe_mul(h2, h3);
+                    bi = fe_mul(fe_sub(h2, l2), fe_sub(h3, l3));
+                }
+                fe_pin3(b0, b1, bi);
+                {
+                    Fe l0, h0, l1, h1;
+                    LoadFactor<0, kR1>::run(S, b2, r, l0, h0);
+                    LoadFactor<1, kR1>::run(S, b2, r, l1, h1);
+                    c0 = fe_mul(l0, l1);
+                    c1 = fe_mul(h0, h1);
+                    ci = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
+                }
+                fe_pin3(c0, c1, ci);
+                {
+                    Fe l2, h2, l3, h3;
+                    LoadFactor<2, kR1>::run(S, b2, r, l2, h2);
+                    LoadFactor<3, kR1>::run(S, b2, r, l3, h3);
+                    d0 = fe_mul(l2, l3);
+                    d1 = fe_mul(h2, h3);
+                    di = fe_mul(fe_sub(h2, l2), fe_sub(h3, l3));
+                }
+                P[0] = fe_mul2_sum(a0, b0, c0, d0);
+                P[1] = fe_mul2_sum(a1, b1, c1, d1);
+                P[2] = fe_mul2_sum(ai, bi, ci, di);
+                // q(-1) = 2 q(0) + 2 q(inf) - q(1), q(2) = 2 q(1) + 2 q(inf) - q(0), re-tightened for the shared reduction
+                auto qm1 = [](const Fe &q0, const Fe &q1, const Fe &qi) { return fe_carry_pass(fe_sub(fe_add(fe_add(qi, qi), fe_add(q0, q0)), q1)); };
+                auto qp2 = [](const Fe &q0, const Fe &q1, const Fe &qi) { return fe_carry_pass(fe_sub(fe_add(fe_add(qi, qi), fe_add(q1, q1)), q0)); };
+                P[3] = fe_mul2_sum(qm1(a0, a1, ai), qm1(b0, b1, bi), qm1(c0, c1, ci), qm1(d0, d1, di));
+                P[4] = fe_mul2_sum(qp2(a0, a1, ai), qp2(b0, b1, bi), qp2(c0, c1, ci), qp2(d0, d1, di));
+            } else if constexpr (M == 2) {
                 Fe l0, h0, l1, h1, m0, k0, m1, k1;
-                LoadFactor<0>::run(S, b, r, l0, h0);
-                LoadFactor<1>::run(S, b, r, l1, h1);
-                LoadFactor<0>::run(S, b2, r, m0, k0);
-                LoadFactor<1>::run(S, b2, r, m1, k1);
+                LoadFactor<0, kR1>::run(S, b, r, l0, h0);
+                LoadFactor<1, kR1>::run(S, b, r, l1, h1);
+                LoadFactor<0, kR1>::run(S, b2, r, m0, k0);
+                LoadFactor<1, kR1>::run(S, b2, r, m1, k1);
                 P[0] = fe_mul2_sum(l0, l1, m0, m1);
                 P[1] = fe_mul2_sum(h0, h1, k0, k1);
                 P[2] = fe_mul2_sum(fe_sub(h0, l0), fe_sub(h1, l1), fe_sub(k0, m0), fe_sub(k1, m1));
@@ -344,25 +396,25 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
                 Fe q0, q1, qi, l2, h2;
                 {
                     Fe l0, h0, l1, h1;
-                    LoadFactor<0>::run(S, b, r, l0, h0);
-                    LoadFactor<1>::run(S, b, r, l1, h1);
+                    LoadFactor<0, kR1>::run(S, b, r, l0, h0);
+                    LoadFactor<1, kR1>::run(S, b, r, l1, h1);
                     q0 = fe_mul(l0, l1);
                     q1 = fe_mul(h0, h1);
                     qi = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
                 }
                 fe_pin3(q0, q1, qi);
-                LoadFactor<2>::run(S, b, r, l2, h2);
+                LoadFactor<2, kR1>::run(S, b, r, l2, h2);
                 Fe s0, s1, si, m2, k2;
                 {
                     Fe l0, h0, l1, h1;
-                    LoadFactor<0>::run(S, b2, r, l0, h0);
-                    LoadFactor<1>::run(S, b2, r, l1, h1);
+                    LoadFactor<0, kR1>::run(S, b2, r, l0, h0);
+                    LoadFactor<1, kR1>::run(S, b2, r, l1, h1);
                     s0 = fe_mul(l0, l1);
                     s1 = fe_mul(h0, h1);
                     si = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
                 }
                 fe_pin3(s0, s1, si);
-                LoadFactor<2>::run(S, b2, r, m2, k2);
+                LoadFactor<2, kR1>::run(S, b2, r, m2, k2);
                 P[0] = fe_mul2_sum(l2, q0, m2, s0);
                 P[1] = fe_mul2_sum(h2, q1, k2, s1);
                 P[2] = fe_mul2_sum(fe_sub(h2, l2), qi, fe_sub(k2, m2), si);
@@ -389,11 +441,11 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
         // half-products: a0/a1/ai of factors 0,1 are formed before factors 2,3 are touched.
         Fe P[M + 1];
         if constexpr (M == 1) {
-            LoadFactor<0>::run(S, b, r, P[0], P[1]);
+            LoadFactor<0, kR1>::run(S, b, r, P[0], P[1]);
         } else if constexpr (M == 2) {
             Fe l0, h0, l1, h1;
-            LoadFactor<0>::run(S, b, r, l0, h0);
-            LoadFactor<1>::run(S, b, r, l1, h1);
+            LoadFactor<0, kR1>::run(S, b, r, l0, h0);
+            LoadFactor<1, kR1>::run(S, b, r, l1, h1);
             P[0] = fe_mul(l0, l1);
             P[1] = fe_mul(h0, h1);
             P[2] = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
@@ -401,8 +453,8 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
             Fe q0, q1, qi;
             {
                 Fe l0, h0, l1, h1;
-                LoadFactor<0>::run(S, b, r, l0, h0);
-                LoadFactor<1>::run(S, b, r, l1, h1);
+                LoadFactor<0, kR1>::run(S, b, r, l0, h0);
+                LoadFactor<1, kR1>::run(S, b, r, l1, h1);
                 q0 = fe_mul(l0, l1);
                 q1 = fe_mul(h0, h1);
                 qi = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
@@ -410,7 +462,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
             fe_pin3(q0, q1, qi);
             const Fe qm1 = fe_carry_pass(fe_sub(fe_add(fe_add(qi, qi), fe_add(q0, q0)), q1)); // q(-1) = 2 q(0) + 2 q(inf) - q(1)
             Fe l2, h2;
-            LoadFactor<2>::run(S, b, r, l2, h2);
+            LoadFactor<2, kR1>::run(S, b, r, l2, h2);
             P[0] = fe_mul(l2, q0);
             P[1] = fe_mul(h2, q1);
             P[2] = fe_mul(fe_sub(h2, l2), qi);
@@ -420,8 +472,8 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
             Fe a0, a1, ai, b0, b1, bi;
             {
                 Fe l0, h0, l1, h1;
-                LoadFactor<0>::run(S, b, r, l0, h0);
-                LoadFactor<1>::run(S, b, r, l1, h1);
+                LoadFactor<0, kR1>::run(S, b, r, l0, h0);
+                LoadFactor<1, kR1>::run(S, b, r, l1, h1);
                 a0 = fe_mul(l0, l1);
                 a1 = fe_mul(h0, h1);
                 ai = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
@@ -429,8 +481,8 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
             fe_pin3(a0, a1, ai);
             {
                 Fe l2, h2, l3, h3;
-                LoadFactor<2>::run(S, b, r, l2, h2);
-                LoadFactor<3>::run(S, b, r, l3, h3);
+                LoadFactor<2, kR1>::run(S, b, r, l2, h2);
+                LoadFactor<3, kR1>::run(S, b, r, l3, h3);
                 b0 = fe_mul(l2, l3);
                 b1 = fe_mul(h2, h3);
                 bi = fe_mul(fe_sub(h2, l2), fe_sub(h3, l3));
@@ -1004,6 +1056,27 @@ __global__ __launch_bounds__(kBlock, 3) void k_round_tree(const RoundArgs R, con
 #endif // SC_EXPERIMENTS
 }
 
+// Round 1 of a proof as its own instantiation: no bind, canonical inputs only.  Without the bind path's registers the kernel affords
+// two pairs per iteration for products of FOUR multiplicands too (five more shared reductions per two pairs).
+__global__ __launch_bounds__(kBlock, 3) void k_round1_tree(const RoundArgs R, const uint64_t n_pairs, uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    __shared__ int32_t rt[kBindLds]; // (unused: the factor loader's signature)
+    __shared__ int32_t lacc[9 * 5 * kBlock];
+    const int n = R.n_prod;
+    int k = (int)((blockIdx.x & 7u) % (uint32_t)n);
+    for (int i = 0; i < n; ++i) {
+        const TreeProd &T = R.prod[k];
+        uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x);
+        switch (T.M) {
+        case 1: tree_pass<1, true>(T.slot, rt, n_pairs, row, sm, lacc); break;
+        case 2: tree_pass<2, true>(T.slot, rt, n_pairs, row, sm, lacc); break;
+        case 3: tree_pass<3, true>(T.slot, rt, n_pairs, row, sm, lacc); break;
+        default: tree_pass<4, true>(T.slot, rt, n_pairs, row, sm, lacc); break;
+        }
+        if (++k == n) k = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The persistent tail kernel: ALL latency-bound rounds of a proof (<= kSmallRoundPairs pairs) in ONE launch.
 // Between dependent kernel launches the command processor needs ~5 us; a late round is three or four of them for a few
@@ -1449,6 +1522,13 @@ hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64
     }();
     extra_lds = env_lds;
 #endif
+    bool round1 = args.fin.enabled == 0; // every factor read in place from a canonical table: the round-1 instantiation
+    for (int q = 0; q < args.n_prod && round1; ++q)
+        for (uint32_t f = 0; f < args.prod[q].M; ++f) round1 = round1 && args.prod[q].slot[f].mode == 0 && args.prod[q].slot[f].src_top == nullptr;
+    if (round1 && extra_lds == 0) {
+        hipLaunchKernelGGL(k_round1_tree, dim3(grid), dim3(kBlock), 0, stream, args, n_pairs, (uint4 *)d_partials);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_round_tree, dim3(grid), dim3(kBlock), extra_lds, stream, args, r32, n_pairs, (uint4 *)d_partials);
     return hipGetLastError();
 }
