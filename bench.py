@@ -266,7 +266,7 @@ def main():
         dom = int(np.argmax(list(ms)))
         merged = ln[0] > 0 and all(ln[q] == 0 for q in range(1, K))
         u_dom = U if merged else len(set(shapes[dom]))
-        kname = "k_round_tree" if merged else f"k_prod_tree<{len(shapes[dom])}>"
+        kname = "k_round_tree" if merged else f"k_prod_tree<{len(shapes[dom])}>"  # (round 1 runs its own instantiation, k_round1_tree)
         big_rounds = max(nv_local - 17, 1) if nv_local > 17 else 0
         big_bytes = 32 * u_dom * ((1 << nv_local) + sum((1 << (nv_local - i + 2)) + (1 << (nv_local - i + 1)) for i in range(2, big_rounds + 1)))
         launches = int(ln[dom])
@@ -276,7 +276,7 @@ def main():
         traffic = None  # measured off-line with rocprofv3 PMC passes (tools/profile.sh), per launch of the same kernel
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")))
-            if tj.get("kernel", "").endswith(kname) and nv_local == 24 and args.config == 3:
+            if kname in tj.get("kernel", "") and nv_local == 24 and args.config == 3:
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             pass
@@ -296,7 +296,8 @@ def main():
                        "field_ops_per_step": ops, "sharding": f"high-bit x{world}" if world > 1 else "none",
                        "round_loop": round_loop},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": f"{kname} ({'all products, one launch per big round' if merged else f'product {dom}, big rounds'})",
+                         "traffic": traffic, "kernel": (f"k_round1_tree (round 1) + k_round_tree (rounds 2..{big_rounds}): all products, one launch per big round" if merged
+                                    else f"{kname} (product {dom}, big rounds)"),
                          "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "big_rounds_GBps_incl_finalize": big_rounds_gbps, "big_rounds_ms_per_step": rounds_ms.value / args.steps,
                          "whole_proof_GBps": algorithmic_bytes(nv_local, U) * args.steps / elapsed / 1e9,

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-kern = sys.argv[2] if len(sys.argv) > 2 else "k_round_tree"
+kern = sys.argv[2] if len(sys.argv) > 2 else "k_round_tree+k_round1_tree"
 base = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 out = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(base, "stats", "bench_kernel_stats.csv"), os.path.join(out, f"{tag}_rocprofv3_kernel_stats.csv"))
@@ -23,8 +23,11 @@ for name, f in (("FETCH_SIZE", "pmc_fetch/bench_counter_collection.csv"), ("WRIT
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
     counters[name] = {k: {"calls": n, "sum_KB": v, "per_call_KB": v / n} for k, (n, v) in agg.items()}
-key = next(k for k in counters["FETCH_SIZE"] if kern in k)
-f, w = counters["FETCH_SIZE"][key], counters["WRITE_SIZE"][key]
+# the merged big-round launch is two kernels: k_round1_tree (round 1) and k_round_tree (rounds 2..7): both count
+keys = [k for k in counters["FETCH_SIZE"] if any(x in k for x in kern.split("+"))]
+key = " + ".join(keys)
+f = {"calls": sum(counters["FETCH_SIZE"][k]["calls"] for k in keys), "sum_KB": sum(counters["FETCH_SIZE"][k]["sum_KB"] for k in keys)}
+w = {"calls": sum(counters["WRITE_SIZE"][k]["calls"] for k in keys), "sum_KB": sum(counters["WRITE_SIZE"][k]["sum_KB"] for k in keys)}
 summary = {
     "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --output-format csv) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
     "corrections": "FETCH_SIZE x2 (MI355X_MICROARCH.md: gfx950 counts 64 B per 128-B request for 16 B/lane coalesced reads; checked on the "
