@@ -1,4 +1,4 @@
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -4
+timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/r2_gputest.txt 2>&1; grep -E "passed|failed" gpurun_out/r2_gputest.txt
 timeout 600 python bench.py 2>/dev/null | tail -1 > gpurun_out/r2c_bench_line.json; cut -c1-200 gpurun_out/r2c_bench_line.json
 bash tools/profile.sh r2c 2>&1 | tail -3
 timeout 120 python tools/round_times.py 24 2>&1 | tail -27 > gpurun_out/r2c_round_times.txt
