@@ -168,10 +168,13 @@ SC_API void sc_rng_sample_fr(sc_rng *rng, uint64_t *out);                       
 /* ---- MLSumcheck::prove / prove_as_subprotocol (reference src/ml_sumcheck/mod.rs:42-70) ------- */
 /* rng_or_null: NULL = fresh Blake2b512Rng::setup() (MLSumcheck::prove).  out_proof: num_vars x (deg+1) x 4.
  * out_state_or_null: receives the ProverState handle (caller frees) as prove_as_subprotocol returns it.
- * The latency-bound late rounds are pipelined: the next round is enqueued behind a wait kernel before the current
- * round's message is hashed.  The wait is bounded (seconds); if the calling thread is stalled for longer, the call
- * returns SC_ERR_HIP ("... the proof is void") rather than messages computed on a stale challenge -- reset the
- * handle and prove again.  SC_PIPELINE=0 in the environment turns the pipelining off. */
+ * The latency-bound late rounds do not go back to the host for their launches: rounds with more than 2048 pairs are pipelined (the
+ * next round is enqueued behind a wait kernel before the current round's message is hashed), the last rounds (<= 2048 pairs) run in
+ * ONE persistent kernel that publishes every message into host-mapped memory and polls a host-mapped mailbox for the challenge;
+ * the calling thread only hashes and answers.  Every device-side wait is bounded (seconds); if the calling thread is stalled for
+ * longer, the call returns SC_ERR_HIP ("... the proof is void") rather than messages computed on a stale challenge -- reset the
+ * handle and prove again.  SC_PIPELINE=0 in the environment (or a runtime that serialises kernel launches, e.g. a counter-collecting
+ * profiler, detected by a probe) turns all of it off: every round is then launched after its challenge is known. */
 SC_API int sc_ml_prove(const sc_poly_desc *desc, sc_rng *rng_or_null, uint64_t *out_proof, sc_prover **out_state_or_null);
 /* n_rounds x (prove_round, feed, sample) of that loop (mod.rs:57-64) on a handle at round 0, continuing `rng` without feeding
  * PolynomialInfo: the last log2 G rounds of a sharded proof, on the gathered G-entry tables.  out_randomness: n_rounds x 4. */
