@@ -22,8 +22,10 @@
  * tables are read by kernels on the handle's stream: the caller must have synchronised their producer before the first round.  A handle owns its device memory until
  * sc_prover_free.  Outputs go to caller-owned host buffers unless the parameter says "device".
  *
- * THREADING.  One handle = one host thread at a time.  Distinct handles are independent.  Calls are
- * synchronous (return after the result is on the host) unless named *_async / *_partial.
+ * THREADING.  One handle = one host thread at a time.  Distinct handles are independent and may be used from different threads
+ * concurrently, on one GPU or several; the library serialises its own HIP calls per device (a pipelined round must never find
+ * the launch that follows its wait kernel blocked behind another thread's call), so threads sharing a GPU take turns at the
+ * granularity of one round.  Calls are synchronous (return after the result is on the host) unless named *_async / *_partial.
  *
  * ERRORS.  Nothing aborts across the ABI.  The four misuse panics of the reference map to status codes
  * (the shim turns them back into the same panic! messages); sc_last_error() gives detail.
@@ -172,8 +174,9 @@ SC_API void sc_rng_sample_fr(sc_rng *rng, uint64_t *out);                       
  * next round is enqueued behind a wait kernel before the current round's message is hashed), the last rounds (<= 2048 pairs) run in
  * ONE persistent kernel that publishes every message into host-mapped memory and polls a host-mapped mailbox for the challenge;
  * the calling thread only hashes and answers.  Every device-side wait is bounded (seconds); if the calling thread is stalled for
- * longer, the call returns SC_ERR_HIP ("... the proof is void") rather than messages computed on a stale challenge -- reset the
- * handle and prove again.  SC_PIPELINE=0 in the environment (or a runtime that serialises kernel launches, e.g. a counter-collecting
+ * longer, messages computed on a stale challenge are never returned: a handle whose inputs are still there (borrowed or streamed
+ * tables) proves again from round 0 with synchronous rounds inside the same call; otherwise the call returns SC_ERR_HIP ("... the
+ * proof is void") -- reset the handle with its tables and prove again.  SC_PIPELINE=0 in the environment (or a runtime that serialises kernel launches, e.g. a counter-collecting
  * profiler, detected by a probe) turns all of it off: every round is then launched after its challenge is known. */
 SC_API int sc_ml_prove(const sc_poly_desc *desc, sc_rng *rng_or_null, uint64_t *out_proof, sc_prover **out_state_or_null);
 /* n_rounds x (prove_round, feed, sample) of that loop (mod.rs:57-64) on a handle at round 0, continuing `rng` without feeding

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,47 @@ using scd::TablePtrs;
 // ---------------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 static thread_local int g_device = 0;
+
+// The device gate.  Pipelined rounds leave a kernel in the stream that waits for THIS thread's answer; while it waits, a HIP call of
+// this thread must not block.  Measured: with a second thread of the process making HIP calls on the same device, a kernel launch
+// behind the waiting kernel did block -- until the wait's bound expired, seconds later (profiles/r2c_concurrency_note.txt).  So the
+// library's HIP calls on one device are serialised across threads by a recursive mutex, and a pipelined round holds it from the
+// launch of its wait kernel until the challenge has been handed over (~ one round, tens of microseconds); everything else holds
+// it only for the duration of its own calls.  (HIP calls made by OTHER code of the process on the same device during such a window
+// can still delay a proof; the waits are bounded and the library then reports a void proof instead of a wrong one.)
+// (A host transport's collective blocks until every rank has called it, and ranks may be threads that share the device: the gate is
+// let go around those calls -- GateYield -- which is safe because such a communicator never has a pipelined round in flight.)
+static std::recursive_mutex g_gate_mutex[64];
+static thread_local uint16_t g_gate_depth[64];
+static void gate_lock(int device) {
+    g_gate_mutex[(unsigned)device & 63u].lock();
+    ++g_gate_depth[(unsigned)device & 63u];
+}
+static void gate_unlock(int device) {
+    --g_gate_depth[(unsigned)device & 63u];
+    g_gate_mutex[(unsigned)device & 63u].unlock();
+}
+struct DeviceGate {
+    const int device;
+    explicit DeviceGate(int d) : device(d) { gate_lock(device); }
+    ~DeviceGate() { gate_unlock(device); }
+    DeviceGate(const DeviceGate &) = delete;
+    DeviceGate &operator=(const DeviceGate &) = delete;
+};
+struct GateYield { // drop every level this thread holds, take them back on scope exit
+    const int device;
+    uint16_t depth;
+    GateYield(int d, bool enable) : device(d), depth(enable ? g_gate_depth[(unsigned)d & 63u] : 0) {
+        for (uint16_t i = 0; i < depth; ++i) gate_unlock(device);
+    }
+    ~GateYield() {
+        for (uint16_t i = 0; i < depth; ++i) gate_lock(device);
+    }
+    GateYield(const GateYield &) = delete;
+    GateYield &operator=(const GateYield &) = delete;
+};
+void sc_internal_gate_lock(int device) { gate_lock(device); } // gkr.hip
+void sc_internal_gate_unlock(int device) { gate_unlock(device); }
 
 static int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -177,6 +219,7 @@ struct sc_prover {
     FrHost *d_mail = nullptr;       // device-memory copy of the slot in use (two slots), filled by the wait kernel
     uint32_t *d_tail_sync = nullptr; // persistent tail kernel: 4 sync words + 2 challenge slots (device)
     int tail_max_blocks = 0;        // blocks of it the device holds at once (its grid never exceeds that)
+    uint32_t n_retries = 0;         // proofs repeated after an expired device-side wait (sc_ml_prove_handle)
     bool pipeline_ok = true;        // cleared when the wait-value path is unavailable (or SC_PIPELINE=0)
     bool deferred_pending = false;  // a round is enqueued behind the wait and still needs its challenge
     bool fused_finalize = false;    // experiments, SC_FUSED_FIN=1: the merged big-round launch finalizes in-kernel (measured: slower than the k_finalize launch)
@@ -211,6 +254,7 @@ struct sc_prover {
 
 static void prover_destroy(sc_prover *p) {
     if (!p) return;
+    DeviceGate gate_(p->device);
     (void)hipSetDevice(p->device);
     if (p->deferred_pending && p->sig) { // release a stream that still waits for a challenge before synchronising it
         __atomic_store_n(p->sig, p->sig_seq, __ATOMIC_RELEASE);
@@ -315,6 +359,7 @@ static void build_node_matrix(uint32_t M, uint32_t D, const sch::Fr &scale, std:
 }
 
 static int prover_build(const sc_poly_desc *d, sc_prover *p) {
+    DeviceGate gate_(g_device);
     if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
     p->device = g_device;
     HIP_TRY(hipSetDevice(p->device));
@@ -539,6 +584,7 @@ extern "C" int sc_prover_init_streamed(const sc_poly_desc *desc, uint32_t chunk_
 
 extern "C" int sc_prover_set_stream(sc_prover *p, void *hip_stream, int use_own) {
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    DeviceGate gate_(p->device);
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     p->stream = use_own ? p->own_stream : static_cast<hipStream_t>(hip_stream); // NULL = the legacy default stream
@@ -664,6 +710,7 @@ static void provide_challenge(sc_prover *p, const sch::Fr &r) {
 static bool wait_gave_up(sc_prover *p) { return p->sig && __atomic_load_n(p->sig + 1, __ATOMIC_ACQUIRE) != 0; }
 // error path: let a stream that is blocked on the wait drain (the round then runs on a stale challenge; its result is discarded)
 static void abandon_deferred(sc_prover *p) {
+    DeviceGate gate_(p->device);
     if (p->deferred_pending) {
         __atomic_store_n(p->sig, p->sig_seq, __ATOMIC_RELEASE);
         p->deferred_pending = false;
@@ -794,7 +841,22 @@ static int launch_round_streamed(sc_prover *p, const uint64_t *r_or_null, bool p
 
 // deferred = true (library-internal): the challenge does not exist yet.  The round is enqueued behind a wait on p->sig and its
 // bind kernel reads the challenge from the mailbox; provide_challenge() supplies it later.  Late (small) rounds only.
+// SC_HOST_TRACE: report any single HIP call of a round's launch sequence that takes longer than a millisecond (stderr)
+struct SlowCallProbe {
+    const char *what;
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    explicit SlowCallProbe(const char *w) : what(w), on(std::getenv("SC_HOST_TRACE") != nullptr) {
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    ~SlowCallProbe() {
+        if (!on) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 1.0) std::fprintf(stderr, "[sc] slow host call: %s took %.1f ms\n", what, ms);
+    }
+};
 static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool publish_to_host, bool deferred = false) {
+    DeviceGate gate(p->device);
     if (p->streamed && p->round < 2 && !p->exhausted) { // the inputs are still in host memory: the round is computed chunk by chunk
         if (d_wide || deferred) return fail(SC_ERR_BAD_ARG, "streamed tables: rounds 1 and 2 are neither sharded nor pipelined");
         return launch_round_streamed(p, r_or_null, publish_to_host);
@@ -845,7 +907,10 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     if (deferred) {
         if (!small_round) return fail(SC_ERR_BAD_ARG, "only late rounds are pipelined");
         p->sig_seq += 1;
-        HIP_TRY(scd::launch_wait_challenge(p->sig_dev, p->sig_seq, p->h_mail_dev + (p->sig_seq & 1u), p->d_mail + (p->sig_seq & 1u), p->stream));
+        {
+            SlowCallProbe pr("launch k_wait_challenge");
+            HIP_TRY(scd::launch_wait_challenge(p->sig_dev, p->sig_seq, p->h_mail_dev + (p->sig_seq & 1u), p->d_mail + (p->sig_seq & 1u), p->stream));
+        }
         r_mail = p->d_mail + (p->sig_seq & 1u);
         p->deferred_pending = true;
     }
@@ -871,7 +936,10 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
                 tp.src_top[u] = t.cur_top;
                 tp.dst[u] = t.buf[t.next];
             }
-            HIP_TRY(scd::launch_fix_multi(tp, (int)p->U, rdev, r_mail, 2 * n_pairs, p->stream));
+            {
+                SlowCallProbe pr("launch k_fix_multi");
+                HIP_TRY(scd::launch_fix_multi(tp, (int)p->U, rdev, r_mail, 2 * n_pairs, p->stream));
+            }
             for (uint32_t u = 0; u < p->U; ++u) {
                 Table &t = p->tabs[u];
                 t.cur = t.buf[t.next];
@@ -880,6 +948,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
             }
         }
         for (uint32_t u = 0; u < p->U; ++u) tp.src[u] = p->tabs[u].cur;
+        SlowCallProbe pr_sum("launch k_sum_combos");
         if (p->has_meta) HIP_TRY(scd::launch_sum_combos_meta(tp, p->meta, p->n_combos, n_pairs, p->d_partials, grid, p->stream));
         else HIP_TRY(scd::launch_sum_combos(tp, p->d_combos, p->n_combos, p->d_slot_table, p->d_slot_exp, n_pairs, p->d_partials, grid, p->stream));
         bind = false;
@@ -1051,6 +1120,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     }
     if (!finalized) {
     p->seq += 1;
+    SlowCallProbe pr_fin("launch k_finalize");
     HIP_TRY(scd::launch_finalize(p->d_finprods, p->h_finprods.empty() ? nullptr : p->h_finprods.data(), p->d_W, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide,
                                  publish_to_host ? p->h_out_dev : nullptr, publish_to_host ? p->h_flag_dev : nullptr, p->seq, scaled,
                                  p->stream));
@@ -1091,10 +1161,18 @@ static int await_round(sc_prover *p, uint64_t *out_evals, const uint32_t want) {
             abandon_deferred(p);
             return fail(SC_ERR_HIP, "round did not publish its message within 2 s");
         }
-        HIP_TRY(hipStreamSynchronize(p->stream));
+        {
+            DeviceGate gate_(p->device);
+            HIP_TRY(hipStreamSynchronize(p->stream));
+        }
         if (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) != want) return fail(SC_ERR_HIP, "round finished without publishing its message");
     }
     if (wait_gave_up(p)) { // a wait kernel's bound expired before its challenge arrived: that round ran on a stale one
+        if (std::getenv("SC_HOST_TRACE"))
+            std::fprintf(stderr, "[sc] give-up seen in await_round: marker %u, sig word %u, sig_seq %u, awaited seq %u, h_flag %u, round %u, deferred_pending %d, waited %.3f s\n",
+                         __atomic_load_n(p->sig + 1, __ATOMIC_ACQUIRE), __atomic_load_n(p->sig, __ATOMIC_ACQUIRE), p->sig_seq, want,
+                         __atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE), p->round, (int)p->deferred_pending,
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
         abandon_deferred(p);
         p->exhausted = true;
         return fail(SC_ERR_HIP, "the host took longer than the wait kernel's bound to deliver a challenge; the proof is void");
@@ -1129,6 +1207,16 @@ static bool tail_possible(sc_prover *p) {
 
 // n_rounds rounds (prove_round, feed, sample) starting at the handle's next round; r_or_null = the challenge that round binds
 static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, const sch::Fr *r_or_null, uint64_t *out_msgs, sch::Fr *out_challenges) {
+    gate_lock(p->device); // until the kernel is launched; the host loop below makes no HIP calls
+    struct Unlock {
+        const int device;
+        bool held = true;
+        void release() {
+            if (held) gate_unlock(device);
+            held = false;
+        }
+        ~Unlock() { release(); }
+    } gate{p->device};
     HIP_TRY(hipSetDevice(p->device));
     int rc_t = collect_timing(p);
     if (rc_t) return rc_t;
@@ -1171,8 +1259,9 @@ static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, co
         const uint64_t sum_blocks = ((A.first_pairs + scd::kBlock - 1) / scd::kBlock) * (uint64_t)p->n_combos;
         grid = (int)std::min<uint64_t>((uint64_t)p->tail_max_blocks, std::max(bind_blocks, sum_blocks));
     }
-    HIP_TRY(hipMemsetAsync(p->d_tail_sync, 0, kTailSyncBytes + 64, p->stream));
+    HIP_TRY(scd::launch_zero_words(p->d_tail_sync, (uint32_t)((kTailSyncBytes + 64) / 4), p->stream));
     HIP_TRY(scd::launch_tail_rounds(A, p->meta, fm, grid, p->stream));
+    gate.release();
     p->seq += n_rounds;
     p->sig_seq += n_rounds - 1;
     if (r_or_null) p->randomness.push_back(*r_or_null); // bound by the first of these rounds (prover.rs:84)
@@ -1192,9 +1281,16 @@ static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, co
                     if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) break;
                 }
             }
-            if (!seen || wait_gave_up(p))
+            if (!seen || wait_gave_up(p)) {
+                if (std::getenv("SC_HOST_TRACE")) {
+                    const uint64_t *tg = reinterpret_cast<const uint64_t *>(p->h_mail) + 16;
+                    std::fprintf(stderr, "[sc] tail failure: waiting for message %u of %u (seq %u), h_flag %u, give-up marker %u, sig0 %u, grid %d, first_pairs %llu, tags %u %u\n", j,
+                                 n_rounds, A.seq0 + j, __atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE), __atomic_load_n(p->sig + 1, __ATOMIC_ACQUIRE), A.sig0, grid,
+                                 (unsigned long long)A.first_pairs, (uint32_t)tg[0], (uint32_t)tg[8]);
+                }
                 rc = fail(SC_ERR_HIP, wait_gave_up(p) ? "the host took longer than the wait kernel's bound to deliver a challenge; the proof is void"
                                                       : "a tail round did not publish its message within 20 s");
+            }
         }
         if (trace) {
             const auto now = std::chrono::steady_clock::now();
@@ -1220,6 +1316,7 @@ static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, co
         }
     }
     if (rc != SC_OK) {
+        DeviceGate g2(p->device);
         (void)hipStreamSynchronize(p->stream);
         p->exhausted = true; // tables are no longer meaningful: the handle must be reset
         return rc;
@@ -1267,20 +1364,30 @@ static int run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, 
         const bool next_is_tail = tail_shape_ok(p) && p->round < p->nv && (1ULL << (p->nv - (p->round + 1))) <= scd::kTailMaxPairs &&
                                   !(p->streamed && p->round < 2);
         if (i + 1 < n_rounds && !next_is_tail && can_defer_next(p)) {
+            gate_lock(p->device); // held until the challenge is handed over: see DeviceGate
             rc = launch_round(p, nullptr, nullptr, true, true);
-            if (rc) return rc;
+            if (rc) {
+                gate_unlock(p->device);
+                return rc;
+            }
             want_next = p->seq;
             next_enqueued = true;
         }
         const auto t1 = clk::now();
         rc = await_round(p, pm, want);
-        if (rc) return rc;
+        if (rc) {
+            if (next_enqueued) gate_unlock(p->device);
+            return rc;
+        }
         const auto t2 = clk::now();
         rng.feed_prover_msg(reinterpret_cast<const sch::Fr *>(pm), D); // mod.rs:61
         vm = rng.sample_fr();                                           // mod.rs:63
         have = true;
         if (out_challenges_or_null) out_challenges_or_null[i] = vm;
-        if (next_enqueued) provide_challenge(p, vm);
+        if (next_enqueued) {
+            provide_challenge(p, vm);
+            gate_unlock(p->device);
+        }
         enqueued = next_enqueued;
         want = want_next;
         if (t_launch) {
@@ -1301,6 +1408,7 @@ extern "C" int sc_prove_round_partial(sc_prover *p, const uint64_t *r_or_null, u
 // Bind the challenge `r` into every table once more and write the results back to back (table u at d_out + u * n * 4 limbs, n =
 // 2^(num_vars - round) entries each, canonical form whatever the tables' internal format).  After this the handle is exhausted.
 static int prover_bind_out(sc_prover *p, const uint64_t *r, uint64_t *d_out) {
+    DeviceGate gate_(p->device);
     if (p->exhausted || p->round == 0 || p->round > p->nv) return fail(SC_ERR_NOT_ACTIVE, "bind needs a prover that has run at least one round");
     sch::Fr rr;
     std::memcpy(&rr, r, 32);
@@ -1339,6 +1447,7 @@ extern "C" int sc_prover_push_randomness(sc_prover *p, const uint64_t *r) {
 
 extern "C" int sc_prover_state(sc_prover *p, uint64_t *randomness, uint32_t *n_randomness, uint64_t *tables_out, uint32_t *round) {
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    DeviceGate gate_(p->device);
     if (randomness && !p->randomness.empty()) std::memcpy(randomness, p->randomness.data(), p->randomness.size() * 32);
     if (n_randomness) *n_randomness = (uint32_t)p->randomness.size();
     if (round) *round = p->round;
@@ -1378,6 +1487,7 @@ extern "C" int sc_prover_last_round_ms(sc_prover *p, float *ms) {
 
 extern "C" int sc_prover_set_timing(sc_prover *p, int on) {
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    DeviceGate gate_(p->device);
     HIP_TRY(hipSetDevice(p->device));
     if (on && p->prod_ev.empty()) {
         p->prod_ev.resize(2 * (size_t)p->K);
@@ -1393,6 +1503,7 @@ extern "C" int sc_prover_set_timing(sc_prover *p, int on) {
 
 extern "C" int sc_prover_get_timing(sc_prover *p, double *ms_per_product, uint64_t *launches_per_product, double *rounds_ms) {
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    DeviceGate gate_(p->device);
     if (!p->timing) return fail(SC_ERR_BAD_ARG, "timing is not enabled on this handle");
     HIP_TRY(hipSetDevice(p->device));
     int rc = collect_timing(p);
@@ -1410,6 +1521,7 @@ extern "C" int sc_prover_get_timing(sc_prover *p, double *ms_per_product, uint64
 // (host pointers, or device pointers when flags has SC_TABLES_ON_DEVICE).
 extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_null, uint32_t flags) {
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    DeviceGate gate_(p->device);
     HIP_TRY(hipSetDevice(p->device));
     abandon_deferred(p);
     if (wait_gave_up(p)) {
@@ -1471,6 +1583,7 @@ extern "C" int sc_fix_variables(const uint64_t *in, uint32_t nv, const uint64_t 
     if (!in || !out || (k && !point)) return fail(SC_ERR_BAD_ARG, "null argument");
     if (k > nv || nv > 40) return fail(SC_ERR_BAD_ARG, "invalid partial point dimension"); // ark-poly's assert
     if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    DeviceGate gate_(g_device);
     HIP_TRY(hipSetDevice(g_device));
     const bool on_device = flags & SC_TABLES_ON_DEVICE;
     const uint64_t n = 1ULL << nv;
@@ -1603,6 +1716,7 @@ extern "C" int sc_poly_evaluate(const sc_poly_desc *d, const uint64_t *point, ui
         if (sch::geq_p(pt[i])) return fail(SC_ERR_BAD_ARG, "point[%u] is not a canonical field element", i);
     }
     if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    DeviceGate gate_(g_device);
     HIP_TRY(hipSetDevice(g_device));
     StreamGuard sg;
     HIP_TRY(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
@@ -1711,7 +1825,22 @@ extern "C" int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *o
     static const bool trace = std::getenv("SC_HOST_TRACE") != nullptr; // stderr: where the host's share of a proof goes
     double t_launch = 0, t_wait = 0, t_fs = 0;
     std::vector<sch::Fr> ch(p->nv);
+    const sch::Blake2b512Rng transcript_at_start = rng;
     int rc = run_rounds(p, rng, p->nv, out_proof, ch.data(), trace ? &t_launch : nullptr, &t_wait, &t_fs);
+    if (rc && wait_gave_up(p) && (p->borrow || p->streamed || p->host_tabs.size() == p->U)) {
+        // A device-side wait expired (something stalled this thread or its HIP calls for longer than the bound): the rounds after
+        // it ran on a stale challenge.  The inputs are intact, so prove again from round 0 with every round synchronous.
+        abandon_deferred(p);
+        const bool was = p->pipeline_ok;
+        if (sc_prover_reset(p, nullptr, 0) == SC_OK) {
+            if (trace) std::fprintf(stderr, "[sc] a device-side wait expired; proving again without pipelining\n");
+            p->pipeline_ok = false;
+            rng = transcript_at_start;
+            rc = run_rounds(p, rng, p->nv, out_proof, ch.data(), trace ? &t_launch : nullptr, &t_wait, &t_fs);
+            p->pipeline_ok = was;
+            ++p->n_retries;
+        }
+    }
     if (rc) {
         abandon_deferred(p);
         return rc;
@@ -1972,6 +2101,7 @@ extern "C" int sc_comm_selftest(sc_comm *c) {
         (void)hipFree(d);
         (void)hipFree(dg);
     } else if (G > 1) {
+        GateYield yield_(g_device, true);
         if (c->h_allgather(c->ctx, mine.data(), gathered.data(), (size_t)n * 8) != 0) return fail(SC_ERR_HIP, "the host transport's all-gather failed");
         if (c->h_allreduce(c->ctx, lanes.data(), (size_t)n) != 0) return fail(SC_ERR_HIP, "the host transport's all-reduce failed");
     } else {
@@ -1996,7 +2126,10 @@ int sc_internal_allreduce_lanes(sc_comm *c, uint64_t *d_lanes, size_t n_words, h
     std::vector<uint64_t> h(n_words);
     HIP_TRY(hipMemcpyAsync(h.data(), d_lanes, n_words * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (c->h_allreduce(c->ctx, h.data(), n_words) != 0) return fail(SC_ERR_HIP, "the host transport's all-reduce failed");
+    {
+        GateYield yield_(g_device, true);
+        if (c->h_allreduce(c->ctx, h.data(), n_words) != 0) return fail(SC_ERR_HIP, "the host transport's all-reduce failed");
+    }
     HIP_TRY(hipMemcpyAsync(d_lanes, h.data(), n_words * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s)); // `h` goes out of scope
     return SC_OK;
@@ -2035,6 +2168,7 @@ static int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, 
     // deferred = true the whole sequence sits behind the wait kernel (pipelined late rounds, see run_rounds): every rank's host
     // derives the same challenge at about the same time, so the ranks' all-reduces still meet.
     auto enqueue = [&](const uint64_t *r, bool deferred, uint32_t *want_out) -> int {
+        DeviceGate gate_(p->device);
         int rc = launch_round(p, r, p->d_wide, false, deferred);
         if (rc) return rc;
         if (on_stream) NCCL_TRY(g_nccl.AllReduce(p->d_wide, p->d_wide, (size_t)n_words, ncclUint64, ncclSum, comm->comm, p->stream));
@@ -2049,12 +2183,21 @@ static int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, 
         uint32_t want_next = 0;
         bool next_enqueued = false;
         if (i + 1 < n_rounds && may_defer && can_defer_next(p)) {
+            gate_lock(p->device); // held until the challenge is handed over: see DeviceGate
             if ((rc = enqueue(nullptr, true, &want_next))) {
                 abandon_deferred(p);
+                gate_unlock(p->device);
                 return rc;
             }
             next_enqueued = true;
         }
+        struct GateRelease { // every early return below leaves the window
+            const int device;
+            bool held;
+            ~GateRelease() {
+                if (held) gate_unlock(device);
+            }
+        } window{p->device, next_enqueued};
         uint64_t spins = 0;
         bool seen = false;
         const auto t_start = std::chrono::steady_clock::now();
@@ -2076,6 +2219,7 @@ static int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, 
         }
         std::vector<uint64_t> lanes(p->h_wide, p->h_wide + n_words); // (the device reuses the page for the next round)
         if (!on_stream && comm->nranks > 1) {
+            GateYield yield_(p->device, true);
             if (comm->h_allreduce(comm->ctx, lanes.data(), (size_t)n_words) != 0) {
                 abandon_deferred(p);
                 return fail(SC_ERR_HIP, "the host transport's all-reduce failed");
@@ -2094,6 +2238,7 @@ static int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, 
         if (next_enqueued) provide_challenge(p, vm);
         enqueued = next_enqueued;
         want = want_next;
+        // (`window` releases the gate here)
     }
     return SC_OK;
 }
@@ -2118,6 +2263,7 @@ static uint32_t sharded_tail_m(uint32_t nv_local, uint32_t k) { // log2 of the e
 }
 static int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, const uint64_t *last_challenge, uint32_t k, uint32_t m, uint64_t *out_proof,
                         uint64_t *out_randomness) {
+    DeviceGate gate_(p->device);
     const uint32_t G = (uint32_t)comm->nranks, U = p->U, per = 1u << m;
     const size_t send_bytes = (size_t)U * per * 32;
     if (p->tail && (p->tail->nv != k + m || p->tail_ranks != G)) { // the handle meets a communicator of another size: rebuild the tail
@@ -2142,7 +2288,10 @@ static int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, co
         std::vector<uint64_t> send(send_bytes / 8), recv(send_bytes / 8 * G);
         HIP_TRY(hipMemcpyAsync(send.data(), p->d_tail_send, send_bytes, hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
-        if (comm->h_allgather(comm->ctx, send.data(), recv.data(), send_bytes) != 0) return fail(SC_ERR_HIP, "the host transport's all-gather failed");
+        {
+            GateYield yield_(p->device, comm->nranks > 1);
+            if (comm->h_allgather(comm->ctx, send.data(), recv.data(), send_bytes) != 0) return fail(SC_ERR_HIP, "the host transport's all-gather failed");
+        }
         HIP_TRY(hipMemcpyAsync(p->d_tail_recv, recv.data(), send_bytes * G, hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream)); // `recv` goes out of scope
     }

@@ -37,6 +37,8 @@ using scd::FrU;
 using scd::kBlock;
 
 int sc_internal_fail(int code, const char *fmt, ...); // api.hip
+void sc_internal_gate_lock(int device);                // api.hip: the device gate (serialises the library's HIP calls per device)
+void sc_internal_gate_unlock(int device);
 int sc_internal_device();                             // api.hip: the calling thread's device (sc_set_device)
 int sc_internal_run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_t *out_msgs, sch::Fr *out_challenges); // api.hip
 struct sc_rng {
@@ -44,6 +46,12 @@ struct sc_rng {
 };
 
 namespace {
+
+struct GkrGate { // RAII: the calling thread's device
+    int dev;
+    GkrGate() : dev(sc_internal_device()) { sc_internal_gate_lock(dev); }
+    ~GkrGate() { sc_internal_gate_unlock(dev); }
+};
 
 struct FrAdd {
     __device__ Fr operator()(const Fr &a, const Fr &b) const { return scd::fr_add(a, b); }
@@ -500,6 +508,7 @@ extern "C" int sc_gkr_phase_one(const uint64_t *f1_idx, const uint64_t *f1_vals,
                                 const uint64_t *g, uint32_t flags, uint64_t *h_g, uint64_t *f1g_idx, uint64_t *f1g_vals, uint64_t *f1g_nnz) {
     if ((nnz && (!f1_idx || !f1_vals)) || !f3 || !g || !h_g || !f1g_nnz || (nnz && (!f1g_idx || !f1g_vals)))
         return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    GkrGate gate_;
     int rc = check_gkr_args(nnz, dim);
     if (rc) return rc;
     if ((rc = check_points(g, dim, "g"))) return rc;
@@ -546,6 +555,7 @@ extern "C" int sc_gkr_phase_one(const uint64_t *f1_idx, const uint64_t *f1_vals,
 extern "C" int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_vals, uint64_t nnz, uint32_t dim, const uint64_t *u,
                                 uint32_t flags, uint64_t *f1_gu) {
     if ((nnz && (!f1g_idx || !f1g_vals)) || !u || !f1_gu) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    GkrGate gate_;
     int rc = check_gkr_args(nnz, dim);
     if (rc) return rc;
     if ((rc = check_points(u, dim, "u"))) return rc;
@@ -605,6 +615,7 @@ extern "C" int sc_wide_reduce_table(const uint64_t *lanes, uint64_t n, uint64_t 
     if (n && (!lanes || !out)) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
     if (n == 0) return SC_OK;
     if (sc_device_count() <= 0) return sc_internal_fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    GkrGate gate_;
     G_TRY(hipSetDevice(sc_internal_device()));
     const bool dev = flags & SC_TABLES_ON_DEVICE;
     hipStream_t s = nullptr;
@@ -630,6 +641,7 @@ extern "C" int sc_gkr_phase_one_sharded(sc_comm *comm_or_null, const uint64_t *f
                                         uint64_t *f1g_idx, uint64_t *f1g_vals, uint64_t *f1g_nnz) {
     if ((nnz_local && (!f1_idx || !f1_vals)) || !f3 || !g || !f1g_nnz || (nnz_local && (!f1g_idx || !f1g_vals)) || (!h_g_or_null && !lanes_or_null))
         return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    GkrGate gate_;
     int rc = check_gkr_args(nnz_local, dim);
     if (rc) return rc;
     if ((rc = check_points(g, dim, "g"))) return rc;
@@ -677,6 +689,7 @@ extern "C" int sc_gkr_phase_one_sharded(sc_comm *comm_or_null, const uint64_t *f
 extern "C" int sc_gkr_phase_two_sharded(sc_comm *comm_or_null, const uint64_t *f1g_idx, const uint64_t *f1g_vals, uint64_t nnz_local, uint32_t dim,
                                         const uint64_t *u, uint32_t flags, uint64_t *f1_gu_or_null, uint64_t *lanes_or_null) {
     if ((nnz_local && (!f1g_idx || !f1g_vals)) || !u || (!f1_gu_or_null && !lanes_or_null)) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    GkrGate gate_;
     int rc = check_gkr_args(nnz_local, dim);
     if (rc) return rc;
     if ((rc = check_points(u, dim, "u"))) return rc;
@@ -710,6 +723,7 @@ extern "C" int sc_dense_scale(const uint64_t *in, uint64_t n, const uint64_t *sc
     if (rc) return rc;
     if (n == 0) return SC_OK;
     if (sc_device_count() <= 0) return sc_internal_fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    GkrGate gate_;
     G_TRY(hipSetDevice(sc_internal_device()));
     const bool dev = flags & SC_TABLES_ON_DEVICE;
     hipStream_t s = nullptr;
@@ -740,6 +754,7 @@ extern "C" int sc_sparse_evaluate(const uint64_t *idx, const uint64_t *vals, uin
     if (num_vars > 63) return sc_internal_fail(SC_ERR_BAD_ARG, "num_vars %u: indices are 64-bit", num_vars);
     if (nnz >= (1ULL << 32)) return sc_internal_fail(SC_ERR_BAD_ARG, "nnz too large");
     if (sc_device_count() <= 0) return sc_internal_fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    GkrGate gate_;
     G_TRY(hipSetDevice(sc_internal_device()));
     int rc;
     if ((rc = check_points(point, num_vars, "point"))) return rc;
@@ -834,6 +849,7 @@ struct ProverGuard { // declared AFTER the DevBuf it pairs with, so it is destro
 extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim, const uint64_t *f2,
                             const uint64_t *f3, const uint64_t *g, uint32_t flags, uint64_t *out_proof, uint64_t *out_uv_or_null) {
     if (!rng || (nnz && (!f1_idx || !f1_vals)) || !f2 || !f3 || !g || !out_proof) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    GkrGate gate_;
     int rc = check_gkr_args(nnz, dim);
     if (rc) return rc;
     if ((rc = check_points(g, dim, "g"))) return rc;

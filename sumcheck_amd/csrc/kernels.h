@@ -167,6 +167,7 @@ struct TailArgs {
 };
 int tail_max_resident_blocks(int device); // co-resident blocks of the tail kernel (0: unknown -> the tail kernel is not used)
 uint32_t wait_spins_default(); // bound of the device-side polls for a challenge (SC_WAIT_SPINS overrides it: tests)
+hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream); // (a plain kernel: hipMemsetAsync may take runtime paths that wait on other streams)
 hipError_t launch_tail_rounds(const TailArgs &args, const ComboMeta &meta, const FinMeta &fin, int grid, hipStream_t stream);
 
 int grid_for_pairs(uint64_t n_pairs);

@@ -1322,6 +1322,14 @@ int tail_max_resident_blocks(int device) {
     return cached;
 }
 
+__global__ void k_zero_words(uint32_t *p, const uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
+}
+hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_zero_words, dim3(4), dim3(256), 0, stream, p, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_tail_rounds(const TailArgs &args, const ComboMeta &meta, const FinMeta &fin, int grid, hipStream_t stream) {
     const size_t lds = (size_t)args.K * args.D * (args.D + 2) * 32;
     if (lds > kFinLdsMax) return hipErrorInvalidValue;

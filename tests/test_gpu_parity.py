@@ -620,3 +620,54 @@ def test_streamed_host_tables_match_oracle(nv, nt, shapes, chunk):
         p5.add_product([mles[0]] * 5, coefs[0])
         with pytest.raises(sc.SumcheckError, match="streamed tables need"):
             sc.IPForMLSumcheck.prover_init(p5, streamed_chunk_log2=chunk)
+
+
+def test_provers_on_several_threads_share_one_gpu():
+    """Three host threads, one GPU: two whole-proof provers (pipelined late rounds + persistent tail kernel) and a GKR prover,
+    each repeating its proof.  The library serialises its HIP calls per device (api.hip: DeviceGate) so that a kernel waiting
+    for one thread's challenge never sits in front of another thread's blocked call; every proof must equal the oracle's."""
+    import threading
+
+    def ml_worker(k, nv, shapes, nt, reps, out):
+        try:
+            tabs = [cref.synth_table(3100 + k, s, 1 << nv) for s in range(nt)]
+            coefs = cref.synth_table(3100 + k, 1000, len(shapes))
+            want, _ = cref.ml_prove(H.desc_from(nv, shapes, tabs, coefs), threads=4)
+            poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device="cuda:0")
+            st = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+            bad = 0
+            for _ in range(reps):
+                st.reset()
+                bad += not np.array_equal(np.asarray(st.prove()).reshape(want.shape), want)
+            out[k] = bad
+        except Exception as e:  # a give-up ("proof is void") lands here
+            out[k] = repr(e)
+
+    def gkr_worker(k, dim, reps, out):
+        try:
+            n = 1 << dim
+            rng = np.random.default_rng(77)
+            idx = np.unique(rng.integers(0, 1 << (3 * dim), size=2 * n, dtype=np.uint64))
+            vals, f2, f3, g = (cref.synth_table(3200, 1, idx.shape[0]), cref.synth_table(3200, 2, n), cref.synth_table(3200, 3, n),
+                               cref.synth_table(3200, 4, dim))
+            want, _ = cref.gkr_prove(idx, vals, dim, f2, f3, g, threads=4)
+            f1 = sc.SparseMultilinearExtension(3 * dim, idx, vals)
+            bad = 0
+            for _ in range(reps):
+                pr = sc.GKRRoundSumcheck.prove(sc.Blake2b512Rng.setup(), f1, sc.DenseMultilinearExtension(dim, f2),
+                                               sc.DenseMultilinearExtension(dim, f3), g)
+                bad += not (np.array_equal(np.stack([m.evaluations for m in pr.phase1_sumcheck_msgs]), want[0])
+                            and np.array_equal(np.stack([m.evaluations for m in pr.phase2_sumcheck_msgs]), want[1]))
+            out[k] = bad
+        except Exception as e:
+            out[k] = repr(e)
+
+    out = [None, None, None]
+    ts = [threading.Thread(target=ml_worker, args=(0, 15, [[0, 1, 2], [3]], 4, 200, out)),
+          threading.Thread(target=ml_worker, args=(1, 19, [[0, 1, 2, 3], [1, 2]], 4, 60, out)),
+          threading.Thread(target=gkr_worker, args=(2, 12, 40, out))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert out == [0, 0, 0], out

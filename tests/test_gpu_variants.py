@@ -137,3 +137,31 @@ except sc.SumcheckError as e:
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "ERROR" in r.stdout and "proof is void" in r.stdout, r.stdout + r.stderr[-500:]
+
+
+def test_wait_kernel_give_up_is_retried_when_the_inputs_survive():
+    """Same forced give-up, but on a handle that borrows its (device) tables: the inputs are intact, so sc_ml_prove_handle
+    proves again from round 0 with synchronous rounds and the caller gets the right proof (SC_HOST_TRACE reports the retry)."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sumcheck_amd as sc
+from oracle import cref
+from tests import helpers as H
+nv, shapes = 13, [[0, 1, 2], [1]]
+tabs = [cref.synth_table(8, s, 1 << nv) for s in range(3)]
+coefs = cref.synth_table(8, 1000, len(shapes))
+want, wrand = cref.ml_prove(H.desc_from(nv, shapes, tabs, coefs), threads=4)
+poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device="cuda:0")
+proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly, borrow=True)
+ok = np.array_equal(np.stack([m.evaluations for m in proof]), want) and np.array_equal(state.randomness, wrand)
+state.reset()
+ok2 = np.array_equal(np.asarray(state.prove(sc.Blake2b512Rng.setup())).reshape(want.shape), want)
+print("RETRIED-OK" if ok and ok2 else "MISMATCH")
+'''
+    env = dict(os.environ, SC_WAIT_SPINS="1", SC_PIPELINE="1", SC_HOST_TRACE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RETRIED-OK" in r.stdout, r.stdout + r.stderr[-500:]
+    assert "proving again without pipelining" in r.stderr, r.stderr[-1500:]
