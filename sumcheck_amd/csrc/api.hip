@@ -181,6 +181,7 @@ struct sc_prover {
     void *arena = nullptr;
     FrHost *d_partials = nullptr;
     FrHost *d_partials2 = nullptr;    // in-kernel finalize of the merged big-round launch: per-group partial sums ...
+    uint32_t *d_fin_mb_counter = nullptr; // (inside d_fin_counters)
     uint32_t *d_fin_counters = nullptr; // ... and its arrival counters (the kernel leaves them at zero)
     FinProd *d_finprods = nullptr;
     FrHost *d_W = nullptr; // node -> message matrices of every product (see FinProd::w_off)
@@ -508,8 +509,9 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     }
     HIP_TRY(hipMalloc(&p->d_partials, std::max<uint64_t>(partial_elems, 1) * 32));
     HIP_TRY(hipMalloc(&p->d_partials2, std::max<uint64_t>(partial_elems, 1) * 32)); // second level of the in-kernel finalize (k_round_tree)
-    HIP_TRY(hipMalloc(&p->d_fin_counters, 4 * (2 + scd::kMaxGrid / 32)));
-    HIP_TRY(hipMemsetAsync(p->d_fin_counters, 0, 4 * (2 + scd::kMaxGrid / 32), p->stream));
+    HIP_TRY(hipMalloc(&p->d_fin_counters, 4 * (2 + scd::kMaxGrid / 32 + 16)));
+    HIP_TRY(hipMemsetAsync(p->d_fin_counters, 0, 4 * (2 + scd::kMaxGrid / 32 + 16), p->stream));
+    p->d_fin_mb_counter = p->d_fin_counters + (2 + scd::kMaxGrid / 32 + 8); // k_finalize_mb's arrival counter
     HIP_TRY(hipMalloc(&p->d_finprods, std::max<size_t>(p->K, 1) * sizeof(FinProd)));
     if (p->K) HIP_TRY(hipMemcpyAsync(p->d_finprods, fin.data(), p->K * sizeof(FinProd), hipMemcpyHostToDevice, p->stream));
     p->h_finprods = fin;
@@ -690,6 +692,15 @@ static bool ensure_mailbox(sc_prover *p) {
     return false;
 }
 // Pipelined late rounds.  can_defer_next: the NEXT round is a latency-bound one and the mailbox machinery is available.
+// SC_FIN_MB=0 (experiments build): the single-block finalize
+static bool fin_mb_enabled() {
+#ifdef SC_EXPERIMENTS
+    static const bool on = !(std::getenv("SC_FIN_MB") && std::atoi(std::getenv("SC_FIN_MB")) == 0);
+    return on;
+#else
+    return true;
+#endif
+}
 static bool can_defer_next(sc_prover *p) {
     if (!p->pipeline_ok || p->exhausted || p->round == 0 || p->round >= p->nv) return false;
     if (p->streamed && p->round < 2) return false; // round 2 of a streamed handle walks the host tables chunk by chunk
@@ -817,7 +828,7 @@ static int launch_round_streamed(sc_prover *p, const uint64_t *r_or_null, bool p
                                             p->tabs[u].buf[0] + 2 * (c * (C / 2)), to_dev(r), C / 2, p->stream));
         }
         HIP_TRY(scd::launch_finalize(p->d_finprods, p->h_finprods.empty() ? nullptr : p->h_finprods.data(), p->d_W, (int)p->K, (int)p->D, grid, p->d_partials,
-                                     p->d_scratch, p->d_chunk_msg, nullptr, nullptr, nullptr, 0, 1, p->stream));
+                                     p->d_scratch, p->d_chunk_msg, nullptr, nullptr, nullptr, 0, 1, p->d_fin_mb_counter, p->stream));
         const bool last = c + 1 == n_chunks;
         HIP_TRY(scd::launch_msg_accumulate(p->d_chunk_msg, p->d_chunk_msg + p->D, (int)p->D, c == 0, last, p->d_out, (last && publish_to_host) ? p->h_out_dev : nullptr,
                                            (last && publish_to_host) ? p->h_flag_dev : nullptr, p->seq, p->stream));
@@ -1123,7 +1134,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     SlowCallProbe pr_fin("launch k_finalize");
     HIP_TRY(scd::launch_finalize(p->d_finprods, p->h_finprods.empty() ? nullptr : p->h_finprods.data(), p->d_W, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide,
                                  publish_to_host ? p->h_out_dev : nullptr, publish_to_host ? p->h_flag_dev : nullptr, p->seq, scaled,
-                                 p->stream));
+                                 fin_mb_enabled() ? p->d_fin_mb_counter : nullptr, p->stream));
     }
     if (timed) HIP_TRY(hipEventRecord(p->ev1, p->stream));
     if (!deferred) { // (a pipelined round leaves the previous round's pending event pairs to the next collect_timing)

@@ -214,7 +214,9 @@ hipError_t launch_sum_combos_meta(const TablePtrs &tp, const ComboMeta &meta, in
 // h_prods_or_null: host copy of the records; with at most kMetaProds products they travel as a kernel argument
 hipError_t launch_finalize(const FinProd *d_prods, const FinProd *h_prods_or_null, const FrHost *d_W, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
                            FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
-                           int scaled, hipStream_t stream);
+                           int scaled, uint32_t *d_counter_or_null, hipStream_t stream);
+// (d_counter_or_null: one zeroed device word owned by the caller selects the multi-block form, which needs d_scratch for K * D sums
+// and leaves the word at zero)
 hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);
 hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t n, hipStream_t stream);
 hipError_t launch_publish_words(const uint64_t *d_src, uint64_t *h_dst_mapped, int n, uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream);

@@ -848,59 +848,153 @@ __global__ __launch_bounds__(kBlock) void k_sum_combos_meta(const TablePtrs tp, 
 // One block of 1024 threads; everything here is O(K*D) field operations and latency-bound, so the intermediate vectors
 // live in LDS when they fit (kLds; K*D*(D+2) elements) and phase 1 keeps eight partial loads in flight per lane.
 // ------------------------------------------------------------------------------------------------
+#ifdef SC_FIN_CLOCKS // tools/build_variant.sh fin_clocks -DSC_FIN_CLOCKS: where k_finalize's time goes (100 MHz wall clock)
+__device__ uint64_t g_fin_clk[12];
+#define FIN_STAMP(i)                                                                                                                      \
+    do {                                                                                                                                  \
+        if (threadIdx.x == 0) g_fin_clk[i] = wall_clock64();                                                                              \
+    } while (0)
+#else
+#define FIN_STAMP(i)
+#endif
 constexpr int kFinBlock = 1024; // 16 wavefronts: one per (product, point) combination for typical shapes
 constexpr size_t kFinLdsMax = 48 * 1024;
 // the body, for a block of BLOCK threads (k_finalize: 1024; the persistent tail kernel: its own block size); `scratch` holds
 // K * D * (D + 2) elements (LDS when it fits); prod_of(k) returns the k-th FinProd
 // phase 1: S_k[t] = sum over blocks of partial_k[t][blk] -> scratch[k * D + t]
+// Everything here is load latency (the partials were written by other XCDs: every dependent load is a trip to memory), so the
+// loads of one combination are issued together and the combinations are spread over as many lanes as the block has:
+//   nblocks <= 8   eight lanes per (product, node), one partial each, three shuffle steps;
+//   otherwise      the v-th VALID (product, node) pair -- t <= M_k, enumerated without the gaps of the K x D grid, so that a
+//                  shape with 14 pairs keeps 14 of the 16 wavefronts busy once instead of 16 and then 4 -- gets W = 1, 2 or 4
+//                  wavefronts, each lane up to 12 loads in flight; the W wavefront sums meet in LDS.
 template <int BLOCK, typename ProdFn>
 __device__ __forceinline__ void finalize_sums(const ProdFn &prod_of, const int K, const int D, const int nblocks, const uint4 *__restrict__ partials,
                                               uint4 *__restrict__ scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (nblocks <= 8) { // a handful of partials per combination: one lane adds them up, no cross-lane reduction (late rounds)
-        for (int combo = threadIdx.x; combo < K * D; combo += BLOCK) {
-            const int k = combo / D, t = combo % D;
-            if (t > (int)prod_of(k).M) continue;
-            const uint4 *base = partials + 2 * (prod_of(k).partial_off + (uint64_t)t * nblocks);
-            Fr acc = fr_load(base);
-            for (int b = 1; b < nblocks; ++b) acc = fr_add(acc, fr_load(base + 2 * b));
-            fr_store(scratch + 2 * combo, acc);
+    constexpr int kWaves = BLOCK / 64;
+    if (nblocks <= 8) {
+        for (int c0 = 0; c0 < K * D; c0 += BLOCK / 8) { // (uniform trip count: every lane takes part in the shuffles)
+            const int combo = c0 + (int)(threadIdx.x >> 3), j = threadIdx.x & 7;
+            const int k = min(combo, K * D - 1) / D, t = min(combo, K * D - 1) % D;
+            const bool live = combo < K * D && t <= (int)prod_of(k).M;
+            Fr acc = fr_zero();
+            if (live && j < nblocks) acc = fr_load(partials + 2 * (prod_of(k).partial_off + (uint64_t)t * nblocks + j));
+            acc = fr_add(acc, fr_shfl_down(acc, 4));
+            acc = fr_add(acc, fr_shfl_down(acc, 2));
+            acc = fr_add(acc, fr_shfl_down(acc, 1));
+            if (live && j == 0) fr_store(scratch + 2 * combo, acc);
         }
         __syncthreads();
         return;
     }
-    // one wave per (product, node) combination, eight independent loads in flight per lane
-    for (int combo = wave; combo < K * D; combo += BLOCK / 64) {
-        const int k = combo / D, t = combo % D;
-        const int M = (int)prod_of(k).M;
-        if (t > M) continue;
-        const uint4 *base = partials + 2 * prod_of(k).partial_off;
-        Fr acc = fr_zero();
-        for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {
-            Fr x[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                // clamped address + select: the eight loads are issued back to back (a predicated load would wait for its own data)
-                const int blk = b0 + 64 * j;
-                const Fr v = fr_load(base + 2 * ((uint64_t)t * nblocks + min(blk, nblocks - 1)));
-#pragma unroll
-                for (int i = 0; i < 8; ++i) x[j].v[i] = blk < nblocks ? v.v[i] : 0u;
+    int n_valid = 0;
+    for (int k = 0; k < K; ++k) n_valid += min((int)prod_of(k).M, D - 1) + 1;
+    FIN_STAMP(6);
+    const int W = n_valid * 4 <= kWaves ? 4 : (n_valid * 2 <= kWaves ? 2 : 1);
+    __shared__ uint4 xwave[kWaves * 2];
+    for (int v0 = 0; v0 < n_valid; v0 += kWaves / W) {
+        const int v = v0 + wave / W, sub = wave % W;
+        int k = 0, t = 0;
+        bool live = v < n_valid;
+        if (live) { // v -> (k, t)
+            int rest = v;
+            for (k = 0; k < K; ++k) {
+                const int cnt = min((int)prod_of(k).M, D - 1) + 1;
+                if (rest < cnt) break;
+                rest -= cnt;
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = fr_add(x[j], x[j + 4]);
-            acc = fr_add(acc, fr_add(fr_add(x[0], x[1]), fr_add(x[2], x[3])));
+            t = rest;
         }
+        Fr acc = fr_zero();
+        if (live) {
+            const uint4 *base = partials + 2 * (prod_of(k).partial_off + (uint64_t)t * nblocks);
+            constexpr int kLoads = BLOCK >= 1024 ? 12 : 6; // (768 partials = one batch of 12 for k_finalize; the tail kernel keeps its register budget)
+            for (int b0 = sub * 64 + lane; b0 < nblocks; b0 += 64 * W * kLoads) {
+                Fr x[kLoads];
+#pragma unroll
+                for (int j = 0; j < kLoads; ++j) {
+                    // clamped address + select: the loads are issued back to back (a predicated load would wait for its own data)
+                    const int blk = b0 + 64 * W * j;
+                    const Fr ld = fr_load(base + 2 * min(blk, nblocks - 1));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[j].v[i] = blk < nblocks ? ld.v[i] : 0u;
+                }
+                if constexpr (kLoads == 12) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) x[j] = fr_add(x[j], x[j + 6]);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) x[j] = fr_add(x[j], x[j + 3]);
+                acc = fr_add(acc, fr_add(fr_add(x[0], x[1]), x[2]));
+            }
+        }
+        FIN_STAMP(7);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) acc = fr_add(acc, fr_shfl_down(acc, off));
-        if (lane == 0) fr_store(scratch + 2 * (k * D + t), acc);
+        FIN_STAMP(8);
+        if (W == 1) {
+            if (live && lane == 0) fr_store(scratch + 2 * (k * D + t), acc);
+        } else {
+            if (lane == 0) fr_store(xwave + 2 * wave, acc);
+            __syncthreads();
+            if (live && lane == 0 && sub == 0) {
+                for (int w = 1; w < W; ++w) acc = fr_add(acc, fr_load(xwave + 2 * (wave + w)));
+                fr_store(scratch + 2 * (k * D + t), acc);
+            }
+            __syncthreads(); // xwave is reused by the next pass
+        }
     }
+    FIN_STAMP(9);
     __syncthreads();
 }
-// phases 2 and 3: the node sums in scratch[k * D + t] -> the round message
+// The compact form of phases 2 and 3 (K * D <= 32 and 32 * D <= BLOCK: every shape the benchmarks use): message point t belongs to
+// the 32 lanes [32 t, 32 t + 32); lane (k, s) of them holds the single product (c_k W_k)[t][s] * S_k[s], five shuffle steps add them
+// up.  No intermediate vector, no barrier between the products and the sums; the weight can be fetched before the node sums exist
+// (fin_prefetch_weight at the top of the kernel -- or once per launch in the persistent kernel), which takes its ~1.5 us memory
+// latency off the critical path.
+template <int BLOCK>
+__device__ __forceinline__ bool fin_compact(const int K, const int D) { return K * D <= 32 && 32 * D <= BLOCK; }
+template <typename ProdFn>
+__device__ __forceinline__ Fr fin_prefetch_weight(const ProdFn &prod_of, const uint4 *__restrict__ Wm, const int K, const int D, const int scaled) {
+    const int t = threadIdx.x >> 5, slot = threadIdx.x & 31, k = slot / D, sN = slot % D;
+    if (t >= D || k >= K) return fr_zero();
+    const int M = (int)prod_of(k).M;
+    if (sN > M) return fr_zero();
+    const uint64_t woff = prod_of(k).w_off + ((scaled && M <= kMaxFusedM) ? (uint64_t)D * (M + 1) : 0);
+    return fr_load(Wm + 2 * (woff + (uint64_t)t * (M + 1) + sN));
+}
+// phases 2 and 3: the node sums in scratch[k * D + t] -> the round message.  w_pre: this thread's fin_prefetch_weight, or null
 template <int BLOCK, typename ProdFn>
 __device__ __forceinline__ void finalize_message(const ProdFn &prod_of, const uint4 *__restrict__ Wm, const int K, const int D, uint4 *__restrict__ scratch,
                                                  uint4 *__restrict__ out, uint64_t *__restrict__ out_wide, uint4 *__restrict__ h_out,
-                                                 uint32_t *__restrict__ h_flag, const uint32_t seq, const int scaled) {
+                                                 uint32_t *__restrict__ h_flag, const uint32_t seq, const int scaled, const Fr *w_pre = nullptr) {
+    if (fin_compact<BLOCK>(K, D)) {
+        if ((int)(threadIdx.x & ~63u) < 32 * D) { // whole wavefronts
+            const int t = threadIdx.x >> 5, slot = threadIdx.x & 31, k = slot / D, sN = slot % D;
+            const bool live = t < D && k < K && sN <= (int)prod_of(k).M;
+            const Fr w = w_pre ? *w_pre : fin_prefetch_weight(prod_of, Wm, K, D, scaled);
+            Fr acc = fr_zero();
+            if (live) acc = fr_mul(w, fr_load(scratch + 2 * (k * D + sN)));
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) acc = fr_add(acc, fr_shfl_down(acc, off));
+            if (slot == 0 && t < D) {
+                if (out) fr_store(out + 2 * t, acc);
+                if (h_out) fr_store(h_out + 2 * t, acc); // host-mapped pinned memory: the message lands on the host without a copy
+                if (out_wide) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) out_wide[8 * t + i] = acc.v[i];
+                }
+            }
+        }
+        FIN_STAMP(4);
+        if (h_flag) {
+            __threadfence_system();
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     // phase 2: message point t of product k = sum_s (c_k W_k)[t][s] * S_k[s].  One thread per (k, t, s) does the single
     // Montgomery product (a lone lane needs ~1 us per product, so the M+1 products of a point must not be chained) ...
     for (int idx = threadIdx.x; idx < K * D * D; idx += BLOCK) {
@@ -913,6 +1007,7 @@ __device__ __forceinline__ void finalize_message(const ProdFn &prod_of, const ui
         fr_store(scratch + 2 * ((2 * K) * D + idx), fr_mul(fr_load(Wk + 2 * sN), fr_load(scratch + 2 * (k * D + sN))));
     }
     __syncthreads();
+    FIN_STAMP(2);
     // ... and one thread per (k, t) adds them up
     for (int combo = threadIdx.x; combo < K * D; combo += BLOCK) {
         const int k = combo / D;
@@ -922,6 +1017,7 @@ __device__ __forceinline__ void finalize_message(const ProdFn &prod_of, const ui
         fr_store(scratch + 2 * ((K + k) * D + combo % D), acc);
     }
     __syncthreads();
+    FIN_STAMP(3);
     // phase 3b: sum over products
     for (int t = threadIdx.x; t < D; t += BLOCK) {
         Fr acc = fr_zero();
@@ -933,6 +1029,7 @@ __device__ __forceinline__ void finalize_message(const ProdFn &prod_of, const ui
             for (int i = 0; i < 8; ++i) out_wide[8 * t + i] = acc.v[i];
         }
     }
+    FIN_STAMP(4);
     if (h_flag) { // publish: every writer fences to system scope, then one lane raises the sequence flag
         __threadfence_system();
         __syncthreads();
@@ -945,9 +1042,12 @@ template <int BLOCK, typename ProdFn>
 __device__ __forceinline__ void finalize_body(const ProdFn &prod_of, const uint4 *__restrict__ Wm, const int K, const int D, const int nblocks,
                                               const uint4 *__restrict__ partials, uint4 *__restrict__ scratch, uint4 *__restrict__ out,
                                               uint64_t *__restrict__ out_wide, uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag, const uint32_t seq,
-                                              const int scaled) {
+                                              const int scaled, const Fr *w_pre = nullptr) {
+    FIN_STAMP(0);
     finalize_sums<BLOCK>(prod_of, K, D, nblocks, partials, scratch);
-    finalize_message<BLOCK>(prod_of, Wm, K, D, scratch, out, out_wide, h_out, h_flag, seq, scaled);
+    FIN_STAMP(1);
+    finalize_message<BLOCK>(prod_of, Wm, K, D, scratch, out, out_wide, h_out, h_flag, seq, scaled, w_pre);
+    FIN_STAMP(5);
 }
 
 template <bool kLds, bool kMeta>
@@ -964,6 +1064,72 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const FinProd *__restric
         else return prods[k];
     };
     finalize_body<kFinBlock>(prod_of, Wm, K, D, nblocks, partials, scratch, out, out_wide, h_out, h_flag, seq, scaled);
+}
+
+// The same step spread over blocks.  One block adding up 768 x 14 partials is bound by what a single CU can pull from memory
+// (344 KB: ~7 us) and by the start-up of a 1024-thread block (profiles/r2d_finalize_phases.txt), so: one 256-thread block per VALID
+// (product, node) pair adds up that pair's partials and leaves the sum in `sums`; the block that arrives last at the counter turns
+// the sums into the message.  The hand-over is a handful of 32-byte elements, so its device-scope release/acquire is cheap (unlike
+// the same protocol inside the round kernel, whose L2 is full of freshly bound table lines).  With at most eight partials per
+// pair the launch is a single block.  The counter is left at zero.
+constexpr int kFinMbBlock = 256;
+__global__ __launch_bounds__(kFinMbBlock) void k_finalize_mb(const FinMeta meta, const uint4 *__restrict__ Wm, const int K, const int D, const int nblocks,
+                                                             const uint4 *__restrict__ partials, uint4 *__restrict__ sums, uint32_t *__restrict__ counter,
+                                                             uint4 *__restrict__ out, uint64_t *__restrict__ out_wide, uint4 *__restrict__ h_out,
+                                                             uint32_t *__restrict__ h_flag, const uint32_t seq, const int scaled) {
+    extern __shared__ uint4 fin_lds[];
+    auto prod_of = [&](int k) -> FinProd { return meta.prod[k]; };
+    if (gridDim.x == 1) {
+        finalize_body<kFinMbBlock>(prod_of, Wm, K, D, nblocks, partials, fin_lds, out, out_wide, h_out, h_flag, seq, scaled);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint4 xwave[(kFinMbBlock / 64) * 2];
+    __shared__ uint32_t arrived;
+    const bool compact = fin_compact<kFinMbBlock>(K, D);
+    Fr w_pre = fr_zero();
+    if (compact) w_pre = fin_prefetch_weight(prod_of, Wm, K, D, scaled); // (every block: which one finishes the message is not known yet)
+    int k = 0, t = (int)blockIdx.x; // block v -> the v-th valid (k, t)
+    for (; k < K; ++k) {
+        const int cnt = min((int)meta.prod[k].M, D - 1) + 1;
+        if (t < cnt) break;
+        t -= cnt;
+    }
+    const uint4 *base = partials + 2 * (meta.prod[k].partial_off + (uint64_t)t * nblocks);
+    Fr acc = fr_zero();
+    constexpr int kLoads = 3; // 768 partials = one batch
+    for (int b0 = threadIdx.x; b0 < nblocks; b0 += kFinMbBlock * kLoads) {
+        Fr x[kLoads];
+#pragma unroll
+        for (int j = 0; j < kLoads; ++j) {
+            const int blk = b0 + kFinMbBlock * j;
+            const Fr ld = fr_load(base + 2 * min(blk, nblocks - 1));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[j].v[i] = blk < nblocks ? ld.v[i] : 0u;
+        }
+        acc = fr_add(acc, fr_add(fr_add(x[0], x[1]), x[2]));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc = fr_add(acc, fr_shfl_down(acc, off));
+    if (lane == 0) fr_store(xwave + 2 * wave, acc);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kFinMbBlock / 64; ++w) acc = fr_add(acc, fr_load(xwave + 2 * w));
+        fr_store(sums + 2 * (k * D + t), acc);
+        arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT); // releases the sum, acquires the others'
+    }
+    __syncthreads();
+    if (arrived + 1 != gridDim.x) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // every wavefront of the last block reads other blocks' sums
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int c = threadIdx.x; c < K * D; c += kFinMbBlock) {
+        if (c % D <= (int)meta.prod[c / D].M) {
+            fin_lds[2 * c] = sums[2 * c];
+            fin_lds[2 * c + 1] = sums[2 * c + 1];
+        }
+    }
+    __syncthreads();
+    finalize_message<kFinMbBlock>(prod_of, Wm, K, D, fin_lds, out, out_wide, h_out, h_flag, seq, scaled, compact ? &w_pre : nullptr);
 }
 
 // every product of the round in one launch (RoundArgs in kernels.h).
@@ -1146,6 +1312,13 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
     auto tab = [&](uint32_t u) -> const uint4 * { return binds == 0 ? A.t.cur0[u] : (binds & 1) ? A.t.b0[u] : A.t.b1[u]; };
     auto prod_of = [&](int k) -> FinProd { return fin.prod[k]; };
     if (threadIdx.x == 0) stop_sh = 0;
+    // block 0 writes every message: its threads keep their Lagrange weight for the whole launch (finalize_message's compact form)
+    Fr w_fin = fr_zero();
+    const Fr *w_pre = nullptr;
+    if (blockIdx.x == 0 && fin_compact<kBlock>(A.K, A.D)) {
+        w_fin = fin_prefetch_weight(prod_of, A.Wm, A.K, A.D, 0);
+        w_pre = &w_fin;
+    }
     for (int j = 0; j < A.n_rounds; ++j, n_pairs >>= 1) {
         // The rounds shrink: blocks beyond what this round can use retire for good (the count never grows again), so the barriers of
         // the later rounds synchronise a handful of blocks instead of one per CU, and the last rounds run in block 0 alone.
@@ -1230,7 +1403,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                 }
             }
             __syncthreads();
-            finalize_message<kBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 0);
+            finalize_message<kBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 0, w_pre);
         } else {
             // ---- sums: virtual blocks (vx, combo) of the k_sum_combos launch this round would have been -------------------------
             const uint32_t vgx = (uint32_t)((n_pairs + kBlock - 1) / kBlock);
@@ -1261,11 +1434,11 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                         fin_lds[2 * c2 + 1] = A.sums[2 * c2 + 1];
                     }
                     __syncthreads();
-                    finalize_message<kBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 0);
+                    finalize_message<kBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 0, w_pre);
                 }
             } else if (blockIdx.x == 0) {
                 finalize_body<kBlock>(prod_of, A.Wm, A.K, A.D, (int)vgx, A.partials, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag,
-                                      A.seq0 + (uint32_t)j, 0);
+                                      A.seq0 + (uint32_t)j, 0, w_pre);
             }
         }
         // ---- block 0: the next challenge.  The host stores, for limb i of the challenge, the 64-bit word (limb << 32 | tag) into
@@ -1607,13 +1780,19 @@ hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t 
 
 hipError_t launch_finalize(const FinProd *d_prods, const FinProd *h_prods_or_null, const FrHost *d_W, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
                            FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
-                           int scaled, hipStream_t stream) {
+                           int scaled, uint32_t *d_counter_or_null, hipStream_t stream) {
     const size_t lds = (size_t)K * D * (D + 2) * 32;
     FinMeta meta;
     std::memset(&meta, 0, sizeof(meta));
     const bool use_meta = h_prods_or_null && K <= kMetaProds;
     if (use_meta) std::memcpy(meta.prod, h_prods_or_null, (size_t)K * sizeof(FinProd));
-    if (lds <= kFinLdsMax && use_meta)
+    if (lds <= kFinLdsMax && use_meta && d_counter_or_null) {
+        int n_valid = 0;
+        for (int k = 0; k < K; ++k) n_valid += std::min<int>((int)meta.prod[k].M, D - 1) + 1;
+        hipLaunchKernelGGL(k_finalize_mb, dim3(nblocks <= 8 ? 1 : n_valid), dim3(kFinMbBlock), lds, stream, meta, (const uint4 *)d_W, K, D, nblocks,
+                           (const uint4 *)d_partials, (uint4 *)d_scratch, d_counter_or_null, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped,
+                           h_flag_mapped, seq, scaled);
+    } else if (lds <= kFinLdsMax && use_meta)
         hipLaunchKernelGGL((k_finalize<true, true>), dim3(1), dim3(kFinBlock), lds, stream, d_prods, meta, (const uint4 *)d_W, K, D, nblocks,
                            (const uint4 *)d_partials, (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq,
                            scaled);
@@ -1732,3 +1911,9 @@ hipError_t launch_bench_modmul(uint64_t n_threads, uint32_t reps, uint32_t varia
 }
 
 } // namespace scd
+
+#ifdef SC_FIN_CLOCKS
+extern "C" __attribute__((visibility("default"))) int sc_debug_fin_clocks(uint64_t *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scd::g_fin_clk), sizeof(uint64_t) * 12);
+}
+#endif
