@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <vector>
 
@@ -167,12 +168,204 @@ __global__ __launch_bounds__(kBlock) void k_scatter_dense(const uint64_t *__rest
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) fr_st(dense + key[i], fr_ld(val + i));
 }
 
-// flag |= 1 if any idx[i] has a bit at or above `bits` (index range check of device-resident inputs)
+// The two initialisations without the full sorts (used by sc_gkr_prove, which needs neither f1(g,.,.) as a list nor any order):
+//   phase one  a_hg[x]   = sum over non-zeros (z,x,y) of eq(g,z) * v * f3[y]          (mod.rs:30-38, with f1_g expanded)
+//   phase two  f1_gu[y]  = sum over non-zeros (z,x,y) of eq(g,z) * eq(u,x) * v         (mod.rs:62 + to_dense)
+// Field addition is exact, so the sums may be taken in any order and grouping.  The non-zeros are bucketed by the high bits of the
+// target cell (ONE radix pass over those bits; none for phase two when the list arrives sorted by index, the order a BTreeMap gives);
+// one workgroup per bucket of 2^c cells keeps the cells in LDS as eight uint64 lanes of 32-bit limbs each (the wide format of
+// the sharded path), adds every term with LDS integer atomics and reduces each cell mod p once at the end.  Global 64-bit atomics
+// on the dense table were measured first: 8.4 M of them take 0.4 ms on this part (profiles/r2d_gkr_init.txt), slower than sorting.
+__device__ __forceinline__ Fr wide_fold_cell(const uint64_t lane[8]) { // V = sum_j lane_j 2^(32 j) (lanes < 2^63) -> V mod p
+    Fr lo;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint64_t t = lane[j] + carry; // < 2^63 + 2^32: no wrap
+        lo.v[j] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    lo = scd::fr_reduce_once(scd::fr_reduce_once(lo)); // lo < 2^256 < 3p
+    // V = lo + carry * 2^256 and carry * 2^256 mod p = mont_mul(carry, R^2)
+    Fr hi = scd::fr_zero(), r2;
+    hi.v[0] = (uint32_t)carry;
+    hi.v[1] = (uint32_t)(carry >> 32);
+    const uint64_t R2[4] = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        r2.v[2 * q] = (uint32_t)R2[q];
+        r2.v[2 * q + 1] = (uint32_t)(R2[q] >> 32);
+    }
+    return scd::fr_add(lo, scd::fr_mul(hi, r2));
+}
+// eq(point, b) as the product of two small tables (k_eq_halves): b's low kl bits and the rest.  2 x 2^11 entries at most stay in
+// L2, where a 2^dim-entry table is a random 32-byte read from memory per non-zero.
+struct EqSplit {
+    const Fr *lo, *hi;
+    uint32_t kl;
+};
+__device__ __forceinline__ Fr eq_at(const EqSplit &e, const uint64_t b) {
+    const Fr l = fr_ld(e.lo + (b & ((1ULL << e.kl) - 1)));
+    return e.hi ? scd::fr_mul(fr_ld(e.hi + (b >> e.kl)), l) : l;
+}
+// kPhase 1: cell = x, term = eq(g,z) * v * f3[y].  kPhase 2: cell = y, term = eq(g,z) * eq(u,x) * v.
+template <int kPhase>
+__device__ __forceinline__ Fr gkr_term(const uint64_t id, const Fr &v, const uint32_t dim, const EqSplit &eg, const EqSplit &eu, const Fr *__restrict__ f3) {
+    const uint64_t mask = (1ULL << dim) - 1;
+    const Fr a = scd::fr_mul(eq_at(eg, id & mask), v);
+    if (kPhase == 1) return scd::fr_mul(a, fr_ld(f3 + (id >> (2 * dim))));
+    return scd::fr_mul(a, eq_at(eu, (id >> dim) & mask));
+}
+
+// Grouping the terms by bucket (= target cell >> c): a counting sort over the bucket bits, radix-sort style and without global
+// atomics.  Block b owns the contiguous chunk [b * chunk, (b + 1) * chunk) of the list in both sweeps.
+//   k_bucket_count    LDS histogram of the chunk -> counts[b][bucket]
+//   k_bucket_colscan  one thread per bucket: counts[.][bucket] -> exclusive prefix over the blocks, total[bucket]
+//   k_bucket_scan     one block: start[bucket] = exclusive prefix of the totals, start[nb] = n
+//   k_bucket_scatter  recomputes each non-zero's term and writes (term, cell within the bucket) behind start + prefix; the order
+//                     inside a bucket is whatever the LDS rank atomics give (the sums do not care)
+// (rocprim's radix_sort_pairs restricted to the bucket bits runs as a 21-launch merge sort at this size, 0.18 ms.)
+constexpr int kMaxBuckets = 2048, kSortBlock = 1024;
+__device__ __forceinline__ uint32_t bucket_of(const uint64_t id, const uint32_t shift, const uint32_t nb_mask) { return (uint32_t)(id >> shift) & nb_mask; }
+__global__ __launch_bounds__(kSortBlock) void k_bucket_count(const uint64_t *__restrict__ idx, const uint64_t n, const uint64_t chunk, const uint32_t shift,
+                                                             const uint32_t nb_mask, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t hist[kMaxBuckets];
+    for (uint32_t b = threadIdx.x; b <= nb_mask; b += kSortBlock) hist[b] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += kSortBlock) atomicAdd(&hist[bucket_of(idx[i], shift, nb_mask)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b <= nb_mask; b += kSortBlock) counts[(uint64_t)blockIdx.x * (nb_mask + 1) + b] = hist[b];
+}
+__global__ __launch_bounds__(kBlock) void k_bucket_colscan(uint32_t *__restrict__ counts, const uint32_t n_blocks, const uint32_t nb, uint64_t *__restrict__ total) {
+    const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= nb) return;
+    uint64_t run = 0;
+    for (uint32_t r0 = 0; r0 < n_blocks; r0 += 8) { // eight rows in flight
+        uint32_t c[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] = r0 + q < n_blocks ? counts[(uint64_t)(r0 + q) * nb + b] : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (r0 + q < n_blocks) counts[(uint64_t)(r0 + q) * nb + b] = (uint32_t)run; // (the list holds < 2^32 non-zeros)
+            run += c[q];
+        }
+    }
+    total[b] = run;
+}
+// one block of kMaxBuckets / 2 threads: start[b] = sum of total[0 .. b), start[nb] = n
+__global__ __launch_bounds__(kMaxBuckets / 2) void k_bucket_scan(const uint64_t *__restrict__ total, const uint32_t nb, uint64_t *__restrict__ start) {
+    __shared__ uint64_t part[kMaxBuckets / 2];
+    const uint32_t t = threadIdx.x;
+    const uint64_t a = 2 * t < nb ? total[2 * t] : 0, b = 2 * t + 1 < nb ? total[2 * t + 1] : 0;
+    part[t] = a + b;
+    __syncthreads();
+    for (uint32_t off = 1; off < kMaxBuckets / 2; off <<= 1) { // inclusive scan of the pair sums
+        const uint64_t add = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    const uint64_t before = part[t] - (a + b);
+    if (2 * t < nb) start[2 * t] = before;
+    if (2 * t + 1 < nb) start[2 * t + 1] = before + a;
+    if (t == kMaxBuckets / 2 - 1) start[nb] = part[t];
+}
+template <int kPhase>
+__global__ __launch_bounds__(kSortBlock) void k_bucket_scatter(const uint64_t *__restrict__ idx, const Fr *__restrict__ vals, const uint64_t n, const uint64_t chunk,
+                                                               const uint32_t dim, const uint32_t c, const EqSplit eg, const EqSplit eu,
+                                                               const Fr *__restrict__ f3, const uint32_t *__restrict__ counts,
+                                                               const uint64_t *__restrict__ start, Fr *__restrict__ out_term,
+                                                               uint16_t *__restrict__ out_cell) {
+    __shared__ uint32_t rank[kMaxBuckets];
+    __shared__ uint64_t base[kMaxBuckets];
+    const uint32_t cell_shift = kPhase == 1 ? dim : 2 * dim, nb_mask = (1u << (dim - c)) - 1;
+    for (uint32_t b = threadIdx.x; b <= nb_mask; b += kSortBlock) {
+        rank[b] = 0;
+        base[b] = start[b] + counts[(uint64_t)blockIdx.x * (nb_mask + 1) + b];
+    }
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
+        const uint64_t id = idx[i];
+        const Fr t = gkr_term<kPhase>(id, fr_ld(vals + i), dim, eg, eu, f3);
+        const uint32_t b = bucket_of(id, cell_shift + c, nb_mask);
+        const uint64_t pos = base[b] + atomicAdd(&rank[b], 1u);
+        fr_st(out_term + pos, t);
+        out_cell[pos] = (uint16_t)((id >> cell_shift) & ((1u << c) - 1));
+    }
+}
+// start offsets of a list that is already grouped (in non-decreasing bucket order): position i opens every bucket in
+// (bucket(i - 1), bucket(i)]; i = n closes the rest
+__global__ __launch_bounds__(kBlock) void k_bucket_bounds(const uint64_t *__restrict__ idx, const uint64_t n, const uint32_t shift, const uint32_t nb_mask,
+                                                          uint64_t *__restrict__ start) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i <= n; i += stride) {
+        const int64_t prev = i == 0 ? -1 : (int64_t)bucket_of(idx[i - 1], shift, nb_mask);
+        const int64_t cur = i == n ? (int64_t)nb_mask + 1 : (int64_t)bucket_of(idx[i], shift, nb_mask);
+        for (int64_t b = prev + 1; b <= cur; ++b) start[b] = i;
+    }
+}
+// One workgroup per bucket, bucket b at positions [start[b], start[b + 1]): the 2^c cells live in LDS as eight uint64 lanes each.
+// terms != null: (term, cell) pairs written by k_bucket_scatter; terms == null: the list itself is grouped (phase two on an
+// index-ordered list) and the terms are computed here.  A bucket with more than max_entries non-zeros raises *skewed and is left
+// alone (the caller falls back to the list form).
+template <int kPhase>
+__global__ __launch_bounds__(kBlock) void k_bucket_accumulate(const Fr *__restrict__ terms, const uint16_t *__restrict__ cells, const uint64_t *__restrict__ idx,
+                                                              const Fr *__restrict__ vals, const uint32_t dim, const uint32_t c, const EqSplit eg,
+                                                              const EqSplit eu, const Fr *__restrict__ f3, const uint64_t *__restrict__ start,
+                                                              const uint64_t max_entries, unsigned int *__restrict__ skewed, Fr *__restrict__ dense) {
+    extern __shared__ uint64_t cell[]; // lane-major: cell[j << c | i] (neighbouring cells in neighbouring banks)
+    const uint64_t lo = start[blockIdx.x], hi = start[blockIdx.x + 1];
+    for (uint32_t i = threadIdx.x; i < (8u << c); i += kBlock) cell[i] = 0;
+    __syncthreads();
+    if (hi - lo > max_entries) {
+        if (threadIdx.x == 0) atomicOr(skewed, 1u);
+        return;
+    }
+    const uint32_t cell_shift = kPhase == 1 ? dim : 2 * dim;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+        Fr t;
+        uint32_t ci;
+        if (terms) {
+            t = fr_ld(terms + i);
+            ci = cells[i];
+        } else {
+            const uint64_t id = idx[i];
+            t = gkr_term<kPhase>(id, fr_ld(vals + i), dim, eg, eu, f3);
+            ci = (uint32_t)((id >> cell_shift) & ((1u << c) - 1));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(reinterpret_cast<unsigned long long *>(cell + (((uint32_t)j << c) | ci)), (unsigned long long)t.v[j]);
+    }
+    __syncthreads();
+    for (uint32_t ci = threadIdx.x; ci < (1u << c); ci += kBlock) {
+        uint64_t lane[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lane[j] = cell[((uint32_t)j << c) | ci];
+        fr_st(dense + (((uint64_t)blockIdx.x << c) | ci), wide_fold_cell(lane));
+    }
+}
+
+// out[i] = in[i] * (*scalar) (mod.rs:71-75 with f2(u) still on the device)
+__global__ __launch_bounds__(kBlock) void k_scale_by(const Fr *__restrict__ in, const Fr *__restrict__ scalar, const uint64_t n, Fr *__restrict__ out) {
+    const Fr sc = fr_ld(scalar);
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) fr_st(out + i, scd::fr_mul(fr_ld(in + i), sc));
+}
+
+// flag |= 1 if any idx[i] has a bit at or above `bits` (index range check of device-resident inputs); |= 2 if the list is not in
+// non-decreasing index order
 __global__ __launch_bounds__(kBlock) void k_idx_range(const uint64_t *__restrict__ idx, const uint64_t n, const uint32_t bits, unsigned int *__restrict__ flag) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    bool bad = false;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) bad |= (idx[i] >> bits) != 0;
+    bool bad = false, unsorted = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t id = idx[i];
+        bad |= (id >> bits) != 0;
+        unsorted |= i > 0 && idx[i - 1] > id;
+    }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    if (__any(unsorted) && (threadIdx.x & 63) == 0) atomicOr(flag, 2u);
 }
 
 // canonical elements -> 8 zero-extended 32-bit limbs in uint64 lanes (summable across ranks with an integer all-reduce) ...
@@ -192,26 +385,10 @@ __global__ __launch_bounds__(kBlock) void k_widen(const Fr *__restrict__ in, con
 __global__ __launch_bounds__(kBlock) void k_wide_fold(const uint64_t *__restrict__ lanes, const uint64_t n, Fr *__restrict__ out) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        Fr lo;
-        uint64_t carry = 0;
+        uint64_t lane[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint64_t t = lanes[8 * i + j] + carry; // < 2^63 + 2^32: no wrap
-            lo.v[j] = (uint32_t)t;
-            carry = t >> 32;
-        }
-        lo = scd::fr_reduce_once(scd::fr_reduce_once(lo)); // lo < 2^256 < 3p
-        // hi = carry (< 2^32 for any sane rank count); hi * 2^256 mod p = mont_mul(hi, R^2)
-        Fr hi = scd::fr_zero(), r2;
-        hi.v[0] = (uint32_t)carry;
-        hi.v[1] = (uint32_t)(carry >> 32);
-        const uint64_t R2[4] = {0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            r2.v[2 * q] = (uint32_t)R2[q];
-            r2.v[2 * q + 1] = (uint32_t)(R2[q] >> 32);
-        }
-        fr_st(out + i, scd::fr_add(lo, scd::fr_mul(hi, r2)));
+        for (int j = 0; j < 8; ++j) lane[j] = lanes[8 * i + j];
+        fr_st(out + i, wide_fold_cell(lane));
     }
 }
 
@@ -263,6 +440,7 @@ struct GkrCache {
     int device = -1;
     sc_prover *prover = nullptr; // K = 1, M = 2, U = 2 borrowing handle of `prover_dim` variables
     uint32_t prover_dim = 0;
+    hipStream_t side = nullptr;  // sc_gkr_prove: f2(u) and the f3 scaling run beside the phase-two initialisation
 };
 static GkrCache g_cache;
 static thread_local bool t_holds_cache = false;
@@ -279,6 +457,10 @@ hipError_t DevBuf::reserve(size_t bytes) {
                 g_cache.prover = nullptr;
             }
             if (g_cache.arena) (void)hipFree(g_cache.arena);
+            if (g_cache.side && g_cache.device != dev) {
+                (void)hipStreamDestroy(g_cache.side);
+                g_cache.side = nullptr;
+            }
             g_cache.arena = nullptr;
             g_cache.cap = 0;
             g_cache.device = dev;
@@ -308,13 +490,15 @@ extern "C" int sc_release_caches(void) {
     if (g_cache.prover) sc_prover_free(g_cache.prover);
     g_cache.prover = nullptr;
     if (g_cache.arena) (void)hipFree(g_cache.arena);
+    if (g_cache.side) (void)hipStreamDestroy(g_cache.side);
+    g_cache.side = nullptr;
     g_cache.arena = nullptr;
     g_cache.cap = 0;
     g_cache.device = -1;
     return SC_OK;
 }
 
-inline size_t gkr_scratch_estimate(uint64_t nnz, uint64_t N) { return (size_t)704 * (nnz + 1) + (size_t)352 * N + ((size_t)64 << 20); }
+inline size_t gkr_scratch_estimate(uint64_t nnz, uint64_t N) { return (size_t)(704 + 64) * (nnz + 1) + (size_t)(352 + 64) * N + ((size_t)64 << 20); }
 
 inline int grid_for(uint64_t n) { return scd::grid_for_pairs(n); }
 inline FrHost hostfr(const sch::Fr &a) {
@@ -341,6 +525,25 @@ int sort_sparse(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_t n
     return SC_OK;
 }
 
+// eq(point, b) for all b in {0,1}^k (1 <= k <= kEqMaxVars) -> eq[0 .. 2^k)
+int build_eq_table(DevBuf &mem, const sch::Fr *point, uint32_t k, Fr *eq, hipStream_t s) {
+    EqPoint P;
+    std::memset(&P, 0, sizeof(P));
+    for (uint32_t i = 0; i < k; ++i) P.g[i] = hostfr(point[i]);
+    const int kl = (int)std::min<uint32_t>(k, kEqHalfMax), kh = (int)k - kl;
+    if (kh == 0) {
+        hipLaunchKernelGGL(k_eq_halves, dim3(1), dim3(kEqBlock), 0, s, eq, (Fr *)nullptr, P, kl, 0);
+    } else {
+        Fr *lo = nullptr, *hi = nullptr;
+        G_TRY(mem.alloc(&lo, (size_t)1 << kl));
+        G_TRY(mem.alloc(&hi, (size_t)1 << kh));
+        hipLaunchKernelGGL(k_eq_halves, dim3(2), dim3(kEqBlock), 0, s, lo, hi, P, kl, kh);
+        hipLaunchKernelGGL(k_eq_outer, dim3(grid_for(1ULL << k)), dim3(kBlock), 0, s, lo, hi, kl, 1ULL << k, eq);
+    }
+    G_TRY(hipGetLastError());
+    return SC_OK;
+}
+
 // SparseMultilinearExtension::fix_variables over the low k variables of a list sorted by index.
 // Output: merged (key, value) list (sorted, unique keys) in out_key/out_val (capacity n) and *d_count on device.
 int sparse_fix(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_t n, const sch::Fr *point, uint32_t k, uint64_t *out_key,
@@ -360,21 +563,8 @@ int sparse_fix(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_t n,
     } else if (use_table) {
         Fr *eq = nullptr;
         G_TRY(mem.alloc(&eq, (size_t)1 << k));
-        {
-            EqPoint P;
-            std::memset(&P, 0, sizeof(P));
-            for (uint32_t i = 0; i < k; ++i) P.g[i] = hostfr(point[i]);
-            const int kl = (int)std::min<uint32_t>(k, kEqHalfMax), kh = (int)k - kl;
-            if (kh == 0) {
-                hipLaunchKernelGGL(k_eq_halves, dim3(1), dim3(kEqBlock), 0, s, eq, (Fr *)nullptr, P, kl, 0);
-            } else {
-                Fr *lo = nullptr, *hi = nullptr;
-                G_TRY(mem.alloc(&lo, (size_t)1 << kl));
-                G_TRY(mem.alloc(&hi, (size_t)1 << kh));
-                hipLaunchKernelGGL(k_eq_halves, dim3(2), dim3(kEqBlock), 0, s, lo, hi, P, kl, kh);
-                hipLaunchKernelGGL(k_eq_outer, dim3(grid_for(1ULL << k)), dim3(kBlock), 0, s, lo, hi, kl, 1ULL << k, eq);
-            }
-        }
+        int rc_eq = build_eq_table(mem, point, k, eq, s);
+        if (rc_eq) return rc_eq;
         hipLaunchKernelGGL(k_sparse_scale, dim3(grid_for(n)), dim3(kBlock), 0, s, d_idx, d_vals, (const uint32_t *)nullptr, eq, k, n, key, w);
     } else {
         Fr *d_point = nullptr;
@@ -485,11 +675,17 @@ int stage_in(DevBuf &mem, const void *src, uint64_t n, bool on_device, const T *
     return SC_OK;
 }
 // every index below 2^bits (bits < 64); host arrays are checked on the host, device arrays by a kernel
-int check_index_range(DevBuf &mem, const uint64_t *idx, uint64_t n, uint32_t bits, bool on_device, const char *what, hipStream_t s) {
+int check_index_range(DevBuf &mem, const uint64_t *idx, uint64_t n, uint32_t bits, bool on_device, const char *what, hipStream_t s,
+                      bool *sorted_out = nullptr) {
+    if (sorted_out) *sorted_out = true;
     if (bits >= 64 || n == 0) return SC_OK;
     if (!on_device) {
-        for (uint64_t i = 0; i < n; ++i)
+        bool sorted = true;
+        for (uint64_t i = 0; i < n; ++i) {
             if ((idx[i] >> bits) != 0) return sc_internal_fail(SC_ERR_BAD_ARG, "%s index %llu out of range", what, (unsigned long long)i);
+            sorted &= i == 0 || idx[i - 1] <= idx[i];
+        }
+        if (sorted_out) *sorted_out = sorted;
         return SC_OK;
     }
     unsigned int *d_flag = nullptr, h = 0;
@@ -498,7 +694,92 @@ int check_index_range(DevBuf &mem, const uint64_t *idx, uint64_t n, uint32_t bit
     hipLaunchKernelGGL(k_idx_range, dim3(grid_for(n)), dim3(kBlock), 0, s, idx, n, bits, d_flag);
     G_TRY(hipMemcpyAsync(&h, d_flag, sizeof(h), hipMemcpyDeviceToHost, s));
     G_TRY(hipStreamSynchronize(s));
-    if (h) return sc_internal_fail(SC_ERR_BAD_ARG, "%s has an index out of range", what);
+    if (h & 1u) return sc_internal_fail(SC_ERR_BAD_ARG, "%s has an index out of range", what);
+    if (sorted_out) *sorted_out = !(h & 2u);
+    return SC_OK;
+}
+
+// eq(point, .) over dim variables as two small tables (EqSplit) in `mem`
+int build_eq_split(DevBuf &mem, const sch::Fr *point, uint32_t dim, EqSplit *out, hipStream_t s) {
+    EqPoint P;
+    std::memset(&P, 0, sizeof(P));
+    for (uint32_t i = 0; i < dim; ++i) P.g[i] = hostfr(point[i]);
+    const int kl = (int)std::min<uint32_t>(dim, kEqHalfMax), kh = (int)dim - kl;
+    Fr *lo = nullptr, *hi = nullptr;
+    G_TRY(mem.alloc(&lo, (size_t)1 << kl));
+    if (kh > 0) G_TRY(mem.alloc(&hi, (size_t)1 << kh));
+    hipLaunchKernelGGL(k_eq_halves, dim3(kh > 0 ? 2 : 1), dim3(kEqBlock), 0, s, lo, hi, P, kl, kh);
+    G_TRY(hipGetLastError());
+    out->lo = lo;
+    out->hi = hi;
+    out->kl = (uint32_t)kl;
+    return SC_OK;
+}
+
+// Phase two's bucket offsets of an index-ordered list depend on the indices only: sc_gkr_prove computes them on its second stream
+// while phase one runs.  Same bucket shape as bucketed_dense<2>.
+int bucket_bounds_phase_two(DevBuf &mem, const uint64_t *d_idx, uint64_t n, uint32_t dim, uint64_t **start_out, hipStream_t st) {
+    const uint32_t c = (uint32_t)std::max<int>((int)dim - 11, 0);
+    const uint64_t nb = 1ULL << (dim - c);
+    uint64_t *start = nullptr;
+    G_TRY(mem.alloc(&start, nb + 1));
+    hipLaunchKernelGGL(k_bucket_bounds, dim3(grid_for(n + 1)), dim3(kBlock), 0, st, d_idx, n, 2 * dim + c, (uint32_t)(nb - 1), start);
+    G_TRY(hipGetLastError());
+    *start_out = start;
+    return SC_OK;
+}
+
+// One of the two dense tables of sc_gkr_prove through the bucketed kernels.  *done = false: some bucket is too crowded for one
+// workgroup (a pathological index distribution) and `dense` is unfinished -- the caller takes the list form instead.
+template <int kPhase>
+int bucketed_dense(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_t n, uint32_t dim, const EqSplit &eg, const EqSplit &eu, const Fr *d_f3,
+                   bool idx_sorted, Fr *dense, bool *done, hipStream_t s, const std::function<int()> *before_sync = nullptr,
+                   const uint64_t *grouped_start = nullptr) {
+    // 2^c cells per bucket, at most kMaxBuckets buckets: dim 20 -> 2048 buckets of 512 cells (32 KB of lanes, four workgroups per CU)
+    const uint32_t c = (uint32_t)std::max<int>((int)dim - 11, 0);
+    if (c > 10) return sc_internal_fail(SC_ERR_BAD_ARG, "dim %u is outside the bucketed form", dim);
+    if (n >= (1ULL << 32)) return sc_internal_fail(SC_ERR_BAD_ARG, "more than 2^32 - 1 non-zeros");
+    const uint64_t nb = 1ULL << (dim - c);
+    const uint32_t shift = (kPhase == 1 ? dim : 2 * dim) + c, nb_mask = (uint32_t)(nb - 1);
+    uint64_t *start = nullptr;
+    G_TRY(mem.alloc(&start, nb + 1));
+    Fr *terms = nullptr;
+    uint16_t *cells = nullptr;
+    if (kPhase == 2 && idx_sorted && grouped_start) { // (bucket_bounds_phase_two ran earlier)
+        start = const_cast<uint64_t *>(grouped_start);
+    } else if (kPhase == 2 && idx_sorted) { // index order is y-major: already grouped
+        hipLaunchKernelGGL(k_bucket_bounds, dim3(grid_for(n + 1)), dim3(kBlock), 0, s, d_idx, n, shift, nb_mask, start);
+    } else {
+        const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(256, (n + 4095) / 4096);
+        const uint64_t chunk = (n + n_blocks - 1) / n_blocks;
+        uint32_t *counts = nullptr;
+        uint64_t *total = nullptr;
+        G_TRY(mem.alloc(&counts, (size_t)n_blocks * nb));
+        G_TRY(mem.alloc(&total, nb));
+        G_TRY(mem.alloc(&terms, n));
+        G_TRY(mem.alloc(&cells, n));
+        hipLaunchKernelGGL(k_bucket_count, dim3(n_blocks), dim3(kSortBlock), 0, s, d_idx, n, chunk, shift, nb_mask, counts);
+        hipLaunchKernelGGL(k_bucket_colscan, dim3((unsigned)((nb + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, counts, n_blocks, (uint32_t)nb, total);
+        hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(kMaxBuckets / 2), 0, s, total, (uint32_t)nb, start);
+        hipLaunchKernelGGL((k_bucket_scatter<kPhase>), dim3(n_blocks), dim3(kSortBlock), 0, s, d_idx, d_vals, n, chunk, dim, c, eg, eu, d_f3, counts, start, terms,
+                           cells);
+    }
+    G_TRY(hipGetLastError());
+    unsigned int *d_skew = nullptr, h_skew = 0;
+    G_TRY(mem.alloc(&d_skew, 1));
+    G_TRY(hipMemsetAsync(d_skew, 0, sizeof(unsigned int), s));
+    const size_t lds = ((size_t)8 << c) * sizeof(uint64_t);
+    const uint64_t max_entries = std::max<uint64_t>(8192, 64 * (n / nb + 1));
+    hipLaunchKernelGGL((k_bucket_accumulate<kPhase>), dim3((unsigned)nb), dim3(kBlock), lds, s, terms, cells, d_idx, d_vals, dim, c, eg, eu, d_f3, start,
+                       max_entries, d_skew, dense);
+    G_TRY(hipGetLastError());
+    G_TRY(hipMemcpyAsync(&h_skew, d_skew, sizeof(h_skew), hipMemcpyDeviceToHost, s));
+    if (before_sync) { // the caller's independent launches go out while these kernels run
+        int rc_b = (*before_sync)();
+        if (rc_b) return rc_b;
+    }
+    G_TRY(hipStreamSynchronize(s));
+    *done = h_skew == 0;
     return SC_OK;
 }
 
@@ -857,7 +1138,8 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     hipStream_t s = nullptr;
     DevBuf mem;
     (void)mem.reserve(gkr_scratch_estimate(nnz, 1ULL << dim));
-    if ((rc = check_index_range(mem, f1_idx, nnz, 3 * dim, dev, "f1", s))) return rc;
+    bool f1_sorted = true;
+    if ((rc = check_index_range(mem, f1_idx, nnz, 3 * dim, dev, "f1", s, &f1_sorted))) return rc;
     const bool trace = std::getenv("SC_GKR_TRACE") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -887,10 +1169,41 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
         (rc = stage_in(mem, f2, N, dev, &d_f2, s)) || (rc = stage_in(mem, f3, N, dev, &d_f3, s)))
         return rc;
     lap("h2d");
-    if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 3 * dim, d_idx_s, d_vals_s, s))) return rc;
-    lap("sort f1");
+    // Bucketed initialisation (k_bucket_accumulate) whenever the list is dense enough for 2^dim cells to be worth a pass; the list form (sort, merge, scatter:
+    // what sc_gkr_phase_one returns to a caller) otherwise, and when a bucket is too crowded.  SC_GKR_DIRECT=0 forces the list form.
+    static const bool direct_ok = !(std::getenv("SC_GKR_DIRECT") && std::atoi(std::getenv("SC_GKR_DIRECT")) == 0);
+    bool direct = direct_ok && nnz > 0 && dim <= (uint32_t)kEqMaxVars && N <= 8 * nnz + 1024;
+    hipStream_t side = s;
+    if (mem.leased) {
+        if (!g_cache.side && hipStreamCreateWithFlags(&g_cache.side, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            g_cache.side = nullptr;
+        }
+        if (g_cache.side) side = g_cache.side;
+    }
+    struct StreamJoin { // no return path leaves work behind on the second stream (it reads and writes this call's scratch)
+        hipStream_t st;
+        ~StreamJoin() {
+            if (st) (void)hipStreamSynchronize(st);
+        }
+    } join{side != s ? side : nullptr};
+    EqSplit eq_g{nullptr, nullptr, 0}, eq_u{nullptr, nullptr, 0};
     uint64_t n1 = 0;
-    if ((rc = phase_one_device(mem, d_idx_s, d_vals_s, nnz, dim, d_f3, reinterpret_cast<const sch::Fr *>(g), d_hg, d_gi, d_gv, d_n1, &n1, s))) return rc; // mod.rs:106
+    bool have_list = false; // f1(g,.,.) as a merged list in d_gi / d_gv (list form only)
+    uint64_t *start2 = nullptr;
+    if (direct && f1_sorted && side != s && (rc = bucket_bounds_phase_two(mem, d_idx, nnz, dim, &start2, side))) return rc;
+    if (direct) {
+        if ((rc = build_eq_split(mem, reinterpret_cast<const sch::Fr *>(g), dim, &eq_g, s))) return rc;
+        if ((rc = bucketed_dense<1>(mem, d_idx, d_vals, nnz, dim, eq_g, eq_u, d_f3, f1_sorted, d_hg, &direct, s))) return rc; // mod.rs:30-38
+    }
+    auto list_form = [&]() -> int {
+        int r = sort_sparse(mem, d_idx, d_vals, nnz, 3 * dim, d_idx_s, d_vals_s, s);
+        if (r) return r;
+        lap("sort f1");
+        have_list = true;
+        return phase_one_device(mem, d_idx_s, d_vals_s, nnz, dim, d_f3, reinterpret_cast<const sch::Fr *>(g), d_hg, d_gi, d_gv, d_n1, &n1, s); // mod.rs:106
+    };
+    if (!direct && (rc = list_form())) return rc;
     G_TRY(hipStreamSynchronize(s));
     lap("phase one init");
     std::vector<sch::Fr> u(dim), v(dim);
@@ -898,13 +1211,13 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     pg.take_cached(dim, mem.leased);
     if ((rc = run_phase(rng->rng, &pg.p, d_hg, d_f2, dim, out_proof, u.data()))) return rc; // mod.rs:107-119
     lap("phase one sumcheck");
-    if ((rc = phase_two_device(mem, d_gi, d_gv, n1, dim, u.data(), d_f1gu, s))) return rc; // mod.rs:121
-    lap("phase two init");
-    // f2.evaluate(&u) (mod.rs:122): all dim variables bound on the device, three per pass (8 entries in, 1 out), ping-ponging between
-    // two buffers that are free at this point (h_g is spent, d_tmp holds an eighth of it)
-    sch::Fr f2_u;
-    G_TRY(hipStreamSynchronize(s));
-    {
+    // f2.evaluate(&u) (mod.rs:122) and the scaling of f3 by it (mod.rs:71-75) depend on u only, like the phase-two initialisation: they run
+    // beside it on a second stream (the cache's; a call that does not hold the cache runs them in line).  All dim variables are bound on the
+    // device, three per pass (8 entries in, 1 out), ping-ponging between two buffers that are free at this point (h_g is spent, d_tmp
+    // holds an eighth of it); the scalar never visits the host.
+    bool f2_enqueued = false;
+    const std::function<int()> enqueue_f2 = [&]() -> int {
+        f2_enqueued = true;
         const uint4 *cur = reinterpret_cast<const uint4 *>(d_f2);
         uint4 *pp[2] = {reinterpret_cast<uint4 *>(d_hg), reinterpret_cast<uint4 *>(d_tmp)};
         uint64_t m = N;
@@ -921,16 +1234,34 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
                 for (int dbl = 0; dbl < 5; ++dbl) r32v = sch::add(r32v, r32v);
                 fa.r32[l] = hostfr(r32v);
             }
-            G_TRY(scd::launch_fold_multi(fa, L, 1, m, s));
+            G_TRY(scd::launch_fold_multi(fa, L, 1, m, side));
             cur = pp[pass & 1];
             var += L;
         }
-        G_TRY(hipMemcpyAsync(&f2_u, cur, 32, hipMemcpyDeviceToHost, s));
-        G_TRY(hipStreamSynchronize(s));
+        hipLaunchKernelGGL(k_scale_by, dim3(grid_for(N)), dim3(kBlock), 0, side, d_f3, reinterpret_cast<const Fr *>(cur), N, d_f3s);
+        G_TRY(hipGetLastError());
+        return SC_OK;
+    };
+    if (direct) {
+        if (start2) G_TRY(hipStreamSynchronize(side)); // (long finished: it ran beside phase one)
+        if ((rc = build_eq_split(mem, u.data(), dim, &eq_u, s))) return rc;
+        if ((rc = bucketed_dense<2>(mem, d_idx, d_vals, nnz, dim, eq_g, eq_u, d_f3, f1_sorted, d_f1gu, &direct, s, &enqueue_f2, start2))) return rc; // mod.rs:121
+        if (!direct && !have_list) { // (crowded y buckets although the x buckets were fine: build the list now)
+            int r = sort_sparse(mem, d_idx, d_vals, nnz, 3 * dim, d_idx_s, d_vals_s, s);
+            if (r) return r;
+            if ((r = sparse_fix(mem, d_idx_s, d_vals_s, nnz, reinterpret_cast<const sch::Fr *>(g), dim, d_gi, d_gv, d_n1, s))) return r;
+            unsigned int h_n1 = 0;
+            G_TRY(hipMemcpyAsync(&h_n1, d_n1, sizeof(h_n1), hipMemcpyDeviceToHost, s));
+            G_TRY(hipStreamSynchronize(s));
+            n1 = h_n1;
+            have_list = true;
+        }
     }
-    G_TRY(scd::launch_scale(reinterpret_cast<const uint4 *>(d_f3), reinterpret_cast<uint4 *>(d_f3s), hostfr(f2_u), N, s)); // mod.rs:71-75
+    if (!f2_enqueued && (rc = enqueue_f2())) return rc;
+    if (!direct && (rc = phase_two_device(mem, d_gi, d_gv, n1, dim, u.data(), d_f1gu, s))) return rc; // mod.rs:121
     G_TRY(hipStreamSynchronize(s));
-    lap("f2(u), scale f3");
+    if (side != s) G_TRY(hipStreamSynchronize(side));
+    lap("phase two init, f2(u), scale f3");
     if ((rc = run_phase(rng->rng, &pg.p, d_f1gu, d_f3s, dim, out_proof + (size_t)dim * 12, v.data()))) return rc; // mod.rs:122-133
     lap("phase two sumcheck");
     if (out_uv_or_null) {

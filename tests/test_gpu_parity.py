@@ -671,3 +671,55 @@ def test_provers_on_several_threads_share_one_gpu():
     for t in ts:
         t.join(timeout=600)
     assert out == [0, 0, 0], out
+
+
+@pytest.mark.parametrize("case", ["sorted", "shuffled", "crowded_x", "crowded_y", "duplicates", "tiny_dim", "list_form"])
+def test_gkr_prove_bucketed_initialisation(case, monkeypatch):
+    """sc_gkr_prove builds a_hg and f1(g,u,.) by bucketing the non-zeros and adding terms in LDS (gkr.hip: k_bucket_accumulate)
+    instead of sorting and merging.  Same proof bits as the oracle for: index-ordered input (phase two skips its radix pass),
+    shuffled input, index distributions that crowd one x or y bucket (fallback to the list form, in either phase), repeated
+    indices (summed, as the list form does), dim below the bucket width, and the list form forced by SC_GKR_DIRECT=0."""
+    dim = 4 if case == "tiny_dim" else 14
+    n = 1 << dim
+    rng = np.random.default_rng(99)
+    z = rng.integers(0, n, size=4 * n, dtype=np.uint64)
+    x = rng.integers(0, n, size=4 * n, dtype=np.uint64)
+    y = rng.integers(0, n, size=4 * n, dtype=np.uint64)
+    if case == "crowded_x":
+        x &= np.uint64(7)  # every non-zero in x bucket 0 (16 cells per bucket at dim 14)
+    if case == "crowded_y":
+        y &= np.uint64(7)
+    idx = z | (x << np.uint64(dim)) | (y << np.uint64(2 * dim))
+    if case != "duplicates":
+        idx = np.unique(idx)
+    else:
+        idx = np.concatenate([np.unique(idx), idx[:1000]])
+    if case in ("shuffled", "crowded_x", "duplicates"):
+        idx = idx[rng.permutation(idx.shape[0])]
+    vals, f2, f3, g = (cref.synth_table(77, 1, idx.shape[0]), cref.synth_table(77, 2, n), cref.synth_table(77, 3, n), cref.synth_table(77, 4, dim))
+    if case == "duplicates":  # the oracle takes a map: give it the merged list
+        order = np.argsort(idx, kind="stable")
+        si, sv = idx[order], vals[order]
+        ui, start = np.unique(si, return_index=True)
+        ints = field.to_ints(sv)
+        merged = []
+        for a, b in zip(start, list(start[1:]) + [len(si)]):
+            merged.append(sum(ints[a:b]) % field.P)
+        oi, ov = ui, H.mont(merged)
+    else:
+        oi, ov = idx, vals
+    if case == "list_form":
+        monkeypatch.setenv("SC_GKR_DIRECT", "0")  # (read once per process: only effective if no GKR proof ran before; parity holds either way)
+    want, wuv = cref.gkr_prove(oi, ov, dim, f2, f3, g, threads=cref.max_threads())
+    for on_device in (False, True):
+        if on_device:
+            import torch
+            dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+            f1 = sc.SparseMultilinearExtension(3 * dim, dev(idx), dev(vals))
+            m2, m3 = sc.DenseMultilinearExtension(dim, dev(f2)), sc.DenseMultilinearExtension(dim, dev(f3))
+        else:
+            f1 = sc.SparseMultilinearExtension(3 * dim, idx, vals)
+            m2, m3 = sc.DenseMultilinearExtension(dim, f2), sc.DenseMultilinearExtension(dim, f3)
+        proof = sc.GKRRoundSumcheck.prove(sc.Blake2b512Rng.setup(), f1, m2, m3, g)
+        assert np.array_equal(np.stack([m.evaluations for m in proof.phase1_sumcheck_msgs]), want[0]), (case, on_device)
+        assert np.array_equal(np.stack([m.evaluations for m in proof.phase2_sumcheck_msgs]), want[1]), (case, on_device)
