@@ -213,7 +213,11 @@ SC_API int sc_gkr_phase_one(const uint64_t *f1_idx, const uint64_t *f1_vals, uin
 SC_API int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_vals, uint64_t nnz, uint32_t dim, const uint64_t *u,
                      uint32_t flags, uint64_t *f1_gu);
 /* GKRRoundSumcheck::prove (mod.rs:93-139).  out_proof: 2 x dim x 3 x 4 limbs (phase1 then phase2
- * messages); out_uv_or_null: 2 x dim x 4 (u then v). */
+ * messages); out_uv_or_null: 2 x dim x 4 (u then v).
+ * The proof needs the two dense tables of the initialisations but not f1(g,.,.) as a list, so this entry point does not sort: the
+ * non-zeros' terms are grouped by target cell and added up in LDS (exact field sums in any order give the reference's bits); repeated
+ * indices are summed, as a map built by insertion-with-add would; an index-ordered list (BTreeMap order) saves one grouping pass.
+ * sc_gkr_phase_one / _two above return the list and take the sorting route. */
 SC_API int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim,
                  const uint64_t *f2, const uint64_t *f3, const uint64_t *g, uint32_t flags, uint64_t *out_proof, uint64_t *out_uv_or_null);
 /* f4 -- the same two initialisations with f1's non-zeros SPREAD OVER SEVERAL GPUs (worth it from dim ~ 24).

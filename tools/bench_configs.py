@@ -57,7 +57,7 @@ def gkr(dim, reps=7):
     two sumcheck phases over two dense tables each, 32 * 2 * (4 * 2^dim - 6) per phase; initialisation: f1 read (40 B per non-zero:
     8 B index + 32 B value) once per sparse fold plus one result write (2 folds), the two eq tables written once (2^dim each), f3 read
     for the scatter terms (nnz' gathers), h_g / f1(g,u,.) written once each, f2 read once (evaluate) and f3 read + written once (scale).
-    The radix sorts and segmented sums (rocPRIM) move several times that; their share of the time is reported from SC_GKR_TRACE=1."""
+    sc_gkr_prove groups the terms by target cell and adds them in LDS (no sorts); stage times come from SC_GKR_TRACE=1."""
     rng = np.random.default_rng(SEED)
     n = 1 << dim
     idx = np.unique(rng.integers(0, 1 << (3 * dim), size=2 * n, dtype=np.uint64))[:n]
@@ -84,7 +84,7 @@ def gkr(dim, reps=7):
             "gpu_ms_median_host_inputs_incl_h2d": 1e3 * float(np.median(th)), "cpu_port_s": tc, "cpu_threads": cref.max_threads(),
             "speedup_device_resident": tc / med,
             "roofline": {"bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / med / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / med / 1e9 / 8000.0,
-                         "note": "latency-bound: 40 sumcheck rounds over 2^20-entry tables (about 30 us each) and a dozen short initialisation kernels"}}
+                         "note": "latency-bound: 40 sumcheck rounds over 2^20-entry tables (about 25 us each) and a dozen short initialisation kernels"}}
 
 
 def streamed(nv, shapes, nt, reps=3):
