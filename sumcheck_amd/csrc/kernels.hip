@@ -1312,13 +1312,9 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
     auto tab = [&](uint32_t u) -> const uint4 * { return binds == 0 ? A.t.cur0[u] : (binds & 1) ? A.t.b0[u] : A.t.b1[u]; };
     auto prod_of = [&](int k) -> FinProd { return fin.prod[k]; };
     if (threadIdx.x == 0) stop_sh = 0;
-    // block 0 writes every message: its threads keep their Lagrange weight for the whole launch (finalize_message's compact form)
-    Fr w_fin = fr_zero();
+    // (keeping block 0's Lagrange weights in registers for the whole launch was measured: eight more live registers, the first spills
+    // of this kernel, no change in the round time -- the weights are L2 hits after the first round)
     const Fr *w_pre = nullptr;
-    if (blockIdx.x == 0 && fin_compact<kBlock>(A.K, A.D)) {
-        w_fin = fin_prefetch_weight(prod_of, A.Wm, A.K, A.D, 0);
-        w_pre = &w_fin;
-    }
     for (int j = 0; j < A.n_rounds; ++j, n_pairs >>= 1) {
         // The rounds shrink: blocks beyond what this round can use retire for good (the count never grows again), so the barriers of
         // the later rounds synchronise a handful of blocks instead of one per CU, and the last rounds run in block 0 alone.

@@ -1,0 +1,7 @@
+# same-box A/B of several library builds: tools/run_ab3.sh lib1.so lib2.so ...  (ms per proof: mean, min of 30; average big-round launch)
+for rep in 1 2 3; do
+  for L in "$@"; do
+    echo -n "$L  "; SC_LIB_PATH=$PWD/$L timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), round(d['ms_per_step_min'],4), round(d['roofline']['avg_launch_ms'],4))"
+  done
+done
+for L in "$@"; do echo "== $L"; SC_LIB_PATH=$PWD/$L timeout 120 python tools/round_times.py 24 2>&1 | sed -n '3,6p'; done
