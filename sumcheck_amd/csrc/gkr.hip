@@ -241,12 +241,13 @@ __global__ __launch_bounds__(kBlock) void k_bucket_colscan(uint32_t *__restrict_
     const uint32_t b = blockIdx.x * kBlock + threadIdx.x;
     if (b >= nb) return;
     uint64_t run = 0;
-    for (uint32_t r0 = 0; r0 < n_blocks; r0 += 8) { // eight rows in flight
-        uint32_t c[8];
+    constexpr int kRows = 32; // rows in flight (the loop is load latency)
+    for (uint32_t r0 = 0; r0 < n_blocks; r0 += kRows) {
+        uint32_t c[kRows];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) c[q] = r0 + q < n_blocks ? counts[(uint64_t)(r0 + q) * nb + b] : 0;
+        for (int q = 0; q < kRows; ++q) c[q] = r0 + q < n_blocks ? counts[(uint64_t)(r0 + q) * nb + b] : 0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < kRows; ++q) {
             if (r0 + q < n_blocks) counts[(uint64_t)(r0 + q) * nb + b] = (uint32_t)run; // (the list holds < 2^32 non-zeros)
             run += c[q];
         }
@@ -286,13 +287,26 @@ __global__ __launch_bounds__(kSortBlock) void k_bucket_scatter(const uint64_t *_
     }
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += kSortBlock) {
-        const uint64_t id = idx[i];
-        const Fr t = gkr_term<kPhase>(id, fr_ld(vals + i), dim, eg, eu, f3);
-        const uint32_t b = bucket_of(id, cell_shift + c, nb_mask);
-        const uint64_t pos = base[b] + atomicAdd(&rank[b], 1u);
-        fr_st(out_term + pos, t);
-        out_cell[pos] = (uint16_t)((id >> cell_shift) & ((1u << c) - 1));
+    constexpr int kIlp = 4; // four independent product chains per lane: a term is three or four dependent Montgomery products
+    for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (uint64_t)kIlp * kSortBlock) {
+        uint64_t id[kIlp];
+        Fr t[kIlp];
+#pragma unroll
+        for (int q = 0; q < kIlp; ++q) {
+            const uint64_t i = min(i0 + (uint64_t)q * kSortBlock, hi - 1); // (clamped: the surplus lanes recompute the last entry and drop it)
+            id[q] = idx[i];
+            t[q] = fr_ld(vals + i);
+        }
+#pragma unroll
+        for (int q = 0; q < kIlp; ++q) t[q] = gkr_term<kPhase>(id[q], t[q], dim, eg, eu, f3);
+#pragma unroll
+        for (int q = 0; q < kIlp; ++q) {
+            if (i0 + (uint64_t)q * kSortBlock >= hi) continue;
+            const uint32_t b = bucket_of(id[q], cell_shift + c, nb_mask);
+            const uint64_t pos = base[b] + atomicAdd(&rank[b], 1u);
+            fr_st(out_term + pos, t[q]);
+            out_cell[pos] = (uint16_t)((id[q] >> cell_shift) & ((1u << c) - 1));
+        }
     }
 }
 // start offsets of a list that is already grouped (in non-decreasing bucket order): position i opens every bucket in
@@ -324,19 +338,34 @@ __global__ __launch_bounds__(kBlock) void k_bucket_accumulate(const Fr *__restri
         return;
     }
     const uint32_t cell_shift = kPhase == 1 ? dim : 2 * dim;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
-        Fr t;
-        uint32_t ci;
-        if (terms) {
-            t = fr_ld(terms + i);
-            ci = cells[i];
-        } else {
-            const uint64_t id = idx[i];
-            t = gkr_term<kPhase>(id, fr_ld(vals + i), dim, eg, eu, f3);
-            ci = (uint32_t)((id >> cell_shift) & ((1u << c) - 1));
-        }
+    if (terms) {
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+            const Fr t = fr_ld(terms + i);
+            const uint32_t ci = cells[i];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(reinterpret_cast<unsigned long long *>(cell + (((uint32_t)j << c) | ci)), (unsigned long long)t.v[j]);
+            for (int j = 0; j < 8; ++j) atomicAdd(reinterpret_cast<unsigned long long *>(cell + (((uint32_t)j << c) | ci)), (unsigned long long)t.v[j]);
+        }
+    } else {
+        constexpr int kIlp = 2; // two independent product chains per lane (a bucket holds about two non-zeros per lane)
+        for (uint64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (uint64_t)kIlp * kBlock) {
+            uint64_t id[kIlp];
+            Fr t[kIlp];
+#pragma unroll
+            for (int q = 0; q < kIlp; ++q) {
+                const uint64_t i = min(i0 + (uint64_t)q * kBlock, hi - 1);
+                id[q] = idx[i];
+                t[q] = fr_ld(vals + i);
+            }
+#pragma unroll
+            for (int q = 0; q < kIlp; ++q) t[q] = gkr_term<kPhase>(id[q], t[q], dim, eg, eu, f3);
+#pragma unroll
+            for (int q = 0; q < kIlp; ++q) {
+                if (i0 + (uint64_t)q * kBlock >= hi) continue;
+                const uint32_t ci = (uint32_t)((id[q] >> cell_shift) & ((1u << c) - 1));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(reinterpret_cast<unsigned long long *>(cell + (((uint32_t)j << c) | ci)), (unsigned long long)t[q].v[j]);
+            }
+        }
     }
     __syncthreads();
     for (uint32_t ci = threadIdx.x; ci < (1u << c); ci += kBlock) {
@@ -738,7 +767,10 @@ int bucketed_dense(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_
     // 2^c cells per bucket, at most kMaxBuckets buckets: dim 20 -> 2048 buckets of 512 cells (32 KB of lanes, four workgroups per CU)
     const uint32_t c = (uint32_t)std::max<int>((int)dim - 11, 0);
     if (c > 10) return sc_internal_fail(SC_ERR_BAD_ARG, "dim %u is outside the bucketed form", dim);
-    if (n >= (1ULL << 32)) return sc_internal_fail(SC_ERR_BAD_ARG, "more than 2^32 - 1 non-zeros");
+    if (n >= (1ULL << 32)) { // (positions and per-block counts are 32-bit here: the list form takes such a list)
+        *done = false;
+        return SC_OK;
+    }
     const uint64_t nb = 1ULL << (dim - c);
     const uint32_t shift = (kPhase == 1 ? dim : 2 * dim) + c, nb_mask = (uint32_t)(nb - 1);
     uint64_t *start = nullptr;
@@ -750,7 +782,7 @@ int bucketed_dense(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_
     } else if (kPhase == 2 && idx_sorted) { // index order is y-major: already grouped
         hipLaunchKernelGGL(k_bucket_bounds, dim3(grid_for(n + 1)), dim3(kBlock), 0, s, d_idx, n, shift, nb_mask, start);
     } else {
-        const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(256, (n + 4095) / 4096);
+        const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(256, (n + 4095) / 4096); // (one 1024-thread block per CU at 2^20 non-zeros)
         const uint64_t chunk = (n + n_blocks - 1) / n_blocks;
         uint32_t *counts = nullptr;
         uint64_t *total = nullptr;

@@ -29,4 +29,6 @@ for c in range(cases):
     if not ok:
         bad += 1
         print("MISMATCH", c, nv, nt, shapes, dev)
+    if c % 20 == 19:
+        print(f"fuzz: {c + 1} cases, mismatches so far {bad}, {time.time() - t0:.0f} s", flush=True)
 print(f"FUZZ {'OK' if bad == 0 else 'FAILED'}: {cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
