@@ -206,10 +206,11 @@ SC_API int sc_ml_verify(uint32_t num_vars, uint32_t max_multiplicands, const uin
  * are produced in place; without it they are host arrays that the call stages through HBM.  The proof itself, u, v and
  * *f1g_nnz always land on the host.
  * initialize_phase_one (mod.rs:22-42): h_g = 2^dim x 4 out; f1_g out as sorted (index,value) pairs,
- * capacity nnz, *f1g_nnz = count. */
+ * capacity nnz, *f1g_nnz = count.  A list that arrives in index order (what iterating a BTreeMap gives) is not sorted again;
+ * the dense table is accumulated from the list as it came. */
 SC_API int sc_gkr_phase_one(const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz, uint32_t dim, const uint64_t *f3,
                      const uint64_t *g, uint32_t flags, uint64_t *h_g, uint64_t *f1g_idx, uint64_t *f1g_vals, uint64_t *f1g_nnz);
-/* initialize_phase_two (mod.rs:57-63): f1_gu = 2^dim x 4 out */
+/* initialize_phase_two (mod.rs:57-63): f1_gu = 2^dim x 4 out.  Any order of the list; repeated indices add up. */
 SC_API int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_vals, uint64_t nnz, uint32_t dim, const uint64_t *u,
                      uint32_t flags, uint64_t *f1_gu);
 /* GKRRoundSumcheck::prove (mod.rs:93-139).  out_proof: 2 x dim x 3 x 4 limbs (phase1 then phase2

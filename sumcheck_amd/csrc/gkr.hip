@@ -208,10 +208,14 @@ __device__ __forceinline__ Fr eq_at(const EqSplit &e, const uint64_t b) {
     const Fr l = fr_ld(e.lo + (b & ((1ULL << e.kl) - 1)));
     return e.hi ? scd::fr_mul(fr_ld(e.hi + (b >> e.kl)), l) : l;
 }
-// kPhase 1: cell = x, term = eq(g,z) * v * f3[y].  kPhase 2: cell = y, term = eq(g,z) * eq(u,x) * v.
+// kPhase 1: index (z,x,y), cell = x, term = eq(g,z) * v * f3[y].  kPhase 2: index (z,x,y), cell = y, term = eq(g,z) * eq(u,x) * v.
+// kPhase 3 (initialize_phase_two on the list f1(g,.,.)): index (x,y), cell = y, term = eq(u,x) * v.
+template <int kPhase>
+__host__ __device__ constexpr uint32_t cell_shift_of(const uint32_t dim) { return kPhase == 2 ? 2 * dim : dim; }
 template <int kPhase>
 __device__ __forceinline__ Fr gkr_term(const uint64_t id, const Fr &v, const uint32_t dim, const EqSplit &eg, const EqSplit &eu, const Fr *__restrict__ f3) {
     const uint64_t mask = (1ULL << dim) - 1;
+    if (kPhase == 3) return scd::fr_mul(eq_at(eu, id & mask), v);
     const Fr a = scd::fr_mul(eq_at(eg, id & mask), v);
     if (kPhase == 1) return scd::fr_mul(a, fr_ld(f3 + (id >> (2 * dim))));
     return scd::fr_mul(a, eq_at(eu, (id >> dim) & mask));
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(kSortBlock) void k_bucket_scatter(const uint64_t *_
                                                                uint16_t *__restrict__ out_cell) {
     __shared__ uint32_t rank[kMaxBuckets];
     __shared__ uint64_t base[kMaxBuckets];
-    const uint32_t cell_shift = kPhase == 1 ? dim : 2 * dim, nb_mask = (1u << (dim - c)) - 1;
+    const uint32_t cell_shift = cell_shift_of<kPhase>(dim), nb_mask = (1u << (dim - c)) - 1;
     for (uint32_t b = threadIdx.x; b <= nb_mask; b += kSortBlock) {
         rank[b] = 0;
         base[b] = start[b] + counts[(uint64_t)blockIdx.x * (nb_mask + 1) + b];
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_bucket_accumulate(const Fr *__restri
         if (threadIdx.x == 0) atomicOr(skewed, 1u);
         return;
     }
-    const uint32_t cell_shift = kPhase == 1 ? dim : 2 * dim;
+    const uint32_t cell_shift = cell_shift_of<kPhase>(dim);
     if (terms) {
         for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
             const Fr t = fr_ld(terms + i);
@@ -758,6 +762,13 @@ int bucket_bounds_phase_two(DevBuf &mem, const uint64_t *d_idx, uint64_t n, uint
     return SC_OK;
 }
 
+// 2^dim cells are worth a pass of their own when the list is not much sparser than the table (and the eq tables fit EqPoint).
+// SC_GKR_DIRECT=0 switches the bucketed form off (tests of the list form).
+bool bucketed_form_pays(uint64_t nnz, uint32_t dim) {
+    static const bool on = !(std::getenv("SC_GKR_DIRECT") && std::atoi(std::getenv("SC_GKR_DIRECT")) == 0);
+    return on && nnz > 0 && dim <= (uint32_t)kEqMaxVars && (1ULL << dim) <= 8 * nnz + 1024;
+}
+
 // One of the two dense tables of sc_gkr_prove through the bucketed kernels.  *done = false: some bucket is too crowded for one
 // workgroup (a pathological index distribution) and `dense` is unfinished -- the caller takes the list form instead.
 template <int kPhase>
@@ -772,14 +783,14 @@ int bucketed_dense(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_
         return SC_OK;
     }
     const uint64_t nb = 1ULL << (dim - c);
-    const uint32_t shift = (kPhase == 1 ? dim : 2 * dim) + c, nb_mask = (uint32_t)(nb - 1);
+    const uint32_t shift = cell_shift_of<kPhase>(dim) + c, nb_mask = (uint32_t)(nb - 1);
     uint64_t *start = nullptr;
     G_TRY(mem.alloc(&start, nb + 1));
     Fr *terms = nullptr;
     uint16_t *cells = nullptr;
-    if (kPhase == 2 && idx_sorted && grouped_start) { // (bucket_bounds_phase_two ran earlier)
+    if (kPhase != 1 && idx_sorted && grouped_start) { // (bucket_bounds_phase_two ran earlier)
         start = const_cast<uint64_t *>(grouped_start);
-    } else if (kPhase == 2 && idx_sorted) { // index order is y-major: already grouped
+    } else if (kPhase != 1 && idx_sorted) { // index order is y-major: already grouped
         hipLaunchKernelGGL(k_bucket_bounds, dim3(grid_for(n + 1)), dim3(kBlock), 0, s, d_idx, n, shift, nb_mask, start);
     } else {
         const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(256, (n + 4095) / 4096); // (one 1024-thread block per CU at 2^20 non-zeros)
@@ -830,7 +841,8 @@ extern "C" int sc_gkr_phase_one(const uint64_t *f1_idx, const uint64_t *f1_vals,
     DevBuf mem;
     const uint64_t N = 1ULL << dim;
     (void)mem.reserve(gkr_scratch_estimate(nnz, N));
-    if ((rc = check_index_range(mem, f1_idx, nnz, 3 * dim, dev, "f1", s))) return rc;
+    bool f1_sorted = true;
+    if ((rc = check_index_range(mem, f1_idx, nnz, 3 * dim, dev, "f1", s, &f1_sorted))) return rc;
     const uint64_t *d_idx = nullptr;
     const Fr *d_vals = nullptr, *d_f3 = nullptr;
     uint64_t *d_idx_s = nullptr, *d_gi = nullptr;
@@ -850,9 +862,31 @@ extern "C" int sc_gkr_phase_one(const uint64_t *f1_idx, const uint64_t *f1_vals,
         G_TRY(mem.alloc(&d_gi, nnz));
         G_TRY(mem.alloc(&d_gv, nnz));
     }
-    if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 3 * dim, d_idx_s, d_vals_s, s))) return rc;
+    // f1(g,.,.) comes back as a merged list, which needs the non-zeros in index order (a list that arrives ordered, as a BTreeMap's does,
+    // is not sorted again); a_hg does not: it is bucketed from the list as it came whenever that pays (sc_gkr_prove's initialisation)
+    const uint64_t *si = d_idx;
+    const Fr *sv = d_vals;
+    if (!f1_sorted) {
+        if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 3 * dim, d_idx_s, d_vals_s, s))) return rc;
+        si = d_idx_s;
+        sv = d_vals_s;
+    }
     uint64_t n1 = 0;
-    if ((rc = phase_one_device(mem, d_idx_s, d_vals_s, nnz, dim, d_f3, reinterpret_cast<const sch::Fr *>(g), d_hg, d_gi, d_gv, d_n1, &n1, s))) return rc;
+    bool hg_done = false;
+    if (bucketed_form_pays(nnz, dim)) {
+        EqSplit eq_g{nullptr, nullptr, 0}, none{nullptr, nullptr, 0};
+        if ((rc = build_eq_split(mem, reinterpret_cast<const sch::Fr *>(g), dim, &eq_g, s))) return rc;
+        if ((rc = bucketed_dense<1>(mem, d_idx, d_vals, nnz, dim, eq_g, none, d_f3, f1_sorted, d_hg, &hg_done, s))) return rc; // mod.rs:30-38
+    }
+    if (hg_done) {
+        if ((rc = sparse_fix(mem, si, sv, nnz, reinterpret_cast<const sch::Fr *>(g), dim, d_gi, d_gv, d_n1, s))) return rc; // mod.rs:31
+        unsigned int h_n1 = 0;
+        G_TRY(hipMemcpyAsync(&h_n1, d_n1, sizeof(h_n1), hipMemcpyDeviceToHost, s));
+        G_TRY(hipStreamSynchronize(s));
+        n1 = h_n1;
+    } else if ((rc = phase_one_device(mem, si, sv, nnz, dim, d_f3, reinterpret_cast<const sch::Fr *>(g), d_hg, d_gi, d_gv, d_n1, &n1, s))) {
+        return rc;
+    }
     if (!dev) {
         G_TRY(hipMemcpyAsync(h_g, d_hg, N * 32, hipMemcpyDeviceToHost, s));
         if (n1) {
@@ -877,7 +911,8 @@ extern "C" int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_val
     DevBuf mem;
     const uint64_t N = 1ULL << dim;
     (void)mem.reserve(gkr_scratch_estimate(nnz, N));
-    if ((rc = check_index_range(mem, f1g_idx, nnz, 2 * dim, dev, "f1_g", s))) return rc;
+    bool f1g_sorted = true;
+    if ((rc = check_index_range(mem, f1g_idx, nnz, 2 * dim, dev, "f1_g", s, &f1g_sorted))) return rc;
     const uint64_t *d_idx = nullptr;
     const Fr *d_vals = nullptr;
     uint64_t *d_idx_s = nullptr;
@@ -887,8 +922,16 @@ extern "C" int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_val
     G_TRY(mem.alloc(&d_vals_s, nnz));
     if (dev) d_out = reinterpret_cast<Fr *>(f1_gu);
     else G_TRY(mem.alloc(&d_out, N));
-    if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 2 * dim, d_idx_s, d_vals_s, s))) return rc;
-    if ((rc = phase_two_device(mem, d_idx_s, d_vals_s, nnz, dim, reinterpret_cast<const sch::Fr *>(u), d_out, s))) return rc;
+    bool done = false;
+    if (bucketed_form_pays(nnz, dim)) { // the dense table straight from the list, in whatever order it came (ordered: no grouping pass)
+        EqSplit eq_u{nullptr, nullptr, 0}, none{nullptr, nullptr, 0};
+        if ((rc = build_eq_split(mem, reinterpret_cast<const sch::Fr *>(u), dim, &eq_u, s))) return rc;
+        if ((rc = bucketed_dense<3>(mem, d_idx, d_vals, nnz, dim, none, eq_u, nullptr, f1g_sorted, d_out, &done, s))) return rc; // mod.rs:62
+    }
+    if (!done) {
+        if ((rc = sort_sparse(mem, d_idx, d_vals, nnz, 2 * dim, d_idx_s, d_vals_s, s))) return rc;
+        if ((rc = phase_two_device(mem, d_idx_s, d_vals_s, nnz, dim, reinterpret_cast<const sch::Fr *>(u), d_out, s))) return rc;
+    }
     if (!dev) G_TRY(hipMemcpyAsync(f1_gu, d_out, N * 32, hipMemcpyDeviceToHost, s));
     G_TRY(hipStreamSynchronize(s));
     return SC_OK;
@@ -1203,8 +1246,7 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     lap("h2d");
     // Bucketed initialisation (k_bucket_accumulate) whenever the list is dense enough for 2^dim cells to be worth a pass; the list form (sort, merge, scatter:
     // what sc_gkr_phase_one returns to a caller) otherwise, and when a bucket is too crowded.  SC_GKR_DIRECT=0 forces the list form.
-    static const bool direct_ok = !(std::getenv("SC_GKR_DIRECT") && std::atoi(std::getenv("SC_GKR_DIRECT")) == 0);
-    bool direct = direct_ok && nnz > 0 && dim <= (uint32_t)kEqMaxVars && N <= 8 * nnz + 1024;
+    bool direct = bucketed_form_pays(nnz, dim);
     hipStream_t side = s;
     if (mem.leased) {
         if (!g_cache.side && hipStreamCreateWithFlags(&g_cache.side, hipStreamNonBlocking) != hipSuccess) {

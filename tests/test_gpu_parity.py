@@ -723,3 +723,11 @@ def test_gkr_prove_bucketed_initialisation(case, monkeypatch):
         proof = sc.GKRRoundSumcheck.prove(sc.Blake2b512Rng.setup(), f1, m2, m3, g)
         assert np.array_equal(np.stack([m.evaluations for m in proof.phase1_sumcheck_msgs]), want[0]), (case, on_device)
         assert np.array_equal(np.stack([m.evaluations for m in proof.phase2_sumcheck_msgs]), want[1]), (case, on_device)
+        # the stand-alone initialisations take the same bucketed route for their dense tables (and skip the sort of an ordered list)
+        wh, wi, wv = cref.gkr_phase_one(oi, ov, dim, f3, g)
+        h_g, f1_g = sc.initialize_phase_one(f1, m3, g)
+        host = lambda a: a.cpu().numpy().view(np.uint64) if on_device else a
+        assert np.array_equal(host(h_g.evaluations), wh) and np.array_equal(host(f1_g.indices).reshape(-1), wi) and np.array_equal(host(f1_g.values), wv), (case, on_device)
+        back = f1_g if case == "sorted" else sc.SparseMultilinearExtension(2 * dim, f1_g.indices[::-1].copy() if not on_device else f1_g.indices.flip(0).contiguous(),
+                                                                             f1_g.values[::-1].copy() if not on_device else f1_g.values.flip(0).contiguous())
+        assert np.array_equal(host(sc.initialize_phase_two(back, wuv[0]).evaluations), cref.gkr_phase_two(wi, wv, dim, wuv[0])), (case, on_device)

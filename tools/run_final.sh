@@ -5,3 +5,4 @@ timeout 120 python tools/round_times.py 24 2>&1 | tail -27 > gpurun_out/r2d_roun
 timeout 900 python tools/bench_configs.py --config4 > gpurun_out/r2d_bench_configs.json 2>/dev/null; grep -c gpu_ms gpurun_out/r2d_bench_configs.json
 SC_GKR_TRACE=1 timeout 200 python tools/bench_configs.py --only-gkr 2>&1 | grep "^\[gkr\]" | tail -7 > gpurun_out/r2d_gkr_stage_trace.txt
 R=$PWD; cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r2dgkr -o gkr -- python $R/tools/bench_configs.py --only-gkr > $R/gpurun_out/prof_r2dgkr.log 2>&1; cd $R; find gpurun_out/prof_r2dgkr -name "*.db" -delete
+timeout 200 python tools/gkr_init_times.py 2>&1 | grep "dim " > gpurun_out/r2d_gkr_init_times.txt
