@@ -257,7 +257,8 @@ SC_API int sc_sparse_evaluate(const uint64_t *idx, const uint64_t *vals, uint64_
                               uint64_t *out);
 
 /* The GKR entry points keep their device scratch (about 1 GB at dim = 20) and a two-table prover handle in a process-wide
- * cache between calls (allocating and freeing them costs more than a millisecond per call).  This releases it. */
+ * cache between calls (allocating and freeing them costs more than a millisecond per call), and sc_poly_evaluate keeps its
+ * work areas (an eighth of the tables) and stream.  This releases both. */
 SC_API int sc_release_caches(void);
 
 /* ---- synthetic inputs + instrumentation (bench / tests) ------------------------------------- */

@@ -1706,7 +1706,66 @@ struct StreamGuard {
         if (s) (void)hipStreamDestroy(s);
     }
 };
+// sc_poly_evaluate's work areas and stream, kept between calls: three hipMalloc / hipFree pairs and a stream cost ~0.8 ms per call,
+// half of an evaluation at 2^24 entries and most of one at 2^20.  One call at a time holds the lease; a concurrent call (another
+// thread) allocates for itself.  sc_release_caches frees it.
+struct EvalCache {
+    std::mutex mu;
+    void *buf = nullptr;
+    size_t cap = 0;
+    int device = -1;
+    hipStream_t s = nullptr;
+};
+EvalCache g_eval_cache;
+struct EvalLease { // RAII: the cache if it is free, nothing otherwise
+    bool held = false;
+    EvalLease() : held(g_eval_cache.mu.try_lock()) {}
+    ~EvalLease() {
+        if (held) g_eval_cache.mu.unlock();
+    }
+    // a buffer of at least `bytes` and a stream on `device`, or null (the caller then allocates)
+    void *get(int device, size_t bytes, hipStream_t *s_out) {
+        if (!held) return nullptr;
+        EvalCache &c = g_eval_cache;
+        if (c.device != device) {
+            if (c.buf) (void)hipFree(c.buf);
+            if (c.s) (void)hipStreamDestroy(c.s);
+            c.buf = nullptr;
+            c.s = nullptr;
+            c.cap = 0;
+            c.device = device;
+        }
+        if (!c.s && hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            c.s = nullptr;
+            return nullptr;
+        }
+        if (c.cap < bytes) {
+            if (c.buf) (void)hipFree(c.buf);
+            c.buf = nullptr;
+            c.cap = 0;
+            if (hipMalloc(&c.buf, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                c.buf = nullptr;
+                return nullptr;
+            }
+            c.cap = bytes;
+        }
+        *s_out = c.s;
+        return c.buf;
+    }
+};
 } // namespace
+void sc_internal_release_eval_cache() { // sc_release_caches (gkr.hip)
+    std::lock_guard<std::mutex> lk(g_eval_cache.mu);
+    if (g_eval_cache.device >= 0) (void)hipSetDevice(g_eval_cache.device);
+    if (g_eval_cache.buf) (void)hipFree(g_eval_cache.buf);
+    if (g_eval_cache.s) (void)hipStreamDestroy(g_eval_cache.s);
+    g_eval_cache.buf = nullptr;
+    g_eval_cache.s = nullptr;
+    g_eval_cache.cap = 0;
+    g_eval_cache.device = -1;
+}
 
 extern "C" int sc_poly_evaluate(const sc_poly_desc *d, const uint64_t *point, uint64_t *out_value, uint64_t *out_table_values_or_null) {
     if (!d || !out_value || (d->num_vars && !point)) return fail(SC_ERR_BAD_ARG, "null argument");
@@ -1729,8 +1788,6 @@ extern "C" int sc_poly_evaluate(const sc_poly_desc *d, const uint64_t *point, ui
     if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
     DeviceGate gate_(g_device);
     HIP_TRY(hipSetDevice(g_device));
-    StreamGuard sg;
-    HIP_TRY(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
     const bool on_device = d->flags & SC_TABLES_ON_DEVICE;
     const uint64_t n = 1ULL << nv;
     // passes: three variables at a time from the LSB end, the remainder (1 or 2) last, on a table that is tiny by then
@@ -1741,20 +1798,34 @@ extern "C" int sc_poly_evaluate(const sc_poly_desc *d, const uint64_t *point, ui
         left -= l;
     }
     // device memory: staging for host tables, two ping-pong work areas (sizes after pass 1 and pass 2), the U results
-    DevMem stage, wa, wb, vals;
-    if (!on_device) HIP_TRY(hipMalloc(&stage.p, (size_t)U * n * 32));
     const uint64_t na = levels.empty() ? 1 : n >> levels[0];
     const uint64_t nb = levels.size() < 2 ? 1 : na >> levels[1];
-    HIP_TRY(hipMalloc(&wa.p, (size_t)U * na * 32));
-    HIP_TRY(hipMalloc(&wb.p, (size_t)U * nb * 32));
-    HIP_TRY(hipMalloc(&vals.p, (size_t)U * 32));
+    const size_t bytes_stage = on_device ? 0 : (size_t)U * n * 32, bytes_a = (size_t)U * na * 32, bytes_b = (size_t)U * nb * 32, bytes_v = (size_t)U * 32;
+    struct Area { // a view into the leased buffer, or an allocation of this call
+        void *p = nullptr;
+    } stage, wa, wb, vals;
+    EvalLease lease;
+    DevMem own;     // this call's allocation when the cache is taken or too small to grow
+    StreamGuard sg; // ... and its stream
+    hipStream_t s_eval = nullptr;
+    char *base = static_cast<char *>(lease.get(g_device, bytes_stage + bytes_a + bytes_b + bytes_v, &s_eval));
+    if (!base) {
+        HIP_TRY(hipMalloc(&own.p, bytes_stage + bytes_a + bytes_b + bytes_v));
+        HIP_TRY(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+        base = static_cast<char *>(own.p);
+        s_eval = sg.s;
+    }
+    stage.p = base;
+    wa.p = base + bytes_stage;
+    wb.p = base + bytes_stage + bytes_a;
+    vals.p = base + bytes_stage + bytes_a + bytes_b;
     std::vector<const uint4 *> cur(U);
     for (uint32_t u = 0; u < U; ++u) {
         if (on_device) {
             cur[u] = reinterpret_cast<const uint4 *>(d->tables[u]);
         } else {
             uint4 *dst = static_cast<uint4 *>(stage.p) + 2 * n * u;
-            HIP_TRY(hipMemcpyAsync(dst, d->tables[u], n * 32, hipMemcpyHostToDevice, sg.s));
+            HIP_TRY(hipMemcpyAsync(dst, d->tables[u], n * 32, hipMemcpyHostToDevice, s_eval));
             cur[u] = dst;
         }
     }
@@ -1778,18 +1849,18 @@ extern "C" int sc_poly_evaluate(const sc_poly_desc *d, const uint64_t *point, ui
                 for (int dbl = 0; dbl < 5; ++dbl) r32v = sch::add(r32v, r32v);
                 fa.r32[l] = to_dev(r32v);
             }
-            HIP_TRY(scd::launch_fold_multi(fa, L, (int)cnt, m, sg.s));
+            HIP_TRY(scd::launch_fold_multi(fa, L, (int)cnt, m, s_eval));
             for (uint32_t j = 0; j < cnt; ++j) cur[u0 + j] = fa.dst[j];
         }
         var += L;
     }
     std::vector<sch::Fr> tv(U);
     if (levels.empty()) { // zero variables: a table is its single entry
-        for (uint32_t u = 0; u < U; ++u) HIP_TRY(hipMemcpyAsync(&tv[u], cur[u], 32, hipMemcpyDeviceToHost, sg.s));
+        for (uint32_t u = 0; u < U; ++u) HIP_TRY(hipMemcpyAsync(&tv[u], cur[u], 32, hipMemcpyDeviceToHost, s_eval));
     } else {
-        HIP_TRY(hipMemcpyAsync(tv.data(), vals.p, (size_t)U * 32, hipMemcpyDeviceToHost, sg.s));
+        HIP_TRY(hipMemcpyAsync(tv.data(), vals.p, (size_t)U * 32, hipMemcpyDeviceToHost, s_eval));
     }
-    HIP_TRY(hipStreamSynchronize(sg.s));
+    HIP_TRY(hipStreamSynchronize(s_eval));
     sch::Fr acc = sch::zero();
     for (uint32_t k = 0; k < d->n_products; ++k) {
         sch::Fr pr;

@@ -41,6 +41,7 @@ int sc_internal_fail(int code, const char *fmt, ...); // api.hip
 void sc_internal_gate_lock(int device);                // api.hip: the device gate (serialises the library's HIP calls per device)
 void sc_internal_gate_unlock(int device);
 int sc_internal_device();                             // api.hip: the calling thread's device (sc_set_device)
+void sc_internal_release_eval_cache();                // api.hip: sc_poly_evaluate's cached work areas
 int sc_internal_run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_t *out_msgs, sch::Fr *out_challenges); // api.hip
 struct sc_rng {
     sch::Blake2b512Rng rng;
@@ -518,6 +519,7 @@ void DevBuf::release_lease() {
 }
 
 extern "C" int sc_release_caches(void) {
+    sc_internal_release_eval_cache();
     std::lock_guard<std::mutex> lk(g_cache.mu);
     if (g_cache.device >= 0) (void)hipSetDevice(g_cache.device);
     if (g_cache.prover) sc_prover_free(g_cache.prover);
