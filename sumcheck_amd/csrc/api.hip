@@ -1588,107 +1588,7 @@ extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_nu
 }
 
 // ---------------------------------------------------------------------------------------------------
-// DenseMultilinearExtension::fix_variables
-// ---------------------------------------------------------------------------------------------------
-extern "C" int sc_fix_variables(const uint64_t *in, uint32_t nv, const uint64_t *point, uint32_t k, uint64_t *out, uint32_t flags) {
-    if (!in || !out || (k && !point)) return fail(SC_ERR_BAD_ARG, "null argument");
-    if (k > nv || nv > 40) return fail(SC_ERR_BAD_ARG, "invalid partial point dimension"); // ark-poly's assert
-    if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
-    DeviceGate gate_(g_device);
-    HIP_TRY(hipSetDevice(g_device));
-    const bool on_device = flags & SC_TABLES_ON_DEVICE;
-    const uint64_t n = 1ULL << nv;
-    hipStream_t s;
-    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    void *a = nullptr;
-    int rc = SC_OK;
-    auto cleanup = [&]() {
-        if (a) (void)hipFree(a);
-        (void)hipStreamDestroy(s);
-    };
-#define FV_TRY(expr)                                                                                                    \
-    do {                                                                                                                \
-        hipError_t e_ = (expr);                                                                                         \
-        if (e_ != hipSuccess) {                                                                                         \
-            rc = fail(e_ == hipErrorOutOfMemory ? SC_ERR_OOM : SC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-            cleanup();                                                                                                  \
-            return rc;                                                                                                  \
-        }                                                                                                               \
-    } while (0)
-    void *w[2] = {nullptr, nullptr}; // ping-pong work buffers: w[0] holds n/2, w[1] holds n/4
-    auto cleanup_w = [&]() {
-        if (w[0]) (void)hipFree(w[0]);
-        if (w[1]) (void)hipFree(w[1]);
-    };
-    const uint4 *cur;
-    if (on_device) {
-        cur = reinterpret_cast<const uint4 *>(in);
-    } else {
-        FV_TRY(hipMalloc(&a, n * 32));
-        FV_TRY(hipMemcpyAsync(a, in, n * 32, hipMemcpyHostToDevice, s));
-        cur = static_cast<const uint4 *>(a);
-    }
-    uint64_t m = n;
-    for (uint32_t i = 0; i < k; ++i) {
-        sch::Fr r;
-        std::memcpy(&r, point + 4 * i, 32);
-        if (sch::geq_p(r)) {
-            rc = fail(SC_ERR_BAD_ARG, "point[%u] is not a canonical field element", i);
-            cleanup_w();
-            cleanup();
-            return rc;
-        }
-        m >>= 1;
-        uint4 *target;
-        if (i + 1 == k && on_device) {
-            target = reinterpret_cast<uint4 *>(out);
-        } else {
-            if (!w[i & 1]) {
-                hipError_t e_ = hipMalloc(&w[i & 1], std::max<uint64_t>(m, 1) * 32);
-                if (e_ != hipSuccess) {
-                    rc = fail(SC_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e_));
-                    cleanup_w();
-                    cleanup();
-                    return rc;
-                }
-            }
-            target = static_cast<uint4 *>(w[i & 1]);
-        }
-        hipError_t e_ = scd::launch_fix(cur, target, to_dev(r), m, s);
-        if (e_ != hipSuccess) {
-            rc = fail(SC_ERR_HIP, "launch_fix failed: %s", hipGetErrorString(e_));
-            cleanup_w();
-            cleanup();
-            return rc;
-        }
-        cur = target;
-    }
-    if (!(k > 0 && on_device)) {
-        hipError_t e_ = hipMemcpyAsync(out, cur, m * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s);
-        if (e_ == hipSuccess) e_ = hipStreamSynchronize(s);
-        if (e_ != hipSuccess) {
-            rc = fail(SC_ERR_HIP, "copy-out failed: %s", hipGetErrorString(e_));
-            cleanup_w();
-            cleanup();
-            return rc;
-        }
-    }
-    {
-        hipError_t e_ = hipStreamSynchronize(s);
-        cleanup_w();
-        if (e_ != hipSuccess) {
-            rc = fail(SC_ERR_HIP, "sync failed: %s", hipGetErrorString(e_));
-            cleanup();
-            return rc;
-        }
-    }
-    FV_TRY(hipStreamSynchronize(s));
-    cleanup();
-#undef FV_TRY
-    return SC_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
+// DenseMultilinearExtension::fix_variables (below, next to evaluate: both are passes of k_fold_multi) and
 // ListOfProductsOfPolynomials::evaluate (data_structures.rs:99-109): sum_k c_k prod_j T_j(point).
 // The U table evaluations run on the device, three variables per pass (kernels.h: FoldArgs); the K + sum m_k
 // scalar products that combine them are host work.
@@ -1765,6 +1665,73 @@ void sc_internal_release_eval_cache() { // sc_release_caches (gkr.hip)
     g_eval_cache.s = nullptr;
     g_eval_cache.cap = 0;
     g_eval_cache.device = -1;
+}
+
+extern "C" int sc_fix_variables(const uint64_t *in, uint32_t nv, const uint64_t *point, uint32_t k, uint64_t *out, uint32_t flags) {
+    if (!in || !out || (k && !point)) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (k > nv || nv > 40) return fail(SC_ERR_BAD_ARG, "invalid partial point dimension"); // ark-poly's assert
+    std::vector<sch::Fr> pt(k);
+    for (uint32_t i = 0; i < k; ++i) {
+        std::memcpy(&pt[i], point + 4 * i, 32);
+        if (sch::geq_p(pt[i])) return fail(SC_ERR_BAD_ARG, "point[%u] is not a canonical field element", i);
+    }
+    if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    DeviceGate gate_(g_device);
+    HIP_TRY(hipSetDevice(g_device));
+    const bool on_device = flags & SC_TABLES_ON_DEVICE;
+    const uint64_t n = 1ULL << nv;
+    // The k variables are bound three per pass (k_fold_multi: 8 entries in, 1 out, the order of ark-poly's fix_variables), so the table
+    // moves (1 + 1/8 + ...) x its size instead of once per variable.  Work areas: the outputs of passes 1 and 2 (ping-pong from there on),
+    // plus a staging copy of a host table; leased from sc_poly_evaluate's cache when it is free.
+    std::vector<int> levels;
+    for (uint32_t left = k; left > 0;) {
+        const int l = left >= 3 ? 3 : (int)left;
+        levels.push_back(l);
+        left -= l;
+    }
+    const uint64_t na = levels.empty() ? 1 : n >> levels[0];
+    const uint64_t nb = levels.size() < 2 ? 1 : na >> levels[1];
+    const size_t bytes_stage = on_device ? 0 : (size_t)n * 32, bytes_a = (size_t)na * 32, bytes_b = (size_t)nb * 32;
+    EvalLease lease;
+    DevMem own;
+    StreamGuard sg;
+    hipStream_t s = nullptr;
+    char *base = static_cast<char *>(lease.get(g_device, bytes_stage + bytes_a + bytes_b, &s));
+    if (!base) {
+        HIP_TRY(hipMalloc(&own.p, bytes_stage + bytes_a + bytes_b));
+        HIP_TRY(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+        base = static_cast<char *>(own.p);
+        s = sg.s;
+    }
+    uint4 *area[2] = {reinterpret_cast<uint4 *>(base + bytes_stage), reinterpret_cast<uint4 *>(base + bytes_stage + bytes_a)};
+    const uint4 *cur = reinterpret_cast<const uint4 *>(in);
+    if (!on_device) {
+        HIP_TRY(hipMemcpyAsync(base, in, n * 32, hipMemcpyHostToDevice, s));
+        cur = reinterpret_cast<const uint4 *>(base);
+    }
+    uint64_t m = n;
+    uint32_t var = 0;
+    for (size_t ps = 0; ps < levels.size(); ++ps) {
+        const int L = levels[ps];
+        m >>= L;
+        const bool last = ps + 1 == levels.size();
+        scd::FoldArgs fa;
+        std::memset(&fa, 0, sizeof(fa));
+        fa.src[0] = cur;
+        fa.dst[0] = (last && on_device) ? reinterpret_cast<uint4 *>(out) : area[ps & 1];
+        for (int l = 0; l < L; ++l) {
+            sch::Fr r32v = pt[var + l]; // r * 2^5 for the 2^261-radix arithmetic
+            for (int dbl = 0; dbl < 5; ++dbl) r32v = sch::add(r32v, r32v);
+            fa.r32[l] = to_dev(r32v);
+        }
+        HIP_TRY(scd::launch_fold_multi(fa, L, 1, m, s));
+        cur = fa.dst[0];
+        var += L;
+    }
+    if (!(k > 0 && on_device)) // (nothing bound: the table itself; host tables: the result comes back)
+        HIP_TRY(hipMemcpyAsync(out, cur, m * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SC_OK;
 }
 
 extern "C" int sc_poly_evaluate(const sc_poly_desc *d, const uint64_t *point, uint64_t *out_value, uint64_t *out_table_values_or_null) {
