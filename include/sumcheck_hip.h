@@ -179,6 +179,9 @@ SC_API void sc_rng_sample_fr(sc_rng *rng, uint64_t *out);                       
  * proof is void") -- reset the handle with its tables and prove again.  SC_PIPELINE=0 in the environment (or a runtime that serialises kernel launches, e.g. a counter-collecting
  * profiler, detected by a probe) turns all of it off: every round is then launched after its challenge is known. */
 SC_API int sc_ml_prove(const sc_poly_desc *desc, sc_rng *rng_or_null, uint64_t *out_proof, sc_prover **out_state_or_null);
+/* (One-shot use -- MLSumcheck::prove(&poly) in a loop -- does not pay for a prover per call: the library keeps the last one it built
+ * here and rewinds it onto the next polynomial of the same structure; with out_state_or_null == NULL device tables are read in
+ * place.  sc_release_caches gives the memory back.) */
 /* n_rounds x (prove_round, feed, sample) of that loop (mod.rs:57-64) on a handle at round 0, continuing `rng` without feeding
  * PolynomialInfo: the last log2 G rounds of a sharded proof, on the gathered G-entry tables.  out_randomness: n_rounds x 4. */
 SC_API int sc_ml_prove_rounds(sc_prover *p, sc_rng *rng, uint32_t n_rounds, uint64_t *out_proof, uint64_t *out_randomness);
@@ -257,8 +260,9 @@ SC_API int sc_sparse_evaluate(const uint64_t *idx, const uint64_t *vals, uint64_
                               uint64_t *out);
 
 /* The GKR entry points keep their device scratch (about 1 GB at dim = 20) and a two-table prover handle in a process-wide
- * cache between calls (allocating and freeing them costs more than a millisecond per call), and sc_poly_evaluate keeps its
- * work areas (an eighth of the tables) and stream.  This releases both. */
+ * cache between calls (allocating and freeing them costs more than a millisecond per call), sc_poly_evaluate / sc_fix_variables keep
+ * their work areas (an eighth of the tables) and stream, and sc_ml_prove keeps the last prover it built (bound-table buffers of
+ * at most 16 GiB) for the next one-shot proof of the same shape.  This releases all of it. */
 SC_API int sc_release_caches(void);
 
 /* ---- synthetic inputs + instrumentation (bench / tests) ------------------------------------- */

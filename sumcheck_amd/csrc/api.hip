@@ -220,6 +220,8 @@ struct sc_prover {
     FrHost *d_mail = nullptr;       // device-memory copy of the slot in use (two slots), filled by the wait kernel
     uint32_t *d_tail_sync = nullptr; // persistent tail kernel: 4 sync words + 2 challenge slots (device)
     int tail_max_blocks = 0;        // blocks of it the device holds at once (its grid never exceeds that)
+    uint64_t arena_bytes = 0;       // size of the bound-table arena (what a pooled handle keeps allocated)
+    std::vector<uint8_t> pool_key;  // non-empty: created by sc_ml_prove; sc_prover_free offers it back to the pool (handle_pool_*)
     uint32_t n_retries = 0;         // proofs repeated after an expired device-side wait (sc_ml_prove_handle)
     bool pipeline_ok = true;        // cleared when the wait-value path is unavailable (or SC_PIPELINE=0)
     bool deferred_pending = false;  // a round is enqueued behind the wait and still needs its challenge
@@ -300,7 +302,11 @@ static void prover_destroy(sc_prover *p) {
     delete p;
 }
 
-extern "C" void sc_prover_free(sc_prover *p) { prover_destroy(p); }
+static bool handle_pool_offer(sc_prover *p);
+extern "C" void sc_prover_free(sc_prover *p) {
+    if (p && handle_pool_offer(p)) return; // (a handle sc_ml_prove built: kept for the next proof of the same shape)
+    prover_destroy(p);
+}
 
 static int validate_desc(const sc_poly_desc *d) {
     if (!d) return fail(SC_ERR_BAD_ARG, "null descriptor");
@@ -466,6 +472,7 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     const uint64_t s1 = small_foot ? std::max<uint64_t>(n >> 2, 1) : std::max<uint64_t>(n >> 1, 1);
     const uint64_t per_table = (s0 + s1) * 36; // 32 B main + 4 B limb-8 array per element (internal F29 format)
     HIP_TRY(hipMalloc(&p->arena, per_table * p->U));
+    p->arena_bytes = per_table * p->U;
     p->tabs.resize(p->U);
     p->borrow = borrow;
     // Device tables are copied on the handle's own non-blocking stream, which is ordered after nothing the caller enqueued:
@@ -1900,19 +1907,98 @@ extern "C" int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *o
     return SC_OK;
 }
 
+// One-shot proofs (MLSumcheck::prove(&poly) in a loop, the reference's calling convention) would build and free a prover per call:
+// device and pinned allocations, events, a stream, metadata uploads -- 2 ms against a 0.4 ms proof at 2^16 entries.  The last
+// prover sc_ml_prove built is therefore kept (one, process-wide, arena at most kPoolMaxArena) and the next call with the same
+// polynomial STRUCTURE on the same device rewinds it onto the new tables (sc_prover_reset) instead.  A handle that left through
+// out_state comes back when the caller frees it.  sc_release_caches frees the kept one.
+constexpr uint64_t kPoolMaxArena = 16ULL << 30; // (of 288 GB; building and freeing a 4.5 GB arena costs 3 ms)
+struct HandlePool {
+    std::mutex mu;
+    sc_prover *h = nullptr;
+};
+static HandlePool g_pool;
+static std::vector<uint8_t> pool_key_of(const sc_poly_desc *d, int device) {
+    std::vector<uint8_t> k;
+    auto put = [&](const void *p, size_t n) {
+        const uint8_t *b = static_cast<const uint8_t *>(p);
+        k.insert(k.end(), b, b + n);
+    };
+    const uint32_t head[6] = {d->num_vars, d->max_multiplicands, d->n_products, d->n_tables, d->flags, (uint32_t)device};
+    put(head, sizeof(head));
+    if (d->n_products) {
+        put(d->prod_offsets, (size_t)(d->n_products + 1) * 4);
+        put(d->prod_indices, (size_t)d->prod_offsets[d->n_products] * 4);
+        put(d->coeffs, (size_t)d->n_products * 32);
+    }
+    return k;
+}
+static sc_prover *handle_pool_take(const std::vector<uint8_t> &key) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    if (!g_pool.h || g_pool.h->pool_key != key) return nullptr;
+    sc_prover *p = g_pool.h;
+    g_pool.h = nullptr;
+    return p;
+}
+static bool handle_pool_offer(sc_prover *p) {
+    if (p->pool_key.empty() || p->arena_bytes > kPoolMaxArena || p->streamed) return false;
+    sc_prover *old = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        old = g_pool.h;
+        g_pool.h = p;
+    }
+    if (old) prover_destroy(old);
+    return true;
+}
+void sc_internal_release_handle_pool() { // sc_release_caches (gkr.hip)
+    sc_prover *old = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        old = g_pool.h;
+        g_pool.h = nullptr;
+    }
+    if (old) prover_destroy(old);
+}
+
 extern "C" int sc_ml_prove(const sc_poly_desc *desc, sc_rng *rng_or_null, uint64_t *out_proof, sc_prover **out_state_or_null) {
     if (!desc || !out_proof) return fail(SC_ERR_BAD_ARG, "null argument");
     if (out_state_or_null) *out_state_or_null = nullptr;
-    sc_prover *p = nullptr;
-    int rc = sc_prover_init(desc, &p); // prover_init panics on a constant before anything is proved (prover.rs:50-52)
+    int rc = validate_desc(desc); // prover_init panics on a constant before anything is proved (prover.rs:50-52)
     if (rc) return rc;
+    sc_poly_desc eff = *desc;
+    // Without a state to hand back the prover does not outlive this call, and it never writes a caller's table: device tables are
+    // read in place instead of being copied first (their producers are waited for, as a copy would).
+    if (!out_state_or_null && (eff.flags & SC_TABLES_ON_DEVICE) && !(eff.flags & SC_TABLES_BORROW)) {
+        if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+        DeviceGate gate_(g_device);
+        HIP_TRY(hipSetDevice(g_device));
+        HIP_TRY(hipDeviceSynchronize());
+        eff.flags |= SC_TABLES_BORROW;
+    }
+    const std::vector<uint8_t> key = pool_key_of(&eff, g_device);
+    sc_prover *p = handle_pool_take(key);
+    if (p) {
+        rc = sc_prover_reset(p, eff.tables, eff.flags & SC_TABLES_ON_DEVICE);
+        if (rc) { // (a kept handle that cannot be rewound is not worth keeping)
+            p->pool_key.clear();
+            prover_destroy(p);
+            p = nullptr;
+        }
+    }
+    if (!p) {
+        rc = sc_prover_init(&eff, &p);
+        if (rc) return rc;
+        p->pool_key = key;
+    }
     rc = sc_ml_prove_handle(p, rng_or_null, out_proof);
     if (rc) {
+        p->pool_key.clear();
         prover_destroy(p);
         return rc;
     }
     if (out_state_or_null) *out_state_or_null = p;
-    else prover_destroy(p);
+    else sc_prover_free(p);
     return SC_OK;
 }
 

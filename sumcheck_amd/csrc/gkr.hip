@@ -42,6 +42,7 @@ void sc_internal_gate_lock(int device);                // api.hip: the device ga
 void sc_internal_gate_unlock(int device);
 int sc_internal_device();                             // api.hip: the calling thread's device (sc_set_device)
 void sc_internal_release_eval_cache();                // api.hip: sc_poly_evaluate's cached work areas
+void sc_internal_release_handle_pool();               // api.hip: the prover sc_ml_prove keeps between one-shot proofs
 int sc_internal_run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_t *out_msgs, sch::Fr *out_challenges); // api.hip
 struct sc_rng {
     sch::Blake2b512Rng rng;
@@ -520,6 +521,7 @@ void DevBuf::release_lease() {
 
 extern "C" int sc_release_caches(void) {
     sc_internal_release_eval_cache();
+    sc_internal_release_handle_pool();
     std::lock_guard<std::mutex> lk(g_cache.mu);
     if (g_cache.device >= 0) (void)hipSetDevice(g_cache.device);
     if (g_cache.prover) sc_prover_free(g_cache.prover);

@@ -341,7 +341,14 @@ class MLSumcheck:
 
     @staticmethod
     def prove(polynomial: ListOfProductsOfPolynomials) -> List[ProverMsg]:  # mod.rs:42-45
-        return MLSumcheck.prove_as_subprotocol(Blake2b512Rng.setup(), polynomial)[0]
+        """No prover state is returned, so the library reads device-resident tables in place and keeps the prover it built for the
+        next proof of the same shape (sc_ml_prove with a null state pointer)."""
+        d, keep = polynomial._desc(False)
+        D = polynomial.max_multiplicands + 1
+        proof = np.empty((max(polynomial.num_variables, 1), D, 4), dtype=np.uint64)
+        check(lib().sc_ml_prove(C.byref(d), None, _ptr(proof), None))  # null rng = a fresh Blake2b512Rng::setup()
+        del keep
+        return [ProverMsg(proof[i].copy()) for i in range(polynomial.num_variables)]
 
     @staticmethod
     def prove_as_subprotocol(fs_rng: Blake2b512Rng, polynomial: ListOfProductsOfPolynomials, borrow: bool = False):

@@ -731,3 +731,27 @@ def test_gkr_prove_bucketed_initialisation(case, monkeypatch):
         back = f1_g if case == "sorted" else sc.SparseMultilinearExtension(2 * dim, f1_g.indices[::-1].copy() if not on_device else f1_g.indices.flip(0).contiguous(),
                                                                              f1_g.values[::-1].copy() if not on_device else f1_g.values.flip(0).contiguous())
         assert np.array_equal(host(sc.initialize_phase_two(back, wuv[0]).evaluations), cref.gkr_phase_two(wi, wv, dim, wuv[0])), (case, on_device)
+
+
+def test_one_shot_proofs_reuse_the_kept_prover():
+    """MLSumcheck.prove in a loop (sc_ml_prove with no state returned): the library keeps the prover it built and rewinds it onto the
+    next polynomial of the same structure -- different tables each time, host and device tables, a different structure in between,
+    a state handed out and freed -- every proof against the oracle; sc_release_caches in the middle."""
+    import torch
+    nv = 12
+    shapes_a, shapes_b = [[0, 1, 2], [1, 3]], [[0, 1], [2, 2, 3]]
+    for it, (shapes, dev) in enumerate([(shapes_a, "cuda:0"), (shapes_a, "cuda:0"), (shapes_a, None), (shapes_b, "cuda:0"), (shapes_a, "cuda:0"),
+                                        (shapes_a, None), (shapes_a, None)]):
+        tabs = [cref.synth_table(600 + it, s, 1 << nv) for s in range(4)]
+        coefs = cref.synth_table(600, 1000, len(shapes))  # same coefficients: same structure
+        want, wrand = cref.ml_prove(H.desc_from(nv, shapes, tabs, coefs), threads=4)
+        poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device=dev)
+        got = np.stack([m.evaluations for m in sc.MLSumcheck.prove(poly)])
+        assert np.array_equal(got, want), it
+        if it == 1:  # a state that leaves and comes back through sc_prover_free
+            proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly)
+            assert np.array_equal(np.stack([m.evaluations for m in proof]), want) and np.array_equal(state.randomness, wrand)
+            del state
+        if it == 4:
+            _lib.check(sc.lib().sc_release_caches())
+    torch.cuda.synchronize()
