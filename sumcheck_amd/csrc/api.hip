@@ -555,11 +555,23 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     return SC_OK;
 }
 
+static std::vector<uint8_t> pool_key_of(const sc_poly_desc *d, int device);
+static sc_prover *handle_pool_take(const std::vector<uint8_t> &key);
 extern "C" int sc_prover_init(const sc_poly_desc *desc, sc_prover **out) {
     if (!out) return fail(SC_ERR_BAD_ARG, "null out");
     *out = nullptr;
     int rc = validate_desc(desc);
     if (rc) return rc;
+    // a freed prover of the same structure on this device, if the pool has one (see handle_pool_*: built once, rewound afterwards)
+    std::vector<uint8_t> key = pool_key_of(desc, g_device);
+    if (sc_prover *kept = handle_pool_take(key)) {
+        if (sc_prover_reset(kept, desc->tables, desc->flags & SC_TABLES_ON_DEVICE) == SC_OK) {
+            *out = kept;
+            return SC_OK;
+        }
+        kept->pool_key.clear();
+        prover_destroy(kept);
+    }
     sc_prover *p = new (std::nothrow) sc_prover();
     if (!p) return fail(SC_ERR_OOM, "host allocation failed");
     rc = prover_build(desc, p);
@@ -567,6 +579,7 @@ extern "C" int sc_prover_init(const sc_poly_desc *desc, sc_prover **out) {
         prover_destroy(p);
         return rc;
     }
+    p->pool_key = std::move(key);
     *out = p;
     return SC_OK;
 }
@@ -1907,11 +1920,11 @@ extern "C" int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *o
     return SC_OK;
 }
 
-// One-shot proofs (MLSumcheck::prove(&poly) in a loop, the reference's calling convention) would build and free a prover per call:
-// device and pinned allocations, events, a stream, metadata uploads -- 2 ms against a 0.4 ms proof at 2^16 entries.  The last
-// prover sc_ml_prove built is therefore kept (one, process-wide, arena at most kPoolMaxArena) and the next call with the same
-// polynomial STRUCTURE on the same device rewinds it onto the new tables (sc_prover_reset) instead.  A handle that left through
-// out_state comes back when the caller frees it.  sc_release_caches frees the kept one.
+// One-shot proofs (MLSumcheck::prove(&poly) in a loop, the reference's calling convention) and interactive provers (prover_init,
+// prove_round x n, drop) would build and free a prover per use: device and pinned allocations, events, a stream, metadata uploads --
+// 2 ms against a 0.4 ms proof at 2^16 entries.  The last prover that was freed is therefore kept (one, process-wide, arena at most
+// kPoolMaxArena) and the next sc_prover_init / sc_ml_prove with the same polynomial STRUCTURE on the same device rewinds it onto the
+// new tables (sc_prover_reset) instead.  sc_release_caches frees the kept one.
 constexpr uint64_t kPoolMaxArena = 16ULL << 30; // (of 288 GB; building and freeing a 4.5 GB arena costs 3 ms)
 struct HandlePool {
     std::mutex mu;
@@ -1942,6 +1955,9 @@ static sc_prover *handle_pool_take(const std::vector<uint8_t> &key) {
 }
 static bool handle_pool_offer(sc_prover *p) {
     if (p->pool_key.empty() || p->arena_bytes > kPoolMaxArena || p->streamed) return false;
+    if (p->stream != p->own_stream) return false; // (it runs on a stream of the caller's: sc_prover_set_stream)
+    abandon_deferred(p);                          // nothing of it may still be waiting in the queue
+    if (p->timing) (void)sc_prover_set_timing(p, 0);
     sc_prover *old = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
@@ -1976,21 +1992,9 @@ extern "C" int sc_ml_prove(const sc_poly_desc *desc, sc_rng *rng_or_null, uint64
         HIP_TRY(hipDeviceSynchronize());
         eff.flags |= SC_TABLES_BORROW;
     }
-    const std::vector<uint8_t> key = pool_key_of(&eff, g_device);
-    sc_prover *p = handle_pool_take(key);
-    if (p) {
-        rc = sc_prover_reset(p, eff.tables, eff.flags & SC_TABLES_ON_DEVICE);
-        if (rc) { // (a kept handle that cannot be rewound is not worth keeping)
-            p->pool_key.clear();
-            prover_destroy(p);
-            p = nullptr;
-        }
-    }
-    if (!p) {
-        rc = sc_prover_init(&eff, &p);
-        if (rc) return rc;
-        p->pool_key = key;
-    }
+    sc_prover *p = nullptr;
+    rc = sc_prover_init(&eff, &p); // (takes the kept prover when the structure matches)
+    if (rc) return rc;
     rc = sc_ml_prove_handle(p, rng_or_null, out_proof);
     if (rc) {
         p->pool_key.clear();
