@@ -6,3 +6,6 @@ timeout 900 python tools/bench_configs.py --config4 > gpurun_out/r2d_bench_confi
 SC_GKR_TRACE=1 timeout 200 python tools/bench_configs.py --only-gkr 2>&1 | grep "^\[gkr\]" | tail -7 > gpurun_out/r2d_gkr_stage_trace.txt
 R=$PWD; cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r2dgkr -o gkr -- python $R/tools/bench_configs.py --only-gkr > $R/gpurun_out/prof_r2dgkr.log 2>&1; cd $R; find gpurun_out/prof_r2dgkr -name "*.db" -delete
 timeout 200 python tools/gkr_init_times.py 2>&1 | grep "dim " > gpurun_out/r2d_gkr_init_times.txt
+timeout 200 python tools/oneshot_time.py 2>&1 | grep "nv=" > gpurun_out/r2d_oneshot_times.txt
+timeout 100 python tools/evaluate_time.py 2>&1 | grep evaluate > gpurun_out/r2d_evaluate_times.txt; timeout 100 python tools/evaluate_time.py 20 2>&1 | grep evaluate >> gpurun_out/r2d_evaluate_times.txt
+timeout 100 python tools/fix_variables_time.py 2>&1 | grep fix_ > gpurun_out/r2d_fix_variables_times.txt; timeout 100 python tools/fix_variables_time.py 18 2>&1 | grep fix_ >> gpurun_out/r2d_fix_variables_times.txt
