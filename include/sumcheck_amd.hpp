@@ -297,8 +297,14 @@ struct MLSumcheck {
         return {std::move(proof), ProverState(h, polynomial)};
     }
     static Proof prove(const ListOfProductsOfPolynomials &polynomial) { // mod.rs:42-45
-        Blake2b512Rng rng;
-        return prove_as_subprotocol(rng, polynomial).first;
+        // no state comes back: the library reads device tables in place and keeps the prover for the next proof of this shape
+        auto D = polynomial.desc();
+        const size_t nv = polynomial.num_variables, Dg = polynomial.max_multiplicands + 1;
+        std::vector<Fr> flat(std::max<size_t>(nv, 1) * Dg);
+        check(sc_ml_prove(&D->d, nullptr, flat[0].l, nullptr));
+        Proof proof(nv);
+        for (size_t i = 0; i < nv; ++i) proof[i].evaluations.assign(flat.begin() + i * Dg, flat.begin() + (i + 1) * Dg);
+        return proof;
     }
     static SubClaim verify_as_subprotocol(Blake2b512Rng &fs_rng, const PolynomialInfo &info, const Fr &claimed_sum, const Proof &proof) {
         const size_t nv = info.num_variables, Dg = info.max_multiplicands + 1;
