@@ -994,6 +994,17 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     const bool merged = !small && p->merge_rounds && !p->any_generic;
     if (merged) {
         grid = std::min(grid, scd::kRoundTreeGrid);
+        // One product per block row (k_round_tree_split / k_round1_tree_split): `grid` blocks per product.  Measured per round size on
+        // config 3 (profiles/r2e_split_rounds.txt): many small blocks for the rounds that stream tables, fewer for the short ones.
+        bool split = !p->fused_finalize;
+        int split_grid = n_pairs >= (1ULL << 21) ? 1024 : n_pairs >= (1ULL << 20) ? 768 : n_pairs >= (1ULL << 18) ? 384 : n_pairs >= (1ULL << 17) ? 256 : 192;
+#ifdef SC_EXPERIMENTS // SC_SPLIT=0: every product in every block (k_round_tree); SC_SPLIT_GRID=n: blocks per product
+        static const bool split_off = std::getenv("SC_SPLIT") && std::atoi(std::getenv("SC_SPLIT")) == 0;
+        static const int split_cap = std::getenv("SC_SPLIT_GRID") ? std::atoi(std::getenv("SC_SPLIT_GRID")) : 0;
+        if (split_off) split = false;
+        if (split_cap > 0) split_grid = split_cap;
+#endif
+        if (split) grid = std::min(scd::grid_for_pairs(n_pairs), split_grid);
         // One launch for the round.  The first factor touching a table binds and stores it (mode 1); every later factor on
         // that table -- in the same or in another product -- re-binds from the old buffer without storing (mode 3), so no
         // product reads what another one writes in this launch.
@@ -1051,7 +1062,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         ra.fin.h_flag = publish_to_host ? p->h_flag_dev : nullptr;
         ra.fin.seq = p->seq;
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[0], p->stream));
-        HIP_TRY(scd::launch_round_tree(ra, rc, n_pairs, p->d_partials, grid, p->stream));
+        HIP_TRY(scd::launch_round_tree(ra, rc, n_pairs, p->d_partials, grid, p->stream, split));
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[1], p->stream));
         scaled = 1;
         if (p->fused_finalize) finalized = true;

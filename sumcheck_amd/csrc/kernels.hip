@@ -1222,6 +1222,38 @@ __global__ __launch_bounds__(kBlock, 3) void k_round_tree(const RoundArgs R, con
 #endif // SC_EXPERIMENTS
 }
 
+// The same round with one product per block row (grid.y = product): for the big rounds with few pairs per lane the time of a launch is
+// the longest dependent chain of one lane -- all products of a pair, 41 Montgomery products for config 3 -- and splitting by product
+// cuts it to the longest product's (19) at the price of more, smaller blocks.  Same slots, same partial layout (gridDim.x blocks per
+// product), so the finalize step does not change.
+__global__ __launch_bounds__(kBlock, 3) void k_round1_tree_split(const RoundArgs R, const uint64_t n_pairs, uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    __shared__ int32_t rt[kBindLds]; // (unused: the factor loader's signature)
+    __shared__ int32_t lacc[9 * 5 * kBlock];
+    const TreeProd &T = R.prod[blockIdx.y];
+    uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x);
+    switch (T.M) {
+    case 1: tree_pass<1, true>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 2: tree_pass<2, true>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 3: tree_pass<3, true>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    default: tree_pass<4, true>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    }
+}
+__global__ __launch_bounds__(kBlock, 3) void k_round_tree_split(const RoundArgs R, const BindConst r, const uint64_t n_pairs, uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    __shared__ int32_t rt[kBindLds];
+    __shared__ int32_t lacc[9 * 5 * kBlock];
+    bind_consts_to_lds(r, rt);
+    const TreeProd &T = R.prod[blockIdx.y];
+    uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x);
+    switch (T.M) {
+    case 1: tree_pass<1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 2: tree_pass<2>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 3: tree_pass<3>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    default: tree_pass<4>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    }
+}
+
 // Round 1 of a proof as its own instantiation: no bind, canonical inputs only.  Without the bind path's registers the kernel affords
 // two pairs per iteration for products of FOUR multiplicands too (five more shared reductions per two pairs).
 __global__ __launch_bounds__(kBlock, 3) void k_round1_tree(const RoundArgs R, const uint64_t n_pairs, uint4 *__restrict__ partials) {
@@ -1690,7 +1722,7 @@ hipError_t launch_prod_tree(int M, const ProdArgs &args, const BindConst &r32, u
     }
 }
 
-hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
+hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream, bool split) {
     size_t extra_lds = 0;
 #ifdef SC_EXPERIMENTS // SC_EXTRA_LDS: unused dynamic LDS per block, to lower the number of resident blocks per CU (occupancy experiments)
     static const size_t env_lds = [] {
@@ -1702,8 +1734,16 @@ hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64
     bool round1 = args.fin.enabled == 0; // every factor read in place from a canonical table: the round-1 instantiation
     for (int q = 0; q < args.n_prod && round1; ++q)
         for (uint32_t f = 0; f < args.prod[q].M; ++f) round1 = round1 && args.prod[q].slot[f].mode == 0 && args.prod[q].slot[f].src_top == nullptr;
+    if (round1 && split) {
+        hipLaunchKernelGGL(k_round1_tree_split, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, n_pairs, (uint4 *)d_partials);
+        return hipGetLastError();
+    }
     if (round1 && extra_lds == 0) {
         hipLaunchKernelGGL(k_round1_tree, dim3(grid), dim3(kBlock), 0, stream, args, n_pairs, (uint4 *)d_partials);
+        return hipGetLastError();
+    }
+    if (split) {
+        hipLaunchKernelGGL(k_round_tree_split, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_round_tree, dim3(grid), dim3(kBlock), extra_lds, stream, args, r32, n_pairs, (uint4 *)d_partials);

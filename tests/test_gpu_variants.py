@@ -58,6 +58,7 @@ VARIANT_SHAPES = [
     {"SC_KERNEL": "3", "SC_MERGE": "0"},  # one launch per product
     {"SC_PIPELINE": "0"},                 # late rounds launched after their challenge (no persistent tail kernel, no wait kernel)
     {"SC_FUSED_FIN": "1"},                # big rounds: in-kernel two-level finalize instead of the k_finalize launch (a measured negative result)
+    {"SC_SPLIT": "0"},                    # big rounds: every product in every block (k_round_tree) instead of one product per block row
     {"SC_FIN_MB": "0"},                   # big rounds: the single-block k_finalize instead of one block per (product, node)
     {"SC_TAIL": "0"},                     # late rounds as pipelined launches behind the wait kernel (what sharded RCCL proofs use)
     {"SC_KERNEL": "3", "SC_F29": "0"},    # product tree, canonical tables
