@@ -296,7 +296,7 @@ def main():
                        "field_ops_per_step": ops, "sharding": f"high-bit x{world}" if world > 1 else "none",
                        "round_loop": round_loop},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": (f"k_round1_tree (round 1) + k_round_tree (rounds 2..{big_rounds}): all products, one launch per big round" if merged
+                         "traffic": traffic, "kernel": (f"k_round1_tree_split (round 1) + k_round_tree_split (rounds 2..{big_rounds}): all products, one launch per big round, one product per block row" if merged
                                     else f"{kname} (product {dom}, big rounds)"),
                          "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "big_rounds_GBps_incl_finalize": big_rounds_gbps, "big_rounds_ms_per_step": rounds_ms.value / args.steps,

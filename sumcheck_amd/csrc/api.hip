@@ -1004,6 +1004,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         if (split_off) split = false;
         if (split_cap > 0) split_grid = split_cap;
 #endif
+        if (p->K == 1) split_grid = std::min(split_grid, scd::kRoundTreeGrid); // (one product: one full wave of resident blocks, as before)
         if (split) grid = std::min(scd::grid_for_pairs(n_pairs), split_grid);
         // One launch for the round.  The first factor touching a table binds and stores it (mode 1); every later factor on
         // that table -- in the same or in another product -- re-binds from the old buffer without storing (mode 3), so no
