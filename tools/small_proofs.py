@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, sumcheck_amd as sc
 from oracle import cref
 from tests import helpers as H
-SHAPES = {"c3": ([[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10), "c2": ([[0, 1, 2]], 3), "gkr": ([[0, 1]], 2)}  # SC_SHAPE selects (default c3)
+SHAPES = {"c3": ([[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10), "c2": ([[0, 1, 2]], 3), "gkr": ([[0, 1]], 2), "shared": ([[0, 1, 2], [1, 3]], 4)}  # SC_SHAPE selects (default c3)
 shapes, nt = SHAPES[os.environ.get("SC_SHAPE", "c3")]
 out = []
 for nv in [int(a) for a in sys.argv[1:]] or [6, 10, 12, 14, 16]:
