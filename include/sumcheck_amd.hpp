@@ -268,6 +268,10 @@ class ProverState { // prover.rs:19-33, tables resident in HBM
     size_t n_tables_ = 0;
 };
 
+// The library keeps device memory between calls (the last prover it built, the work areas of evaluate / fix_variables, the GKR
+// scratch) so that one-shot calls cost what kept state costs; this returns all of it.
+inline void release_caches() { check(sc_release_caches()); }
+
 struct IPForMLSumcheck {
     static ProverState prover_init(const ListOfProductsOfPolynomials &polynomial) { // prover.rs:49-69
         auto D = polynomial.desc();

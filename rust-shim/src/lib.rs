@@ -83,6 +83,7 @@ extern "C" {
     pub fn sc_prover_push_randomness(p: *mut sc_prover, r: *const u64) -> c_int;
     pub fn sc_prover_state(p: *mut sc_prover, randomness: *mut u64, n_randomness: *mut u32, tables_out: *mut u64, round: *mut u32) -> c_int;
     pub fn sc_prover_free(p: *mut sc_prover);
+    pub fn sc_release_caches() -> c_int;
     pub fn sc_fix_variables(input: *const u64, nv: u32, point: *const u64, k: u32, out: *mut u64, flags: u32) -> c_int;
     pub fn sc_poly_evaluate(desc: *const sc_poly_desc, point: *const u64, out_value: *mut u64, out_table_values_or_null: *mut u64) -> c_int;
     pub fn sc_sparse_evaluate(idx: *const u64, vals: *const u64, nnz: u64, num_vars: u32, point: *const u64, out: *mut u64) -> c_int;
@@ -297,6 +298,12 @@ pub fn prove<F: Limbs4>(polynomial: &ListOfProductsOfPolynomials<F>) -> Proof<F>
     let mut proof = vec![[0u64; 4]; polynomial.num_variables.max(1) * d];
     check(unsafe { sc_ml_prove(&desc, core::ptr::null_mut(), proof.as_mut_ptr() as *mut u64, core::ptr::null_mut()) });
     proof.chunks(d).take(polynomial.num_variables).map(prover_msg).collect()
+}
+
+/// The library keeps device memory between calls so that one-shot use costs what a kept prover costs: the last prover it built (up to
+/// 16 GiB of bound-table buffers), the work areas of `evaluate` / `fix_variables`, the GKR scratch.  This gives all of it back.
+pub fn release_caches() {
+    check(unsafe { sc_release_caches() });
 }
 
 /// `ListOfProductsOfPolynomials::evaluate` (reference `src/ml_sumcheck/data_structures.rs:99-109`): the oracle query that
