@@ -840,7 +840,7 @@ static int launch_round_streamed(sc_prover *p, const uint64_t *r_or_null, bool p
                 }
             }
         }
-        HIP_TRY(scd::launch_round_tree(ra, rc, pairs_per_chunk, p->d_partials, grid, p->stream));
+        HIP_TRY(scd::launch_round_tree(ra, rc, pairs_per_chunk, p->d_partials, grid, p->stream, true));
         if (bind) { // tables no product refers to still follow the state machine
             for (uint32_t u = 0; u < p->U; ++u)
                 if (!bound[u])

@@ -186,8 +186,9 @@ hipError_t launch_prod_round_fe(int M, const ProdArgs &args, const FrHost &r32, 
 hipError_t launch_prod_tree(int M, const ProdArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid,
                             hipStream_t stream);
 // all products of a round in one launch (see RoundArgs); d_partials is the base of the partial-sum array
-// split: one product per block row (grid x n_prod blocks; `grid` partial blocks per product either way)
-hipError_t launch_round_tree(const RoundArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream, bool split = false);
+// one product per block row: grid x n_prod blocks, `grid` partial blocks per product.  (split = false, experiments build only: the
+// previous kernels, every block walking all products)
+hipError_t launch_round_tree(const RoundArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream, bool split = true);
 #ifdef SC_EXPERIMENTS // tiled variant (LDS-staged, one wavefront per node): grid from grid_for_tiles, same partial layout and scaling as _fe
 int grid_for_tiles(uint64_t n_pairs);
 hipError_t launch_round_tile(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,

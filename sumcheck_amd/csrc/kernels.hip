@@ -1132,15 +1132,14 @@ __global__ __launch_bounds__(kFinMbBlock) void k_finalize_mb(const FinMeta meta,
     finalize_message<kFinMbBlock>(prod_of, Wm, K, D, fin_lds, out, out_wide, h_out, h_flag, seq, scaled, compact ? &w_pre : nullptr);
 }
 
+#ifdef SC_EXPERIMENTS // the previous form of the big-round kernels (SC_SPLIT=0) and the in-kernel finalize experiment built on it
 // every product of the round in one launch (RoundArgs in kernels.h).
 // Experiments build only -- R.fin.enabled: the round's finalize step inside the launch.  A separate k_finalize launch costs a dispatch gap (~5 us) plus ~20 us for one block to add up 768 x 14
 // partials.  Here the blocks that finish last do it in two levels: the last block of every group of kFinGroup blocks (by block index;
 // an arrival counter per group) adds the group's partials into one set, and the block that completes the last group combines the
 // ~24 group sets into the message (finalize_body), publishes it and resets the counters for the next launch.  Everything the
 // combining block reads was released (agent scope) by its writer before the counter it acquired was incremented.
-#ifdef SC_EXPERIMENTS
 constexpr int kFinGroup = 32;
-#endif
 __global__ __launch_bounds__(kBlock, 3) void k_round_tree(const RoundArgs R, const BindConst r, const uint64_t n_pairs,
                                                        uint4 *__restrict__ partials) {
     __shared__ uint32_t sm[kBlock / 64][8];
@@ -1221,6 +1220,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_round_tree(const RoundArgs R, con
                           R.fin.h_out, R.fin.h_flag, R.fin.seq, 1);
 #endif // SC_EXPERIMENTS
 }
+#endif // SC_EXPERIMENTS
 
 // The same round with one product per block row (grid.y = product): for the big rounds with few pairs per lane the time of a launch is
 // the longest dependent chain of one lane -- all products of a pair, 41 Montgomery products for config 3 -- and splitting by product
@@ -1254,6 +1254,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_round_tree_split(const RoundArgs 
     }
 }
 
+#ifdef SC_EXPERIMENTS
 // Round 1 of a proof as its own instantiation: no bind, canonical inputs only.  Without the bind path's registers the kernel affords
 // two pairs per iteration for products of FOUR multiplicands too (five more shared reductions per two pairs).
 __global__ __launch_bounds__(kBlock, 3) void k_round1_tree(const RoundArgs R, const uint64_t n_pairs, uint4 *__restrict__ partials) {
@@ -1274,6 +1275,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_round1_tree(const RoundArgs R, co
         if (++k == n) k = 0;
     }
 }
+#endif // SC_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // The persistent tail kernel: ALL latency-bound rounds of a proof (<= kSmallRoundPairs pairs) in ONE launch.
@@ -1734,19 +1736,18 @@ hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64
     bool round1 = args.fin.enabled == 0; // every factor read in place from a canonical table: the round-1 instantiation
     for (int q = 0; q < args.n_prod && round1; ++q)
         for (uint32_t f = 0; f < args.prod[q].M; ++f) round1 = round1 && args.prod[q].slot[f].mode == 0 && args.prod[q].slot[f].src_top == nullptr;
-    if (round1 && split) {
-        hipLaunchKernelGGL(k_round1_tree_split, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, n_pairs, (uint4 *)d_partials);
+#ifdef SC_EXPERIMENTS
+    if (!split) {
+        if (round1 && extra_lds == 0) hipLaunchKernelGGL(k_round1_tree, dim3(grid), dim3(kBlock), 0, stream, args, n_pairs, (uint4 *)d_partials);
+        else hipLaunchKernelGGL(k_round_tree, dim3(grid), dim3(kBlock), extra_lds, stream, args, r32, n_pairs, (uint4 *)d_partials);
         return hipGetLastError();
     }
-    if (round1 && extra_lds == 0) {
-        hipLaunchKernelGGL(k_round1_tree, dim3(grid), dim3(kBlock), 0, stream, args, n_pairs, (uint4 *)d_partials);
-        return hipGetLastError();
-    }
-    if (split) {
-        hipLaunchKernelGGL(k_round_tree_split, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(k_round_tree, dim3(grid), dim3(kBlock), extra_lds, stream, args, r32, n_pairs, (uint4 *)d_partials);
+#else
+    (void)split;
+    (void)extra_lds;
+#endif
+    if (round1) hipLaunchKernelGGL(k_round1_tree_split, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, n_pairs, (uint4 *)d_partials);
+    else hipLaunchKernelGGL(k_round_tree_split, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
     return hipGetLastError();
 }
 
