@@ -17,9 +17,10 @@
 //   block -> k_finalize.
 //
 // Kernels, by role:
-//   k_round_tree       production big-round kernel: ONE launch per round over all products (each <= 4 multiplicands):
-//                      fe_device.hpp carry-free arithmetic, constant-multiplier bind, evaluation nodes 0,1,inf,-1,2, static
-//                      product tree, running sums in LDS, F29 internal table format.
+//   k_round_tree_split, k_round1_tree_split   production big-round kernels: ONE launch per round over all products (each <= 4
+//                      multiplicands), one product per block row: fe_device.hpp carry-free arithmetic, constant-multiplier bind,
+//                      evaluation nodes 0,1,inf,-1,2, static product tree, running sums in LDS, F29 internal table format.
+//   k_round_tree, k_round1_tree   the previous form (every block walks all products): experiments build, SC_SPLIT=0.
 //   k_prod_tree<M>     the same pass for one product per launch (SC_MERGE=0, or more than kMaxRoundProds products).
 //   k_prod_round_fe<M> fe_device.hpp arithmetic node by node (5..8 multiplicands; SC_KERNEL=0 SC_FE=1 as a cross-check).
 //   k_prod_round<M>    saturated 8 x u32 Comba arithmetic (SC_KERNEL=0 SC_FE=0) -- kept as a parity cross-check.
@@ -27,7 +28,8 @@
 //   k_fold_multi<L>    evaluation at a point: all tables, L <= 3 variables per pass (sc_poly_evaluate).
 //   k_sum_generic/k_fix  any M, any aliasing pattern; used beyond kMaxFusedM and for > 32 tables.
 //   k_fix_multi + k_sum_combos   latency-oriented pair for rounds with <= 2^16 pairs.
-//   k_finalize         partial sums -> round message (Lagrange matrix, c_k, sum over products).
+//   k_tail_rounds      every round with <= 2048 pairs in one persistent launch (grid barrier, host mailbox).
+//   k_finalize_mb, k_finalize   partial sums -> round message (Lagrange matrix, c_k, sum over products).
 #include "fr_device.hpp"
 #include "fe_device.hpp"
 #include "kernels.h"
