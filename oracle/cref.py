@@ -170,6 +170,12 @@ class Prover:
     def push_randomness(self, r: np.ndarray):
         lib().orc_prover_push_randomness(self._h, _p64(np.ascontiguousarray(r, dtype=np.uint64)))
 
+    def times(self):
+        """seconds so far in (prover_init's deep copy, fix_variables, the sums): bench.py's per-phase split"""
+        t = (C.c_double * 3)()
+        lib().orc_prover_times(self._h, t)
+        return tuple(t)
+
     def close(self):
         if self._h:
             lib().orc_prover_free(self._h)
@@ -235,6 +241,13 @@ def ml_prove(desc: PolyDesc, rng: Optional[Rng] = None, threads: int = 1):
     if rc != 0:
         raise RuntimeError({1: "Attempt to prove a constant."}.get(rc, f"oracle error {rc}"))
     return proof, rand
+
+
+def last_prove_times():
+    """(init copy, fix_variables, sums) seconds of the last ml_prove of this process"""
+    t = (C.c_double * 3)()
+    lib().orc_last_prove_times(t)
+    return tuple(t)
 
 
 def check_and_generate_subclaim(nv: int, max_mult: int, polys: np.ndarray, randomness: np.ndarray, asserted_sum: np.ndarray):

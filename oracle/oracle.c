@@ -16,12 +16,16 @@
  *
  * Each function cites the reference file:line it follows (relative to the reference repo root).
  */
+#define _POSIX_C_SOURCE 200112L
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+
+static double orc_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 typedef unsigned __int128 u128;
 typedef struct { uint64_t l[4]; } fr_t;
@@ -140,6 +144,7 @@ typedef struct {
     uint32_t n_rand;
     int threads;             /* 1 = the non-parallel build; >1 mirrors the rayon feature */
     int improved_fix;        /* 0 = fix parallel across tables only (prover.rs:87); 1 = inside tables */
+    double t_init, t_bind, t_sum; /* bench.py's per-phase split: deep copy | fix_variables | the fold of prover.rs:110-148 (seconds) */
 } orc_prover;
 
 enum { ORC_OK = 0, ORC_ERR_CONSTANT = 1, ORC_ERR_FIRST_ROUND_HAS_MSG = 2, ORC_ERR_MISSING_MSG = 3, ORC_ERR_NOT_ACTIVE = 4 };
@@ -157,10 +162,20 @@ int orc_prover_init(uint32_t num_vars, uint32_t max_multiplicands, uint32_t n_pr
     p->indices = (uint32_t *)malloc(tot * sizeof(uint32_t)); memcpy(p->indices, indices, tot * sizeof(uint32_t));
     p->tables = (fr_t **)malloc(n_tables * sizeof(fr_t *));
     size_t n = (size_t)1 << num_vars;
+    const double t0 = orc_now();
+    /* the deep copy of prover.rs:55-59.  With threads > 1 every table is copied in slices by all threads, so that its pages are
+     * first touched (and placed) by the cores that will read them; the reference's Vec::clone is one memcpy per table. */
     for (uint32_t u = 0; u < n_tables; ++u) {
         p->tables[u] = (fr_t *)malloc(n * sizeof(fr_t));
-        memcpy(p->tables[u], tables[u], n * sizeof(fr_t));
+        if (threads > 1 && n >= ((size_t)1 << 16)) {
+            const size_t slices = n >> 12; /* 128 KiB slices */
+#pragma omp parallel for num_threads(threads) schedule(static)
+            for (size_t s = 0; s < slices; ++s) memcpy(p->tables[u] + (s << 12), (const fr_t *)tables[u] + (s << 12), sizeof(fr_t) << 12);
+        } else {
+            memcpy(p->tables[u], tables[u], n * sizeof(fr_t));
+        }
     }
+    p->t_init = orc_now() - t0;
     p->randomness = (fr_t *)malloc(num_vars * sizeof(fr_t));
     p->threads = threads < 1 ? 1 : threads;
     *out = p;
@@ -195,6 +210,7 @@ int orc_prove_round(orc_prover *p, const uint64_t *r_or_null, uint64_t *out_eval
     if (r_or_null && p->round == 0) return ORC_ERR_FIRST_ROUND_HAS_MSG; /* prover.rs:79-81 */
     if (!r_or_null && p->round > 0) return ORC_ERR_MISSING_MSG;         /* prover.rs:90-92 */
     if (p->round + 1 > p->num_vars) return ORC_ERR_NOT_ACTIVE;          /* prover.rs:96-98 */
+    const double t_b0 = orc_now();
     if (r_or_null) {
         fr_t r = *(const fr_t *)r_or_null;
         p->randomness[p->n_rand++] = r;                                 /* prover.rs:82 */
@@ -208,6 +224,8 @@ int orc_prove_round(orc_prover *p, const uint64_t *r_or_null, uint64_t *out_eval
         }
     }
     p->round += 1;
+    const double t_s0 = orc_now();
+    p->t_bind += t_s0 - t_b0;
 
     const uint32_t i = p->round, nv = p->num_vars, degree = p->max_multiplicands;
     const size_t npts = (size_t)1 << (nv - i);
@@ -248,8 +266,11 @@ int orc_prove_round(orc_prover *p, const uint64_t *r_or_null, uint64_t *out_eval
     }
     memcpy(out_evals, total, D * sizeof(fr_t));
     free(total);
+    p->t_sum += orc_now() - t_s0;
     return ORC_OK;
 }
+/* seconds spent so far in: [0] prover_init's deep copy, [1] fix_variables (prover.rs:84-89), [2] the sums (prover.rs:100-153) */
+void orc_prover_times(const orc_prover *p, double out[3]) { out[0] = p->t_init; out[1] = p->t_bind; out[2] = p->t_sum; }
 
 /* ml_sumcheck/mod.rs:65-67: the last challenge is recorded but never bound */
 void orc_prover_push_randomness(orc_prover *p, const uint64_t *r) {
@@ -416,6 +437,8 @@ void orc_rng_feed_poly_info(orc_rng *r, uint64_t max_multiplicands, uint64_t num
 
 /* MLSumcheck::prove_as_subprotocol, reference src/ml_sumcheck/mod.rs:50-70.  out_proof: nv x D x 4 limbs.
  * If out_randomness != NULL receives nv x 4 limbs.  rng may be pre-fed by the caller. */
+static double g_last_prove_times[3];
+void orc_last_prove_times(double out[3]) { memcpy(out, g_last_prove_times, sizeof(g_last_prove_times)); } /* of the last orc_ml_prove on this process */
 int orc_ml_prove(orc_rng *rng, uint32_t num_vars, uint32_t max_multiplicands, uint32_t n_products, const uint64_t *coeffs,
                  const uint32_t *offsets, const uint32_t *indices, uint32_t n_tables, const uint64_t *const *tables, int threads,
                  uint64_t *out_proof, uint64_t *out_randomness) {
@@ -431,6 +454,7 @@ int orc_ml_prove(orc_rng *rng, uint32_t num_vars, uint32_t max_multiplicands, ui
     }
     orc_prover_push_randomness(p, (const uint64_t *)&vm);
     if (out_randomness) memcpy(out_randomness, p->randomness, num_vars * sizeof(fr_t));
+    orc_prover_times(p, g_last_prove_times);
     orc_prover_free(p);
     return ORC_OK;
 }

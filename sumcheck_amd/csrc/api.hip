@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <cstdarg>
@@ -198,6 +199,7 @@ struct sc_prover {
     void *d_tail_send = nullptr, *d_tail_recv = nullptr, *d_tail_tabs = nullptr; // sc_ml_prove_sharded: bind_final out, all-gather out, G-entry tables
     sc_prover *tail = nullptr;       // ... and the prover of the replicated last rounds over them (built once, rewound per proof)
     uint32_t tail_ranks = 0;
+    size_t tail_buf_bytes = 0;       // size of d_tail_recv / d_tail_tabs as allocated (d_tail_send: a G-th of it)
     std::vector<std::vector<uint32_t>> prod_indices; // the descriptor's product lists as given (for the tail's descriptor)
     Combo *d_combos = nullptr;    // (product, point) combinations for the small-round kernel
     std::vector<FinProd> h_finprods; // host copy of d_finprods (kernel-argument path of k_finalize)
@@ -903,6 +905,10 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         std::memcpy(&r, r_or_null, 32);
         if (sch::geq_p(r)) return fail(SC_ERR_BAD_ARG, "challenge is not a canonical field element");
     }
+    if (deferred) { // (every check comes before the first change to the handle)
+        const uint64_t np = 1ULL << (p->nv - (p->round + 1));
+        if (!(np <= small_pairs_limit() && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0)) return fail(SC_ERR_BAD_ARG, "only late rounds are pipelined");
+    }
     HIP_TRY(hipSetDevice(p->device));
     if (!deferred) { // (a pipelined round records no events: collecting would wait for the round before it)
         int rc_t = collect_timing(p);
@@ -936,7 +942,6 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     if (timed) HIP_TRY(hipEventRecord(p->ev0, p->stream));
     const FrHost *r_mail = nullptr;
     if (deferred) {
-        if (!small_round) return fail(SC_ERR_BAD_ARG, "only late rounds are pipelined");
         p->sig_seq += 1;
         {
             SlowCallProbe pr("launch k_wait_challenge");
@@ -1228,6 +1233,24 @@ static int await_round(sc_prover *p, uint64_t *out_evals, const uint32_t want) {
 // Usable when the round metadata fits kernel arguments (tail_shape_ok), the next round is a small one, and launches are
 // asynchronous (the kernel waits for the host; SC_PIPELINE=0 switches it off together with the pipelined rounds).
 constexpr size_t kTailSyncBytes = 4 * (16 + (size_t)scd::kTailMaxGrid);
+// ONE tail kernel per device at a time: its grid barrier needs every launched block resident, and the grid is sized for an otherwise
+// idle GPU (tail_max_resident_blocks); two of them from two proving threads could each end up partially resident and wait for
+// blocks that are never scheduled.  A prover that finds the slot taken does not wait for it: its late rounds run as pipelined
+// launches (the path every proof took before the tail kernel existed).  (The kernel's waits are bounded as well: kernels.hip, grid_barrier.)
+static std::atomic<int> g_tail_busy[64];
+struct TailSlot {
+    const int device;
+    bool held;
+    explicit TailSlot(int d) : device(d), held(false) {
+        int expect = 0;
+        held = g_tail_busy[(unsigned)device & 63u].compare_exchange_strong(expect, 1, std::memory_order_acquire);
+    }
+    ~TailSlot() {
+        if (held) g_tail_busy[(unsigned)device & 63u].store(0, std::memory_order_release);
+    }
+    TailSlot(const TailSlot &) = delete;
+    TailSlot &operator=(const TailSlot &) = delete;
+};
 static bool tail_shape_ok(const sc_prover *p) {
     return p->use_tail && p->K > 0 && p->U <= (uint32_t)scd::kMaxSmallTables && p->has_meta && p->K <= (uint32_t)scd::kMetaProds &&
            (size_t)p->K * p->D * (p->D + 2) * 32 <= 48 * 1024;
@@ -1394,8 +1417,10 @@ static int run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, 
         uint64_t *pm = out_msgs + (size_t)i * D * 4;
         const auto t0 = clk::now();
         int rc;
-        if (!enqueued && tail_possible(p)) // from here on every round is latency-bound: one persistent kernel runs them all
-            return run_tail(p, rng, n_rounds - i, have ? &vm : nullptr, pm, out_challenges_or_null ? out_challenges_or_null + i : nullptr);
+        if (!enqueued && tail_possible(p)) { // from here on every round is latency-bound: one persistent kernel runs them all
+            TailSlot slot(p->device);        // (unless another prover's tail kernel has the device: then pipelined launches, below)
+            if (slot.held) return run_tail(p, rng, n_rounds - i, have ? &vm : nullptr, pm, out_challenges_or_null ? out_challenges_or_null + i : nullptr);
+        }
         if (!enqueued) {
             rc = launch_round(p, have ? vm.l : nullptr, nullptr, true);
             if (rc) return rc;
@@ -1969,6 +1994,12 @@ static bool handle_pool_offer(sc_prover *p) {
     if (p->pool_key.empty() || p->arena_bytes > kPoolMaxArena || p->streamed) return false;
     if (p->stream != p->own_stream) return false; // (it runs on a stream of the caller's: sc_prover_set_stream)
     abandon_deferred(p);                          // nothing of it may still be waiting in the queue
+    {   // sc_prover_free promises that the handle's work is over: asynchronous calls (sc_prove_round_partial, sc_prover_bind_final) may
+        // still be reading borrowed tables or writing a caller's d_out, and after the free the caller has no stream left to wait on
+        DeviceGate gate_(p->device);
+        (void)hipSetDevice(p->device);
+        (void)hipStreamSynchronize(p->own_stream);
+    }
     if (p->timing) (void)sc_prover_set_timing(p, 0);
     sc_prover *old = nullptr;
     {
@@ -2117,6 +2148,10 @@ extern "C" int sc_interpolate_uni_poly(const uint64_t *p_i, uint32_t len, const 
 extern "C" int sc_ml_verify(uint32_t num_vars, uint32_t max_multiplicands, const uint64_t *claimed_sum, const uint64_t *proof,
                             uint64_t proof_elems, sc_rng *rng_or_null, uint64_t *out_point, uint64_t *out_expected) {
     if (!claimed_sum || !proof || !out_point || !out_expected) return fail(SC_ERR_BAD_ARG, "null argument");
+    // every message is read at [0] and [1] (verifier.rs:101-102; a one-element message makes the reference panic on the index): a
+    // polynomial without multiplicands has no valid proof, and max_multiplicands + 1 must not wrap
+    if (max_multiplicands == 0 || max_multiplicands == UINT32_MAX)
+        return fail(SC_ERR_BAD_ARG, "max_multiplicands %u: a round message needs at least two evaluations", max_multiplicands);
     const uint32_t D = max_multiplicands + 1;
     // verifier.rs:60-62 panics on a message of the wrong length; here the caller states how many elements `proof` holds
     if (proof_elems != (uint64_t)num_vars * D) return fail(SC_ERR_BAD_ARG, "incorrect number of evaluations");
@@ -2414,69 +2449,81 @@ static uint32_t sharded_tail_m(uint32_t nv_local, uint32_t k) { // log2 of the e
 }
 static int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, const uint64_t *last_challenge, uint32_t k, uint32_t m, uint64_t *out_proof,
                         uint64_t *out_randomness) {
-    DeviceGate gate_(p->device);
     const uint32_t G = (uint32_t)comm->nranks, U = p->U, per = 1u << m;
     const size_t send_bytes = (size_t)U * per * 32;
-    if (p->tail && (p->tail->nv != k + m || p->tail_ranks != G)) { // the handle meets a communicator of another size: rebuild the tail
-        prover_destroy(p->tail);
-        p->tail = nullptr;
-        (void)hipFree(p->d_tail_send);
-        (void)hipFree(p->d_tail_recv);
-        (void)hipFree(p->d_tail_tabs);
-        p->d_tail_send = p->d_tail_recv = p->d_tail_tabs = nullptr;
-    }
-    p->tail_ranks = G;
-    if (!p->d_tail_send) {
-        HIP_TRY(hipMalloc(&p->d_tail_send, send_bytes));
-        HIP_TRY(hipMalloc(&p->d_tail_recv, send_bytes * G));
-        HIP_TRY(hipMalloc(&p->d_tail_tabs, send_bytes * G));
-    }
-    int rc = prover_bind_out(p, last_challenge, reinterpret_cast<uint64_t *>(p->d_tail_send));
-    if (rc) return rc;
-    if (comm->comm) {
-        NCCL_TRY(g_nccl.AllGather(p->d_tail_send, p->d_tail_recv, send_bytes / 8, ncclUint64, comm->comm, p->stream));
-    } else {
-        std::vector<uint64_t> send(send_bytes / 8), recv(send_bytes / 8 * G);
-        HIP_TRY(hipMemcpyAsync(send.data(), p->d_tail_send, send_bytes, hipMemcpyDeviceToHost, p->stream));
-        HIP_TRY(hipStreamSynchronize(p->stream));
-        {
-            GateYield yield_(p->device, comm->nranks > 1);
-            if (comm->h_allgather(comm->ctx, send.data(), recv.data(), send_bytes) != 0) return fail(SC_ERR_HIP, "the host transport's all-gather failed");
+    int rc;
+    {
+        DeviceGate gate_(p->device); // (not across the replicated rounds below: their calls take it themselves, and a persistent tail
+                                     // kernel's host loop must never hold it)
+        HIP_TRY(hipSetDevice(p->device));
+        if (p->tail && (p->tail->nv != k + m || p->tail_ranks != G)) { // the handle meets a communicator of another size: rebuild the tail
+            prover_destroy(p->tail);
+            p->tail = nullptr;
         }
-        HIP_TRY(hipMemcpyAsync(p->d_tail_recv, recv.data(), send_bytes * G, hipMemcpyHostToDevice, p->stream));
-        HIP_TRY(hipStreamSynchronize(p->stream)); // `recv` goes out of scope
-    }
-    HIP_TRY(scd::launch_gather_to_tables(static_cast<const uint4 *>(p->d_tail_recv), static_cast<uint4 *>(p->d_tail_tabs), G, U, per, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream)); // the tail prover runs on its own stream
-    if (!p->tail) { // built once per handle: the same products over U borrowed tables of G * 2^m entries
-        std::vector<uint64_t> coeffs((size_t)p->K * 4);
-        std::vector<uint32_t> offs(1, 0), idx;
-        for (uint32_t q = 0; q < p->K; ++q) {
-            std::memcpy(&coeffs[4 * q], &p->prods[q].coeff, 32);
-            idx.insert(idx.end(), p->prod_indices[q].begin(), p->prod_indices[q].end());
-            offs.push_back((uint32_t)idx.size());
+        // the three exchange buffers follow the sizes of THIS call, whatever an earlier (possibly failed) call left behind
+        if (p->tail_buf_bytes != send_bytes * G || p->tail_ranks != G) {
+            if (p->tail) { // it borrows d_tail_tabs
+                prover_destroy(p->tail);
+                p->tail = nullptr;
+            }
+            (void)hipFree(p->d_tail_send);
+            (void)hipFree(p->d_tail_recv);
+            (void)hipFree(p->d_tail_tabs);
+            p->d_tail_send = p->d_tail_recv = p->d_tail_tabs = nullptr;
+            p->tail_buf_bytes = 0;
+            HIP_TRY(hipMalloc(&p->d_tail_send, send_bytes));
+            HIP_TRY(hipMalloc(&p->d_tail_recv, send_bytes * G));
+            HIP_TRY(hipMalloc(&p->d_tail_tabs, send_bytes * G));
+            p->tail_buf_bytes = send_bytes * G;
         }
-        std::vector<const uint64_t *> tabs(U);
-        for (uint32_t u = 0; u < U; ++u) tabs[u] = reinterpret_cast<const uint64_t *>(static_cast<char *>(p->d_tail_tabs) + (size_t)u * G * per * 32);
-        sc_poly_desc d;
-        std::memset(&d, 0, sizeof(d));
-        d.num_vars = k + m;
-        d.max_multiplicands = p->max_mult;
-        d.n_products = p->K;
-        d.coeffs = coeffs.data();
-        d.prod_offsets = offs.data();
-        d.prod_indices = idx.data();
-        d.n_tables = U;
-        d.tables = tabs.data();
-        d.flags = SC_TABLES_ON_DEVICE | SC_TABLES_BORROW;
-        const int saved = g_device;
-        g_device = p->device;
-        rc = sc_prover_init(&d, &p->tail);
-        g_device = saved;
+        p->tail_ranks = G;
+        rc = prover_bind_out(p, last_challenge, reinterpret_cast<uint64_t *>(p->d_tail_send));
         if (rc) return rc;
-    } else {
-        rc = sc_prover_reset(p->tail, nullptr, 0);
-        if (rc) return rc;
+        if (comm->comm) {
+            NCCL_TRY(g_nccl.AllGather(p->d_tail_send, p->d_tail_recv, send_bytes / 8, ncclUint64, comm->comm, p->stream));
+        } else {
+            std::vector<uint64_t> send(send_bytes / 8), recv(send_bytes / 8 * G);
+            HIP_TRY(hipMemcpyAsync(send.data(), p->d_tail_send, send_bytes, hipMemcpyDeviceToHost, p->stream));
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            {
+                GateYield yield_(p->device, comm->nranks > 1);
+                if (comm->h_allgather(comm->ctx, send.data(), recv.data(), send_bytes) != 0) return fail(SC_ERR_HIP, "the host transport's all-gather failed");
+            }
+            HIP_TRY(hipMemcpyAsync(p->d_tail_recv, recv.data(), send_bytes * G, hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(hipStreamSynchronize(p->stream)); // `recv` goes out of scope
+        }
+        HIP_TRY(scd::launch_gather_to_tables(static_cast<const uint4 *>(p->d_tail_recv), static_cast<uint4 *>(p->d_tail_tabs), G, U, per, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream)); // the tail prover runs on its own stream
+        if (!p->tail) { // built once per handle: the same products over U borrowed tables of G * 2^m entries
+            std::vector<uint64_t> coeffs((size_t)p->K * 4);
+            std::vector<uint32_t> offs(1, 0), idx;
+            for (uint32_t q = 0; q < p->K; ++q) {
+                std::memcpy(&coeffs[4 * q], &p->prods[q].coeff, 32);
+                idx.insert(idx.end(), p->prod_indices[q].begin(), p->prod_indices[q].end());
+                offs.push_back((uint32_t)idx.size());
+            }
+            std::vector<const uint64_t *> tabs(U);
+            for (uint32_t u = 0; u < U; ++u) tabs[u] = reinterpret_cast<const uint64_t *>(static_cast<char *>(p->d_tail_tabs) + (size_t)u * G * per * 32);
+            sc_poly_desc d;
+            std::memset(&d, 0, sizeof(d));
+            d.num_vars = k + m;
+            d.max_multiplicands = p->max_mult;
+            d.n_products = p->K;
+            d.coeffs = coeffs.data();
+            d.prod_offsets = offs.data();
+            d.prod_indices = idx.data();
+            d.n_tables = U;
+            d.tables = tabs.data();
+            d.flags = SC_TABLES_ON_DEVICE | SC_TABLES_BORROW;
+            const int saved = g_device;
+            g_device = p->device;
+            rc = sc_prover_init(&d, &p->tail);
+            g_device = saved;
+            if (rc) return rc;
+        } else {
+            rc = sc_prover_reset(p->tail, nullptr, 0);
+            if (rc) return rc;
+        }
     }
     // (same reasoning as in sharded_rounds: no polling kernels on a GPU that other ranks of a host transport may share)
     if (!comm->comm && comm->nranks > 1) p->tail->pipeline_ok = false;

@@ -135,6 +135,7 @@ struct ComboMeta {
 // The persistent tail kernel (kernels.hip: k_tail_rounds): every latency-bound round of a proof in one launch.
 constexpr uint64_t kTailMaxPairs = 2048; // rounds above this many pairs are throughput- rather than latency-bound: separate (pipelined) launches
                                          // with full-chip grids beat a resident grid that pays a barrier per phase (measured: 32 vs 54 us at 4096 pairs)
+static_assert(kTailMaxPairs / kBlock <= 8, "k_tail_rounds' block 0 adds up a combination's partial blocks itself: at most 8 of them");
 constexpr int kTailMaxGrid = 1024; // at most 4 resident blocks per CU (120 VGPRs), all co-resident on a 256-CU device
 constexpr int kTailFlatPairs = 16; // rounds with at most this many pairs run in block 0 alone, one lane per (combination, pair)
 struct TailTables {

@@ -1297,25 +1297,55 @@ __global__ __launch_bounds__(kBlock, 3) void k_round1_tree(const RoundArgs R, co
 // atomics on one address: ~0.1 us each, 25 us for 256 blocks), so every block raises its OWN flag word instead (plain stores to
 // distinct addresses), block 0's lanes watch one flag each, and the others watch the generation word block 0 then publishes.
 // sync layout (uint32): [0] generation [1] -- [2] challenges released [3] stop [16 ...] one flag per block
-__device__ __forceinline__ void grid_barrier(uint32_t *sync, uint32_t &gen, const uint32_t n_blocks) {
+// Every wait is BOUNDED (max_spins polls, the bound of the mailbox poll): the barrier needs all of the grid's blocks resident at once,
+// which the host guarantees for the library's own launches (one tail kernel per device at a time, grid <= what the runtime says is
+// co-resident) but cannot guarantee against other code of the process that occupies the GPU.  A block whose wait expires marks itself
+// dead (flag 0xffffffff), tells the host (give-up marker: the host voids the proof) and leaves; block 0 turns a dead or missing block
+// into the stop bit of the generation word, which releases -- and dismisses -- everybody else.  Returns false when the grid is stopping.
+constexpr uint32_t kGenStop = 0x80000000u, kFlagDead = 0xffffffffu;
+__device__ __forceinline__ bool grid_barrier(uint32_t *sync, uint32_t &gen, const uint32_t n_blocks, const uint32_t max_spins, uint32_t *giveup_host,
+                                             const uint32_t giveup_val, uint32_t &stop_sh) {
     __syncthreads();
     gen += 1;
     if (blockIdx.x == 0) {
-        for (uint32_t f = 1 + threadIdx.x; f < n_blocks; f += kBlock)
-            while (__hip_atomic_load(sync + 16 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) __builtin_amdgcn_s_sleep(1);
+        bool dead = false;
+        for (uint32_t f = 1 + threadIdx.x; f < n_blocks; f += kBlock) {
+            uint32_t v, spins = 0;
+            while ((v = __hip_atomic_load(sync + 16 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < gen) {
+                if (++spins > max_spins) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            dead |= v == kFlagDead;
+        }
+        if (dead) stop_sh = 1;
         __syncthreads();
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-            __hip_atomic_store(sync, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (stop_sh) {
+                __hip_atomic_store(sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(giveup_host, giveup_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __hip_atomic_store(sync, stop_sh ? (gen | kGenStop) : gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // this block's writes (every thread's: ordered by the barrier above) reach the device
         __hip_atomic_store(sync + 16 + blockIdx.x, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // relaxed polls (an acquire per poll would invalidate caches every time), one acquire fence at the end
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) __builtin_amdgcn_s_sleep(1);
+        uint32_t v, spins = 0;
+        while (((v = __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~kGenStop) < gen) {
+            if (++spins > max_spins) { // block 0 never came (not resident?): leave, and let it know should it ever arrive
+                __hip_atomic_store(sync + 16 + blockIdx.x, kFlagDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(giveup_host, giveup_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                v = kGenStop;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (v & kGenStop) stop_sh = 1;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    return stop_sh == 0;
 }
 
 // blocks a round of `n_pairs` pairs can use: one per 256 bind outputs, and at least one per (combination, 256 pairs) tile
@@ -1364,9 +1394,20 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                 if (threadIdx.x < 4) r_sh[threadIdx.x] = A.r0.l[threadIdx.x];
             } else if (blockIdx.x != 0) {
                 if (threadIdx.x == 0) {
-                    while (__hip_atomic_load(A.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)j) __builtin_amdgcn_s_sleep(2);
+                    // (block 0's own poll of the host is bounded by max_spins; twice that covers it, and a block 0 that is gone for good)
+                    uint32_t spins = 0;
+                    bool expired = false;
+                    while (__hip_atomic_load(A.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)j) {
+                        if (++spins > 2 * (A.max_spins / 2 + 1)) { expired = true; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     stop_sh = __hip_atomic_load(A.sync + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (expired) {
+                        __hip_atomic_store(A.sync + 16 + blockIdx.x, kFlagDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(A.sig + 1, A.sig0 + (uint32_t)j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        stop_sh = 1;
+                    }
                 }
                 __syncthreads();
                 if (threadIdx.x < 4) r_sh[threadIdx.x] = __hip_atomic_load(A.chal + 4 * (j & 1) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1401,8 +1442,8 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
             binds += 1;
             if (solo) {
                 __syncthreads();
-            } else {
-                grid_barrier(A.sync, gen, Gj);
+            } else if (!grid_barrier(A.sync, gen, Gj, A.max_spins, A.sig + 1, A.sig0 + (uint32_t)j + 1u, stop_sh)) {
+                return;
             }
         }
         if (solo) {
@@ -1444,31 +1485,9 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                 const uint32_t cy = v / vgx, vx = v % vgx;
                 sum_combo_body(tab, meta.combo[cy], meta.slot_table, meta.slot_exp, n_pairs, A.partials, sm, vx, vgx);
             }
-            grid_barrier(A.sync, gen, Gj);
-            if (vgx > 8 && Gj >= (uint32_t)(A.K * A.D)) {
-                // many partials per combination: block c adds up combination c's (all its lanes, then one block sum), so that block 0
-                // only has the K * D sums left to combine
-                const int c = blockIdx.x;
-                if (c < A.K * A.D) {
-                    const int k = c / A.D, t = c % A.D;
-                    if (t <= (int)fin.prod[k].M) {
-                        const uint4 *base = A.partials + 2 * (fin.prod[k].partial_off + (uint64_t)t * vgx);
-                        Fr acc = fr_zero();
-                        for (uint32_t bq = threadIdx.x; bq < vgx; bq += kBlock) acc = fr_add(acc, fr_load(base + 2 * bq));
-                        const Fr tot = block_sum(acc, sm);
-                        if (threadIdx.x == 0) fr_store(A.sums + 2 * c, tot);
-                    }
-                }
-                grid_barrier(A.sync, gen, Gj);
-                if (blockIdx.x == 0) {
-                    for (int c2 = threadIdx.x; c2 < A.K * A.D; c2 += kBlock) {
-                        fin_lds[2 * c2] = A.sums[2 * c2];
-                        fin_lds[2 * c2 + 1] = A.sums[2 * c2 + 1];
-                    }
-                    __syncthreads();
-                    finalize_message<kBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 0, w_pre);
-                }
-            } else if (blockIdx.x == 0) {
+            if (!grid_barrier(A.sync, gen, Gj, A.max_spins, A.sig + 1, A.sig0 + (uint32_t)j + 1u, stop_sh)) return;
+            // (vgx <= kTailMaxPairs / kBlock = 8 partials per combination: block 0 adds them up itself)
+            if (blockIdx.x == 0) {
                 finalize_body<kBlock>(prod_of, A.Wm, A.K, A.D, (int)vgx, A.partials, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag,
                                       A.seq0 + (uint32_t)j, 0, w_pre);
             }

@@ -91,6 +91,85 @@ def test_full_size_interactive_rounds_and_bound_tables_vs_oracle(nv, shapes, nt)
     assert np.array_equal(st.randomness, chal[:8])
 
 
+C4 = (28, [[0, 1, 2]], 3)  # BASELINE config 4 at its real size: 3 tables x 8 GiB
+
+
+def _mem_available_gib():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / (1 << 20)
+    except Exception:
+        pass
+    return 0.0
+
+
+def test_config4_full_size_nv28_unsharded_and_eight_thread_ranks_vs_oracle():
+    """BASELINE config 4 -- MLSumcheck prove, one product of three multilinears, nv = 28, 24 GiB of tables -- at its REAL size against
+    the oracle (shape of reference src/ml_sumcheck/test.rs:64-75: prove, then check every message):
+      (a) sc_ml_prove_sharded with G = 8 thread ranks on GPU 0 over the host transport, every rank borrowing its nv = 25 slice of the
+          three device-generated tables (the index arithmetic of the 8-GPU run: slices at > 2^32-byte offsets, 13 sharded rounds, the early
+          gather with m = 12, k = 3, 15 replicated rounds) -- whole Fiat-Shamir proof and randomness, identical on every rank;
+      (b) the same instance unsharded on one handle (one MI355X holds it);
+    both bit for bit equal to cref.ml_prove on the D2H'd tables.  Needs ~60 GiB of host memory for the oracle (tables + its deep copy
+    + round 2) and ~50 GiB of HBM."""
+    import threading
+
+    import torch
+    from sumcheck_amd import sharded
+    nv, shapes, nt = C4
+    if _mem_available_gib() < 80:
+        pytest.skip(f"config 4's oracle run needs ~60 GiB of host memory; MemAvailable = {_mem_available_gib():.0f} GiB")
+    sc.lib().sc_release_caches()
+    torch.cuda.empty_cache()
+    poly, mles, coefs = _device_poly(nv, shapes, nt, SEED)
+    d = _oracle_desc(nv, shapes, mles, coefs)
+    want, wrand = cref.ml_prove(d, threads=cref.max_threads())
+    last4k = [t[-4096:].copy() for t in d.tables]
+    del d  # (the host copies: 24 GiB)
+    # (b) one handle, the whole instance
+    proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly, borrow=True)
+    got = np.stack([m.evaluations for m in proof])
+    for i in range(nv):
+        assert np.array_equal(got[i], want[i]), f"unsharded: round {i + 1} of {nv}"
+    assert np.array_equal(state.randomness, wrand)
+    state.close()
+    # (a) eight ranks, one thread each, all on GPU 0
+    G = 8
+    n_loc = (1 << nv) // G
+    ex = sharded.ThreadExchange(G)
+    out = [None] * G
+
+    def run(rank):
+        try:
+            _lib.check(sc.lib().sc_set_device(0))
+            eng = sharded.HipShardEngine(nv - 3, shapes, coefs, [m.evaluations[rank * n_loc:(rank + 1) * n_loc] for m in mles], "cuda:0", borrow=True)
+            comm = ex.comm(rank)
+            out[rank] = sharded.prove_sharded_library(eng, comm, nv)
+            comm.close()
+            eng.close()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            out[rank] = RuntimeError(f"rank {rank}: {e}\n{traceback.format_exc()}")
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=900)
+    for r in range(G):
+        assert not isinstance(out[r], Exception) and out[r] is not None, out[r]
+        sp, sr = out[r]
+        for i in range(nv):
+            assert np.array_equal(sp[i], want[i]), f"rank {r}: round {i + 1} of {nv}"
+        assert np.array_equal(sr, wrand), f"rank {r}"
+    # the borrowed inputs were never written
+    for m, t in zip(poly.flattened_ml_extensions, last4k):
+        assert np.array_equal(m.evaluations[-4096:].cpu().numpy().view(np.uint64), t)
+    del poly, mles
+    torch.cuda.empty_cache()
+
+
 FUZZ_SHAPES = 14
 
 

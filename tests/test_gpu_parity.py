@@ -55,6 +55,32 @@ def test_field_arithmetic_every_implementation(op, name):
     assert oi == [pyf(x, y) for x, y in zip(ai, bi)]
 
 
+@pytest.mark.parametrize("op", [0, 3, 4])
+def test_two_adic_root_of_unity_through_the_device_multipliers(op):
+    """Published known answer (third-party pin): 7^((p-1)/2^32) is the generator of BLS12-381 Fr's 2^32-th roots of unity,
+    0x16a2...0d2b.  334 DEPENDENT Montgomery products through the device multiplier (op 0: the production carry-free fe_mul;
+    3 / 4: the saturated CIOS and Comba products) must land on it; 31 more squarings give -1, one more 1."""
+    from oracle import pyoracle as po
+    from tests.test_oracle import TWO_ADIC_ROOT
+
+    def dmul(x, y):
+        out = np.empty_like(x)
+        _lib.check(sc.lib().sc_fr_elementwise(op, C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), C.c_void_p(out.ctypes.data), x.shape[0]))
+        return out
+
+    base = np.ascontiguousarray(cref.ints_to_mont([7, 7, 7]))
+    acc = np.ascontiguousarray(cref.ints_to_mont([1, 1, 1]))
+    for bit in bin((po.P - 1) >> 32)[2:]:
+        acc = dmul(acc, acc)
+        if bit == "1":
+            acc = dmul(acc, base)
+    assert cref.mont_to_ints(acc) == [TWO_ADIC_ROOT] * 3
+    for _ in range(31):
+        acc = dmul(acc, acc)
+    assert cref.mont_to_ints(acc) == [po.P - 1] * 3
+    assert cref.mont_to_ints(dmul(acc, acc)) == [1] * 3
+
+
 def _interactive(poly, challenges, borrow=False):
     st = sc.IPForMLSumcheck.prover_init(poly, borrow=borrow)
     msgs, v = [], None

@@ -46,6 +46,22 @@ def test_transcript_matches_golden():
     assert r.fill_bytes(64).hex() == s["next64"]
 
 
+def test_transcript_blake2b_multi_block_known_answers():
+    """The C++ transcript of the product library (csrc/transcript.hpp) on the multi-block inputs of RFC 7693's self-test (0, 3,
+    128, 129, 255, 1024 bytes) and on ProverMsg-sized ones (168 = 8 + 5 x 32 bytes spans two compression blocks; "abc" does
+    not).  tests/test_oracle.py::test_blake2b_rfc7693_selftest_multi_block ties hashlib to the RFC's published grand hash."""
+    import hashlib
+    from tests.test_oracle import _rfc7693_seq
+    for inlen in (0, 3, 128, 129, 168, 232, 255, 1024):
+        data = _rfc7693_seq(inlen, inlen)
+        r = sc.Blake2b512Rng.setup()
+        if inlen <= 128:
+            r.feed(data)
+        else:  # fed in uneven pieces: the buffered-block logic must not depend on the split
+            r.feed(data[:5]); r.feed(data[5:131]); r.feed(data[131:])
+        assert r.fill_bytes(64) == hashlib.blake2b(data, digest_size=64).digest()
+
+
 def test_transcript_determinism_like_reference():
     # shape of reference src/rng.rs:110-169 (feed / F::rand interleavings incl. unaligned 127/777-byte squeezes)
     rng = np.random.default_rng(5)

@@ -48,6 +48,58 @@ def test_blake2b_known_answer_and_c_impl():
         assert cref.blake2b512(m) == hashlib.blake2b(m, digest_size=64).digest()
 
 
+# ---- published known answers (third-party pins) ----------------------------------------------
+TWO_ADIC_ROOT = 0x16A2A19EDFE81F20D09B681922C813B4B63683508C2280B93829971F439F0D2B  # BLS12-381 Fr: 7^((p-1)/2^32), order 2^32
+
+
+def _rfc7693_seq(n, seed):  # selftest_seq of RFC 7693 appendix E
+    a, b, out = (0xDEAD4BAD * seed) & 0xFFFFFFFF, 1, bytearray()
+    for _ in range(n):
+        t = (a + b) & 0xFFFFFFFF
+        a, b = b, t
+        out.append((t >> 24) & 0xFF)
+    return bytes(out)
+
+
+def test_two_adic_root_of_unity_through_the_c_field_multiplier():
+    """A 223-bit exponentiation (334 dependent Montgomery products of oracle.c's fr_mul) must land on the published generator
+    of the 2^32-th roots of unity of BLS12-381 Fr; 31 more squarings give -1, one more gives 1."""
+    assert pow(7, (po.P - 1) >> 32, po.P) == TWO_ADIC_ROOT
+    e = (po.P - 1) >> 32
+    base = cref.ints_to_mont([7])[0]
+    acc = cref.ints_to_mont([1])[0]
+    for bit in bin(e)[2:]:
+        acc = cref.fr_binop("mul", acc, acc)
+        if bit == "1":
+            acc = cref.fr_binop("mul", acc, base)
+    assert cref.mont_to_ints(acc) == [TWO_ADIC_ROOT]
+    for _ in range(31):
+        acc = cref.fr_binop("mul", acc, acc)
+    assert cref.mont_to_ints(acc) == [po.P - 1]
+    assert cref.mont_to_ints(cref.fr_binop("mul", acc, acc)) == [1]
+
+
+def test_blake2b_rfc7693_selftest_multi_block():
+    """RFC 7693 appendix E: the grand hash over inputs of 0, 3, 128, 129, 255 and 1024 bytes (one to eight compression blocks),
+    keyed and unkeyed, four digest sizes, is a published constant.  hashlib reproduces it (so hashlib is a faithful BLAKE2b on
+    multi-block inputs), and both oracle implementations agree with hashlib on the self-test's own unkeyed 64-byte cases and on a
+    168-byte ProverMsg-sized input (8-byte length + 5 x 32 bytes: two blocks, unlike "abc")."""
+    grand = hashlib.blake2b(digest_size=32)
+    for outlen in (20, 32, 48, 64):
+        for inlen in (0, 3, 128, 129, 255, 1024):
+            data = _rfc7693_seq(inlen, inlen)
+            grand.update(hashlib.blake2b(data, digest_size=outlen).digest())
+            grand.update(hashlib.blake2b(data, digest_size=outlen, key=_rfc7693_seq(outlen, outlen)).digest())
+    assert grand.hexdigest() == "c23a7800d98123bd10f506c61e29da5603d763b8bbad2e737f5e765a7bccd475"
+    for inlen in (0, 3, 128, 129, 168, 232, 255, 1024):
+        data = _rfc7693_seq(inlen, inlen)
+        want = hashlib.blake2b(data, digest_size=64).digest()
+        assert cref.blake2b512(data) == want
+        r = po.Blake2b512Rng()
+        r.feed_bytes(data)
+        assert r.fill_bytes(64) == want  # the first squeeze of the transcript is the plain digest of what was fed (rng.rs:62-63)
+
+
 def test_transcript_golden_both_oracles():
     g = H.load("transcript.json")
     for mk in (po.Blake2b512Rng, cref.Rng):
