@@ -124,11 +124,12 @@ def cpu_baseline(shapes, n_tables, nv_full=24, budget_s=12.0):
     return {"value": allc["value"], "unit": "field-ops/s", "cores": threads, "kind": "port",
             "sample": allc["sample"] + f", OpenMP {threads} threads, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}",
             "phases_s": allc["phases_s"], "whole_prove": allc["whole_prove"],
-            "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "cpu_quota_cores": cref.cpu_quota_cores(),
             "one_thread": one, "all_cores_improved_bind": imp,
             "note": "port = oracle/oracle.c, a C restatement of the reference algorithm (the Rust reference cannot be built here). value = the "
                     "prove_round loop with the tables already copied (what the GPU clock covers); whole_prove adds prover_init's deep copy "
-                    "(done by all threads in slices -- the reference clones serially). all_cores_improved_bind parallelises fix_variables "
+                    "(done by all threads in slices -- the reference clones serially). cores = the threads started: the host's hardware threads "
+                    "capped by the container's CPU quota (cpu_quota_cores; more threads than the quota are throttled, not run). all_cores_improved_bind parallelises fix_variables "
                     "inside a table, which the reference does not"}, kept
 
 
@@ -221,14 +222,23 @@ def main():
     else:
         engine = sharded.HipShardEngine(nv_local, shapes, coefs, tables, dev, borrow=True)
         handle = engine._h
-        box = {"comm": None, "python": os.environ.get("SC_BENCH_PYTHON_ROUNDS") == "1"}
+        box = {"comm": None, "python": os.environ.get("SC_BENCH_PYTHON_ROUNDS") == "1", "why": "SC_BENCH_PYTHON_ROUNDS=1" if os.environ.get("SC_BENCH_PYTHON_ROUNDS") == "1" else ""}
         if not box["python"]:
             try:  # the whole sharded proof inside the library: RCCL on the prover's stream, or (one-GPU test mode) its host transport
                 box["comm"] = sharded.HostComm.over_torch_distributed() if one_gpu else sharded.NativeComm(dev)
                 round_loop = "library+host-transport(gloo)" if one_gpu else "library+rccl"
+                # collective self-test BEFORE the warm-up: one all-reduce and one all-gather of known patterns, checked on every rank
+                _lib.check(sc.lib().sc_comm_selftest(box["comm"]._h))
+                box["why"] = "sc_comm_selftest passed on every rank"
             except Exception as e:
-                log(f"[bench] in-library sharded proof unavailable ({e}); using the torch.distributed round loop")
+                box["why"] = f"in-library communicator unavailable or failed its self-test: {e}"
                 box["python"] = True
+        if world > 1:  # every rank takes the same path: one rank's failure moves all of them to the torch.distributed loop
+            flag = torch.tensor([1 if box["python"] else 0], dtype=torch.int32, device="cpu" if one_gpu else dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and not box["python"]:
+                box["python"], box["why"] = True, "another rank's communicator failed its self-test"
+        log(f"[bench] rank {rank}: round loop = {'torch.distributed (fallback)' if box['python'] else round_loop} -- {box['why']}")
         dcomm = sharded.DistComm()
         tail_factory = sharded.TailEngines(shapes, coefs, dev)  # only the Python loop uses it
 
@@ -330,7 +340,7 @@ def main():
                                    f" ({nv_local} per GPU shard), BLS12-381 Fr, tables HBM-resident",
                        "nv": nv_total, "nv_per_gpu": nv_local, "tables": U, "degree": max(len(s) for s in shapes),
                        "field_ops_per_step": ops, "sharding": f"high-bit x{world}" if world > 1 else "none",
-                       "round_loop": round_loop},
+                       "round_loop": round_loop, "round_loop_reason": (box["why"] if (world > 1 or force_sharded) else "single GPU: no exchange")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": (f"k_round1_tree_split (round 1) + k_round_tree_split (rounds 2..{big_rounds}): all products, one launch per big round, one product per block row" if merged
                                     else f"{kname} (product {dom}, big rounds)"),

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 2
+#define SC_ABI_VERSION 3 /* 3: sc_prover_set_polling, SC_NO_DEVICE_POLLING, sc_set_cache_limit, sc_comm_init_p2p (additions only) */
 #define SC_API __attribute__((visibility("default")))
 
 enum sc_status {
@@ -59,7 +59,8 @@ enum sc_status {
 enum sc_flags {
     SC_TABLES_ON_DEVICE = 1u << 0, /* `tables[]` are device pointers (HBM-resident), not host */
     SC_TABLES_BORROW = 1u << 1,    /* with ON_DEVICE: do not copy; tables are only read and must outlive the handle */
-    SC_TABLES_STREAM = 1u << 2     /* HOST tables too large to copy: see sc_prover_init_streamed (set by it; sc_prover_init accepts it too) */
+    SC_TABLES_STREAM = 1u << 2,    /* HOST tables too large to copy: see sc_prover_init_streamed (set by it; sc_prover_init accepts it too) */
+    SC_NO_DEVICE_POLLING = 1u << 3 /* this handle never parks a kernel on the GPU that waits for the host (sc_prover_set_polling(p, 0) from the start) */
 };
 
 /* Flattened ListOfProductsOfPolynomials (reference src/ml_sumcheck/data_structures.rs:25-35):
@@ -111,6 +112,21 @@ SC_API void sc_prover_free(sc_prover *p);
  * which is what torch.cuda.current_stream().cuda_stream is unless a side stream is active), or -- use_own != 0 --
  * back on the handle's own non-blocking stream. */
 SC_API int sc_prover_set_stream(sc_prover *p, void *hip_stream, int use_own);
+/* DEVICE-SIDE WAITS AND FOREIGN HIP TRAFFIC -- the interference contract.  Inside sc_ml_prove* / sc_gkr_prove the latency-bound rounds
+ * are launched BEFORE their challenge exists: a one-wavefront kernel (k_wait_challenge) or the persistent tail kernel (k_tail_rounds)
+ * sits on the handle's stream and polls a host-mapped word until the calling thread has hashed the previous message.  While such a
+ * kernel waits, the calling thread must be able to finish its HIP calls.  The library's own threads are serialised per device (see
+ * THREADING); HIP calls made by OTHER code of the process on the same device (hipMalloc / hipFree / synchronous copies take
+ * process-wide locks inside the runtime) can hold the calling thread up.  What then happens, in this order:
+ *   - nothing, if the delay is shorter than the wait's bound (seconds; SC_WAIT_SPINS): the proof is slower, never different;
+ *   - the wait expires: messages computed on a stale challenge are never returned.  A handle whose inputs are intact (borrowed or
+ *     streamed tables) proves again from round 0 with synchronous rounds inside the same call; a copying handle returns SC_ERR_HIP
+ *     ("... the proof is void") and must be reset with its tables.
+ * A host that runs its own HIP work on the device concurrently (a Rust application with its own streams, an ML framework) should
+ * switch the device-side waits off for its handles: allow = 0 makes every round of this handle launch after its challenge is known
+ * (about 0.3 ms more per 24-variable proof, no kernel ever waits for the host, nothing can expire).  SC_PIPELINE=0 in the
+ * environment does the same for every handle of the process.  Returns SC_OK; the setting holds until changed. */
+SC_API int sc_prover_set_polling(sc_prover *p, int allow);
 
 /* Sharded use: this handle holds one contiguous high-bit shard of every table.
  * sc_prove_round_partial = prove_round on the shard, result left ON THE DEVICE as (deg+1) x 8 uint64
@@ -145,6 +161,18 @@ typedef int (*sc_allgather_fn)(void *ctx, const void *send, void *recv, size_t b
 SC_API int sc_comm_unique_id(uint8_t *out128);
 SC_API int sc_comm_init(const uint8_t *id128, int rank, int nranks, sc_comm **out);
 SC_API int sc_comm_init_host(int rank, int nranks, sc_allreduce_u64_fn allreduce, sc_allgather_fn allgather, void *ctx, sc_comm **out);
+/*   - or PEER TO PEER (sc_comm_init_p2p), for ranks that are THREADS of one process with one GPU each: no collective library at all.
+ *     Every rank owns a fine-grained inbox on its device; the ranks meet under `group_id` (any number no other live group uses; the
+ *     call blocks until all `nranks` threads have made it -- 60 s at most -- and enables peer access between their devices).  A round's
+ *     all-reduce is then ONE small kernel per rank on the prover's stream: it pushes the rank's (deg+1) x 8 lanes into every peer's
+ *     inbox as self-validating words (posted writes over xGMI), polls its own inbox, adds, and publishes the total to the host --
+ *     instead of ncclAllReduce + a publishing kernel; the tail's gather is peer copies.  Ranks may share a GPU (functional tests on
+ *     a one-GPU box; rounds are then not pipelined and the exchange kernel is re-launched until its peers' kernels have run).
+ *     THREADS AND RCCL: an RCCL communicator driven by one thread per GPU inside one process must follow RCCL's own rule for that
+ *     mode -- one communicator per thread, every thread issuing the same collectives in the same order, no thread holding a lock
+ *     another needs while inside a collective.  The library's per-device gate is never held across devices, so distinct-device
+ *     thread ranks satisfy it; one process per GPU (what bench.py launches) avoids the question, and sc_comm_init_p2p avoids RCCL. */
+SC_API int sc_comm_init_p2p(uint64_t group_id, int rank, int nranks, sc_comm **out);
 /* diagnostic, collective: one all-reduce and one all-gather of known patterns over the communicator, checked on every rank */
 SC_API int sc_comm_selftest(sc_comm *comm);
 SC_API void sc_comm_free(sc_comm *comm);
@@ -264,6 +292,9 @@ SC_API int sc_sparse_evaluate(const uint64_t *idx, const uint64_t *vals, uint64_
  * their work areas (an eighth of the tables) and stream, and sc_ml_prove keeps the last prover it built (bound-table buffers of
  * at most 16 GiB) for the next one-shot proof of the same shape.  This releases all of it. */
 SC_API int sc_release_caches(void);
+/* Upper bound, in bytes of device memory, of what EACH of those three caches may keep between calls (default 16 GiB; 0 = nothing is
+ * kept: every call allocates and frees its own, as a library without caches would).  Lowering the limit releases what is cached now. */
+SC_API int sc_set_cache_limit(uint64_t bytes);
 
 /* ---- synthetic inputs + instrumentation (bench / tests) ------------------------------------- */
 /* SplitMix64-keyed uniform field elements, generated on the device: n elements of

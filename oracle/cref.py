@@ -333,5 +333,27 @@ def gkr_prove(idx, vals, dim: int, f2, f3, g, rng: Optional[Rng] = None, threads
     return proof, uv
 
 
+def cpu_quota_cores():
+    """CPU time this container may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited.  The GPU boxes show all
+    256 hardware threads of their host but run under a quota (16 cores when probed): more OpenMP threads than that are throttled, not run."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(round(int(q) / int(per))))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, int(round(q / per)))
+    except Exception:
+        pass
+    return None
+
+
 def max_threads() -> int:
-    return int(lib().orc_max_threads())
+    """threads worth starting: what OpenMP would start, capped by the container's CPU quota"""
+    n = int(lib().orc_max_threads())
+    q = cpu_quota_cores()
+    return min(n, q) if q else n

@@ -1,4 +1,4 @@
-//! `extern "C"` binding of `libsumcheck_hip.so` (C ABI: `include/sumcheck_hip.h`, SC_ABI_VERSION 2) exposed with the
+//! `extern "C"` binding of `libsumcheck_hip.so` (C ABI: `include/sumcheck_hip.h`, SC_ABI_VERSION 3) exposed with the
 //! signatures of the reference's public API:
 //!
 //! | here | reference |
@@ -60,7 +60,7 @@ pub struct sc_comm {
     _private: [u8; 0],
 }
 
-pub const SC_ABI_VERSION: c_int = 2;
+pub const SC_ABI_VERSION: c_int = 3;
 pub const SC_OK: c_int = 0;
 pub const SC_ERR_CONSTANT_POLY: c_int = 1;
 pub const SC_ERR_FIRST_ROUND_HAS_MSG: c_int = 2;
@@ -69,6 +69,7 @@ pub const SC_ERR_NOT_ACTIVE: c_int = 4;
 pub const SC_ERR_BAD_ARG: c_int = 5;
 pub const SC_TABLES_ON_DEVICE: u32 = 1;
 pub const SC_TABLES_BORROW: u32 = 2;
+pub const SC_NO_DEVICE_POLLING: u32 = 8; // a host with HIP streams of its own: no kernel of this handle ever waits for the host
 
 pub type sc_allreduce_u64_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, inout: *mut u64, count: usize) -> c_int>;
 pub type sc_allgather_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, send: *const c_void, recv: *mut c_void, bytes: usize) -> c_int>;
@@ -84,6 +85,8 @@ extern "C" {
     pub fn sc_prover_state(p: *mut sc_prover, randomness: *mut u64, n_randomness: *mut u32, tables_out: *mut u64, round: *mut u32) -> c_int;
     pub fn sc_prover_free(p: *mut sc_prover);
     pub fn sc_release_caches() -> c_int;
+    pub fn sc_set_cache_limit(bytes: u64) -> c_int;
+    pub fn sc_prover_set_polling(p: *mut sc_prover, allow: c_int) -> c_int;
     pub fn sc_fix_variables(input: *const u64, nv: u32, point: *const u64, k: u32, out: *mut u64, flags: u32) -> c_int;
     pub fn sc_poly_evaluate(desc: *const sc_poly_desc, point: *const u64, out_value: *mut u64, out_table_values_or_null: *mut u64) -> c_int;
     pub fn sc_sparse_evaluate(idx: *const u64, vals: *const u64, nnz: u64, num_vars: u32, point: *const u64, out: *mut u64) -> c_int;
@@ -99,6 +102,7 @@ extern "C" {
     pub fn sc_comm_init(id128: *const u8, rank: c_int, nranks: c_int, out: *mut *mut sc_comm) -> c_int;
     pub fn sc_comm_init_host(rank: c_int, nranks: c_int, allreduce: sc_allreduce_u64_fn, allgather: sc_allgather_fn, ctx: *mut c_void,
                              out: *mut *mut sc_comm) -> c_int;
+    pub fn sc_comm_init_p2p(group_id: u64, rank: c_int, nranks: c_int, out: *mut *mut sc_comm) -> c_int;
     pub fn sc_comm_free(comm: *mut sc_comm);
     pub fn sc_ml_prove_sharded(p: *mut sc_prover, comm: *mut sc_comm, rng_or_null: *mut sc_rng, nv_total: u32, out_proof: *mut u64,
                                out_randomness: *mut u64) -> c_int;

@@ -31,6 +31,7 @@ SC_ERR_REJECT = 8
 SC_TABLES_ON_DEVICE = 1
 SC_TABLES_BORROW = 2
 SC_TABLES_STREAM = 4
+SC_NO_DEVICE_POLLING = 8
 
 
 class PolyDesc(C.Structure):
@@ -61,12 +62,15 @@ SIGNATURES = {
     "sc_prover_state": (C.c_int, [_V, _V, u32p, _V, u32p]),
     "sc_prover_free": (None, [_V]),
     "sc_prover_set_stream": (C.c_int, [_V, _V, C.c_int]),
+    "sc_prover_set_polling": (C.c_int, [_V, C.c_int]),
+    "sc_set_cache_limit": (C.c_int, [C.c_uint64]),
     "sc_prove_round_partial": (C.c_int, [_V, _V, _V]),
     "sc_wide_reduce": (C.c_int, [_V, C.c_uint32, _V]),
     "sc_prover_bind_final": (C.c_int, [_V, _V, _V]),
     "sc_comm_unique_id": (C.c_int, [_V]),
     "sc_comm_init": (C.c_int, [_V, C.c_int, C.c_int, C.POINTER(_V)]),
     "sc_comm_init_host": (C.c_int, [C.c_int, C.c_int, _V, _V, _V, C.POINTER(_V)]),
+    "sc_comm_init_p2p": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.POINTER(_V)]),
     "sc_comm_selftest": (C.c_int, [_V]),
     "sc_comm_free": (None, [_V]),
     "sc_ml_prove_sharded": (C.c_int, [_V, _V, _V, C.c_uint32, _V, _V]),
@@ -131,7 +135,12 @@ def lib():
             pass
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            try:
+                fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            except AttributeError:
+                if os.environ.get("SC_LIB_PATH"):  # an A/B run against an older build (tools/run_ab.sh): it simply lacks the newer entry points
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = L

@@ -10,6 +10,9 @@
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <cstdarg>
 #include <cstdio>
@@ -17,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sumcheck_hip.h"
@@ -86,6 +90,7 @@ static int fail(int code, const char *fmt, ...) {
     g_last_error = buf;
     return code;
 }
+uint64_t sc_internal_cache_limit(); // sc_set_cache_limit: what each process-wide cache may keep (defined with the handle pool)
 // shared with gkr.hip
 int sc_internal_device() { return g_device; } // the calling thread's device (sc_set_device), for gkr.hip
 
@@ -225,7 +230,8 @@ struct sc_prover {
     uint64_t arena_bytes = 0;       // size of the bound-table arena (what a pooled handle keeps allocated)
     std::vector<uint8_t> pool_key;  // non-empty: created by sc_ml_prove; sc_prover_free offers it back to the pool (handle_pool_*)
     uint32_t n_retries = 0;         // proofs repeated after an expired device-side wait (sc_ml_prove_handle)
-    bool pipeline_ok = true;        // cleared when the wait-value path is unavailable (or SC_PIPELINE=0)
+    bool pipeline_ok = true;        // cleared when the wait-value path is unavailable (or SC_PIPELINE=0, SC_NO_DEVICE_POLLING, sc_prover_set_polling(p, 0))
+    bool polling_off_by_caller = false; // ... by the caller: survives what re-enables pipeline_ok internally
     bool deferred_pending = false;  // a round is enqueued behind the wait and still needs its challenge
     bool fused_finalize = false;    // experiments, SC_FUSED_FIN=1: the merged big-round launch finalizes in-kernel (measured: slower than the k_finalize launch)
     bool use_tail = true;           // sc_ml_prove* / GKR: the latency-bound rounds run in the persistent tail kernel (SC_TAIL=0: pipelined launches)
@@ -382,6 +388,10 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     p->K = d->n_products;
     p->U = d->n_tables;
     p->randomness.reserve(p->nv);
+    if (d->flags & SC_NO_DEVICE_POLLING) {
+        p->pipeline_ok = false;
+        p->polling_off_by_caller = true;
+    }
 #ifdef SC_EXPERIMENTS
     if (const char *e = std::getenv("SC_FE")) p->use_fe = std::atoi(e) != 0;
     if (const char *e = std::getenv("SC_KERNEL")) p->kernel_variant = std::atoi(e);
@@ -568,6 +578,8 @@ extern "C" int sc_prover_init(const sc_poly_desc *desc, sc_prover **out) {
     std::vector<uint8_t> key = pool_key_of(desc, g_device);
     if (sc_prover *kept = handle_pool_take(key)) {
         if (sc_prover_reset(kept, desc->tables, desc->flags & SC_TABLES_ON_DEVICE) == SC_OK) {
+            kept->polling_off_by_caller = (desc->flags & SC_NO_DEVICE_POLLING) != 0; // (what a previous owner set with sc_prover_set_polling does not carry over)
+            kept->pipeline_ok = !kept->polling_off_by_caller;
             *out = kept;
             return SC_OK;
         }
@@ -1682,7 +1694,7 @@ struct EvalLease { // RAII: the cache if it is free, nothing otherwise
     }
     // a buffer of at least `bytes` and a stream on `device`, or null (the caller then allocates)
     void *get(int device, size_t bytes, hipStream_t *s_out) {
-        if (!held) return nullptr;
+        if (!held || bytes > sc_internal_cache_limit()) return nullptr; // (over the limit: the caller allocates and frees its own)
         EvalCache &c = g_eval_cache;
         if (c.device != device) {
             if (c.buf) (void)hipFree(c.buf);
@@ -1962,7 +1974,9 @@ extern "C" int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *o
 // 2 ms against a 0.4 ms proof at 2^16 entries.  The last prover that was freed is therefore kept (one, process-wide, arena at most
 // kPoolMaxArena) and the next sc_prover_init / sc_ml_prove with the same polynomial STRUCTURE on the same device rewinds it onto the
 // new tables (sc_prover_reset) instead.  sc_release_caches frees the kept one.
-constexpr uint64_t kPoolMaxArena = 16ULL << 30; // (of 288 GB; building and freeing a 4.5 GB arena costs 3 ms)
+// (default of sc_set_cache_limit: 16 GiB of 288 GB; building and freeing a 4.5 GB arena costs 3 ms)
+static std::atomic<uint64_t> g_cache_limit{16ULL << 30};
+uint64_t sc_internal_cache_limit() { return g_cache_limit.load(std::memory_order_relaxed); } // gkr.hip
 struct HandlePool {
     std::mutex mu;
     sc_prover *h = nullptr;
@@ -1991,7 +2005,7 @@ static sc_prover *handle_pool_take(const std::vector<uint8_t> &key) {
     return p;
 }
 static bool handle_pool_offer(sc_prover *p) {
-    if (p->pool_key.empty() || p->arena_bytes > kPoolMaxArena || p->streamed) return false;
+    if (p->pool_key.empty() || p->arena_bytes > sc_internal_cache_limit() || p->streamed) return false;
     if (p->stream != p->own_stream) return false; // (it runs on a stream of the caller's: sc_prover_set_stream)
     abandon_deferred(p);                          // nothing of it may still be waiting in the queue
     {   // sc_prover_free promises that the handle's work is over: asynchronous calls (sc_prove_round_partial, sc_prover_bind_final) may
@@ -2018,6 +2032,19 @@ void sc_internal_release_handle_pool() { // sc_release_caches (gkr.hip)
         g_pool.h = nullptr;
     }
     if (old) prover_destroy(old);
+}
+
+extern "C" int sc_set_cache_limit(uint64_t bytes) {
+    const uint64_t before = g_cache_limit.exchange(bytes);
+    return bytes < before ? sc_release_caches() : SC_OK;
+}
+
+extern "C" int sc_prover_set_polling(sc_prover *p, int allow) {
+    if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    if (p->deferred_pending) return fail(SC_ERR_BAD_ARG, "a pipelined round is waiting for its challenge");
+    p->pipeline_ok = allow != 0;
+    p->polling_off_by_caller = allow == 0;
+    return SC_OK;
 }
 
 extern "C" int sc_ml_prove(const sc_poly_desc *desc, sc_rng *rng_or_null, uint64_t *out_proof, sc_prover **out_state_or_null) {
@@ -2214,12 +2241,59 @@ static int nccl_load() {
 }
 // A communicator is either an RCCL one (collectives enqueued on the prover's stream, device buffers) or a HOST transport: two
 // caller-supplied functions that exchange host buffers (MPI, gloo, shared memory between the threads of one process, ...).
+// sc_comm_init_p2p: the ranks are threads of this process, one GPU each; they find each other in a process-wide registry under a group
+// id of the caller's choosing.  The group holds every rank's inbox pointer and a small host barrier that also passes one pointer per
+// rank around (the tail's gather buffers).
+struct P2PGroup {
+    std::mutex mu;
+    std::condition_variable cv;
+    int nranks = 0, joined = 0, left = 0;
+    uint64_t *inbox[scd::kP2PMaxRanks] = {};
+    int device[scd::kP2PMaxRanks] = {};
+    // barrier + pointer exchange
+    int arrived = 0;
+    uint64_t phase = 0;
+    void *ptrs[scd::kP2PMaxRanks] = {};
+    bool broken = false;
+    // every rank deposits `mine`, all leave with everybody's; false on timeout (the group is then unusable)
+    bool exchange(int rank, void *mine, void **all_out) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
+        const uint64_t my_phase = phase;
+        ptrs[rank] = mine;
+        if (++arrived == nranks) {
+            arrived = 0;
+            if (all_out) std::copy(ptrs, ptrs + nranks, all_out);
+            last = std::vector<void *>(ptrs, ptrs + nranks);
+            ++phase;
+            cv.notify_all();
+            return true;
+        }
+        if (!cv.wait_for(lk, std::chrono::seconds(60), [&] { return phase != my_phase || broken; }) || broken) {
+            broken = true;
+            cv.notify_all();
+            return false;
+        }
+        if (all_out) std::copy(last.begin(), last.end(), all_out);
+        return true;
+    }
+    std::vector<void *> last;
+};
+static std::mutex g_p2p_mu;
+static std::map<uint64_t, std::shared_ptr<P2PGroup>> g_p2p_groups;
+
 struct sc_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     sc_allreduce_u64_fn h_allreduce = nullptr;
     sc_allgather_fn h_allgather = nullptr;
     void *ctx = nullptr;
+    // peer-to-peer (sc_comm_init_p2p)
+    std::shared_ptr<P2PGroup> p2p;
+    uint64_t p2p_id = 0;
+    uint32_t p2p_gen = 0;          // generations used so far
+    bool p2p_shared_device = false; // two ranks on one GPU (functional tests): no kernel may wait long for another rank's kernel
+    int device = 0;
 };
 #define NCCL_TRY(expr)                                                                                             \
     do {                                                                                                           \
@@ -2266,6 +2340,153 @@ extern "C" int sc_comm_init_host(int rank, int nranks, sc_allreduce_u64_fn allre
     *out = c;
     return SC_OK;
 }
+// Peer-to-peer communicator for thread ranks (one host thread and one GPU per rank inside ONE process): no collective library.  Every
+// rank allocates a fine-grained inbox on its own device, the ranks meet in the process-wide registry under `group_id` (any number
+// not in use by another live group; the call blocks until all `nranks` threads have made it, 60 s at most), peer access is enabled
+// between the devices, and from then on a round's all-reduce is one small kernel per rank (kernels.h: P2PArgs) and the tail's
+// gather is peer copies.  Ranks may share a GPU (functional tests on a one-GPU box): the exchange kernel then gives up quickly when a
+// peer's kernel has not run yet -- it may be queued behind this one -- and the host launches it again.
+extern "C" int sc_comm_init_p2p(uint64_t group_id, int rank, int nranks, sc_comm **out) {
+    if (!out || rank < 0 || rank >= nranks || nranks > scd::kP2PMaxRanks) return fail(SC_ERR_BAD_ARG, "bad argument");
+    *out = nullptr;
+    if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    HIP_TRY(hipSetDevice(g_device));
+    std::shared_ptr<P2PGroup> g;
+    {
+        std::lock_guard<std::mutex> lk(g_p2p_mu);
+        auto &slot = g_p2p_groups[group_id];
+        if (!slot) {
+            slot = std::make_shared<P2PGroup>();
+            slot->nranks = nranks;
+        }
+        g = slot;
+    }
+    uint64_t *inbox = nullptr;
+    {
+        DeviceGate gate_(g_device);
+        // fine-grained: peers' stores become visible to this device's polls without a kernel boundary
+        if (hipExtMallocWithFlags(reinterpret_cast<void **>(&inbox), scd::kP2PInboxWords * 8, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&inbox), scd::kP2PInboxWords * 8));
+        }
+        HIP_TRY(hipMemset(inbox, 0, scd::kP2PInboxWords * 8));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    auto give_up = [&](int code, const char *msg) {
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->broken = true;
+            g->cv.notify_all();
+        }
+        {
+            std::lock_guard<std::mutex> lk(g_p2p_mu);
+            auto it = g_p2p_groups.find(group_id);
+            if (it != g_p2p_groups.end() && it->second == g) g_p2p_groups.erase(it);
+        }
+        (void)hipFree(inbox);
+        return fail(code, "%s", msg);
+    };
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        if (g->nranks != nranks || g->inbox[rank] || g->broken) {
+            lk.unlock();
+            (void)hipFree(inbox);
+            return fail(SC_ERR_BAD_ARG, "p2p group %llu: rank %d joined twice, or the ranks disagree on the group's size", (unsigned long long)group_id, rank);
+        }
+        g->inbox[rank] = inbox;
+        g->device[rank] = g_device;
+        ++g->joined;
+        g->cv.notify_all();
+        if (!g->cv.wait_for(lk, std::chrono::seconds(60), [&] { return g->joined == g->nranks || g->broken; }) || g->broken) {
+            lk.unlock();
+            return give_up(SC_ERR_HIP, "p2p group: not every rank joined within 60 s");
+        }
+    }
+    sc_comm *c = new (std::nothrow) sc_comm();
+    if (!c) return give_up(SC_ERR_OOM, "host allocation failed");
+    c->rank = rank;
+    c->nranks = nranks;
+    c->p2p = g;
+    c->p2p_id = group_id;
+    c->device = g_device;
+    for (int q = 0; q < nranks; ++q) {
+        if (q == rank) continue;
+        if (g->device[q] == g_device) {
+            c->p2p_shared_device = true;
+            continue;
+        }
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, g_device, g->device[q]) != hipSuccess || !can) {
+            delete c;
+            return give_up(SC_ERR_HIP, "p2p group: a peer device is not accessible from this one (no xGMI / PCIe peer access)");
+        }
+        const hipError_t e = hipDeviceEnablePeerAccess(g->device[q], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+            delete c;
+            return give_up(SC_ERR_HIP, "hipDeviceEnablePeerAccess failed");
+        }
+        (void)hipGetLastError();
+    }
+    // (a rank that shares its GPU makes the whole group cautious: every rank must agree on whether rounds are pipelined)
+    void *all[scd::kP2PMaxRanks];
+    if (!g->exchange(rank, c->p2p_shared_device ? (void *)1 : nullptr, all)) {
+        delete c;
+        return give_up(SC_ERR_HIP, "p2p group: a rank dropped out during set-up");
+    }
+    for (int q = 0; q < nranks; ++q) c->p2p_shared_device |= all[q] != nullptr;
+    *out = c;
+    return SC_OK;
+}
+
+// p2p: every rank's `bytes` from d_send into every rank's d_recv (rank order), by peer copies; returns when all pieces are in place
+static int p2p_allgather(sc_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t s) {
+    void *recv[scd::kP2PMaxRanks];
+    HIP_TRY(hipStreamSynchronize(s)); // d_send is complete (and d_recv no longer read by this rank's earlier work)
+    {
+        GateYield yield_(c->device, true);
+        if (!c->p2p->exchange(c->rank, d_recv, recv)) return fail(SC_ERR_HIP, "p2p group: a rank did not reach the gather");
+    }
+    for (int q = 0; q < c->nranks; ++q) {
+        char *dst = static_cast<char *>(recv[q]) + (size_t)c->rank * bytes;
+        if (c->p2p->device[q] == c->device) HIP_TRY(hipMemcpyAsync(dst, d_send, bytes, hipMemcpyDeviceToDevice, s));
+        else HIP_TRY(hipMemcpyPeerAsync(dst, c->p2p->device[q], d_send, c->device, bytes, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    {
+        GateYield yield_(c->device, true);
+        if (!c->p2p->exchange(c->rank, nullptr, nullptr)) return fail(SC_ERR_HIP, "p2p group: a rank did not finish the gather");
+    }
+    return SC_OK;
+}
+// p2p: any number of lanes summed in place over the group (the ranks read each other's buffers directly)
+static int p2p_allreduce_table(sc_comm *c, uint64_t *d_lanes, size_t n_words, hipStream_t s) {
+    void *all[scd::kP2PMaxRanks];
+    uint64_t *tmp = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), n_words * 8));
+    struct Free {
+        void *p;
+        ~Free() { (void)hipFree(p); }
+    } free_tmp{tmp};
+    HIP_TRY(hipStreamSynchronize(s));
+    {
+        GateYield yield_(c->device, true);
+        if (!c->p2p->exchange(c->rank, d_lanes, all)) return fail(SC_ERR_HIP, "p2p group: a rank did not reach the all-reduce");
+    }
+    scd::PeerLanes pl;
+    std::memset(&pl, 0, sizeof(pl));
+    pl.n = c->nranks;
+    for (int q = 0; q < c->nranks; ++q) pl.p[q] = static_cast<const uint64_t *>(all[q]);
+    HIP_TRY(scd::launch_sum_peer_lanes(pl, n_words, tmp, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    {
+        GateYield yield_(c->device, true); // nobody overwrites its lanes while a peer still reads them
+        if (!c->p2p->exchange(c->rank, nullptr, nullptr)) return fail(SC_ERR_HIP, "p2p group: a rank did not finish the all-reduce");
+    }
+    HIP_TRY(hipMemcpyAsync(d_lanes, tmp, n_words * 8, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SC_OK;
+}
+
 // Diagnostic: one all-reduce and one all-gather of known patterns over the communicator, checked on every rank.
 extern "C" int sc_comm_selftest(sc_comm *c) {
     if (!c) return fail(SC_ERR_BAD_ARG, "null argument");
@@ -2286,6 +2507,26 @@ extern "C" int sc_comm_selftest(sc_comm *c) {
         HIP_TRY(hipMemcpy(gathered.data(), dg, (size_t)n * 8 * G, hipMemcpyDeviceToHost));
         (void)hipFree(d);
         (void)hipFree(dg);
+    } else if (c->p2p) {
+        HIP_TRY(hipSetDevice(c->device));
+        DeviceGate gate_(c->device);
+        uint64_t *d = nullptr, *dg = nullptr;
+        HIP_TRY(hipMalloc(&d, n * 8));
+        HIP_TRY(hipMalloc(&dg, (size_t)n * 8 * G));
+        HIP_TRY(hipMemcpy(d, lanes.data(), n * 8, hipMemcpyHostToDevice));
+        int rc = p2p_allgather(c, d, dg, (size_t)n * 8, nullptr);
+        if (!rc) rc = p2p_allreduce_table(c, d, (size_t)n, nullptr);
+        if (!rc) {
+            HIP_TRY(hipMemcpy(lanes.data(), d, n * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(gathered.data(), dg, (size_t)n * 8 * G, hipMemcpyDeviceToHost));
+        }
+        {
+            GateYield yield_(c->device, true); // (a peer may still be reading d: leave together)
+            (void)c->p2p->exchange(c->rank, nullptr, nullptr);
+        }
+        (void)hipFree(d);
+        (void)hipFree(dg);
+        if (rc) return rc;
     } else if (G > 1) {
         GateYield yield_(g_device, true);
         if (c->h_allgather(c->ctx, mine.data(), gathered.data(), (size_t)n * 8) != 0) return fail(SC_ERR_HIP, "the host transport's all-gather failed");
@@ -2309,6 +2550,7 @@ int sc_internal_allreduce_lanes(sc_comm *c, uint64_t *d_lanes, size_t n_words, h
         NCCL_TRY(g_nccl.AllReduce(d_lanes, d_lanes, n_words, ncclUint64, ncclSum, c->comm, s));
         return SC_OK;
     }
+    if (c->p2p) return p2p_allreduce_table(c, d_lanes, n_words, s);
     std::vector<uint64_t> h(n_words);
     HIP_TRY(hipMemcpyAsync(h.data(), d_lanes, n_words * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -2325,6 +2567,26 @@ int sc_internal_comm_ranks(sc_comm *c) { return c ? c->nranks : 1; }
 extern "C" void sc_comm_free(sc_comm *c) {
     if (!c) return;
     if (c->comm && g_nccl.CommDestroy) (void)g_nccl.CommDestroy(c->comm);
+    if (c->p2p) { // the inboxes go when the LAST rank leaves: a peer's kernel may still be pushing into this one
+        std::shared_ptr<P2PGroup> g = c->p2p;
+        bool last = false;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            last = ++g->left == g->nranks;
+        }
+        if (last) {
+            for (int q = 0; q < g->nranks; ++q)
+                if (g->inbox[q]) {
+                    (void)hipSetDevice(g->device[q]);
+                    (void)hipDeviceSynchronize();
+                    (void)hipFree(g->inbox[q]);
+                }
+            (void)hipSetDevice(g_device);
+            std::lock_guard<std::mutex> lk(g_p2p_mu);
+            auto it = g_p2p_groups.find(c->p2p_id);
+            if (it != g_p2p_groups.end() && it->second == g) g_p2p_groups.erase(it);
+        }
+    }
     delete c;
 }
 
@@ -2340,16 +2602,28 @@ static int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, 
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_wide), (size_t)n_words * 8, hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_wide_dev), p->h_wide, 0));
     }
-    const bool on_stream = comm->comm != nullptr; // RCCL: the reduction is a stream operation between the round and its publication
+    const bool p2p = comm->p2p != nullptr && comm->nranks > 1;
+    const bool on_stream = comm->comm != nullptr || p2p; // RCCL / p2p: the reduction is a stream operation between the round and its publication
     // Pipelined late rounds park a polling kernel on the stream until THIS rank's host has the next challenge -- which needs every
     // rank's lanes.  RCCL ranks sit on distinct devices.  Host-transport ranks may share one GPU (tests; threads of one process), where
     // streams share hardware queues: rank A's polling kernel could then sit in front of rank B's round kernels, and A's host would
-    // wait for B forever.  So the rounds are only pipelined where no other rank's work can queue behind the wait.
-    const bool may_defer = on_stream || comm->nranks == 1;
+    // wait for B forever.  So the rounds are only pipelined where no other rank's work can queue behind the wait (the same goes for a
+    // p2p group with two ranks on one GPU, whose exchange kernel also gives up quickly and is launched again by the host loop below).
+    const bool may_defer = comm->comm != nullptr || comm->nranks == 1 || (p2p && !comm->p2p_shared_device);
     sch::Fr vm = sch::zero();
     bool have = false, enqueued = false;
     uint32_t want = 0;
     std::vector<uint64_t> evals((size_t)p->D * 4);
+    scd::P2PArgs xargs[2]; // the exchange of the round awaited (slot want & 1) and of the pipelined one behind it
+    auto fill_xargs = [&](scd::P2PArgs &a) {
+        std::memset(&a, 0, sizeof(a));
+        for (int q = 0; q < comm->nranks; ++q) a.inbox[q] = comm->p2p->inbox[q];
+        a.nranks = comm->nranks;
+        a.rank = comm->rank;
+        a.n_words = n_words;
+        a.gen = ++comm->p2p_gen;
+        a.max_spins = comm->p2p_shared_device ? 2048u : scd::wait_spins_default();
+    };
     // one round on the stream: local kernels -> d_wide, integer all-reduce in place, publish to the host-mapped page.  With
     // deferred = true the whole sequence sits behind the wait kernel (pipelined late rounds, see run_rounds): every rank's host
     // derives the same challenge at about the same time, so the ranks' all-reduces still meet.
@@ -2357,10 +2631,15 @@ static int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, 
         DeviceGate gate_(p->device);
         int rc = launch_round(p, r, p->d_wide, false, deferred);
         if (rc) return rc;
-        if (on_stream) NCCL_TRY(g_nccl.AllReduce(p->d_wide, p->d_wide, (size_t)n_words, ncclUint64, ncclSum, comm->comm, p->stream));
+        if (comm->comm) NCCL_TRY(g_nccl.AllReduce(p->d_wide, p->d_wide, (size_t)n_words, ncclUint64, ncclSum, comm->comm, p->stream));
         p->seq += 1;
         *want_out = p->seq;
-        HIP_TRY(scd::launch_publish_words(p->d_wide, p->h_wide_dev, n_words, p->h_flag_dev, *want_out, p->stream));
+        if (p2p) { // the all-reduce and the publication are one kernel
+            fill_xargs(xargs[*want_out & 1u]);
+            HIP_TRY(scd::launch_p2p_allreduce(xargs[*want_out & 1u], p->d_wide, p->h_wide_dev, p->h_flag_dev, *want_out, p->stream));
+        } else {
+            HIP_TRY(scd::launch_publish_words(p->d_wide, p->h_wide_dev, n_words, p->h_flag_dev, *want_out, p->stream));
+        }
         return SC_OK;
     };
     for (uint32_t i = 0; i < n_rounds; ++i) {
@@ -2388,7 +2667,22 @@ static int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, 
         bool seen = false;
         const auto t_start = std::chrono::steady_clock::now();
         while (!(seen = (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) == want))) {
+            if (p2p && __atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) == (want | scd::kP2PRetryBit)) {
+                // the exchange kernel left without its peers' words.  Ranks that share a GPU: a peer's kernels may have been queued behind
+                // it -- launch it again (pushes are idempotent, what has arrived stays).  Distinct GPUs: its bound is seconds; a peer is gone.
+                if (!comm->p2p_shared_device || next_enqueued || std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) break;
+                __atomic_store_n(p->h_flag, 0u, __ATOMIC_RELEASE);
+                std::this_thread::yield();
+                DeviceGate gate_(p->device);
+                HIP_TRY(scd::launch_p2p_allreduce(xargs[want & 1u], p->d_wide, p->h_wide_dev, p->h_flag_dev, want, p->stream));
+                continue;
+            }
             if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) break;
+        }
+        if (!seen && p2p && (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) & scd::kP2PRetryBit)) {
+            abandon_deferred(p);
+            p->exhausted = true;
+            return fail(SC_ERR_HIP, "p2p all-reduce: a peer's lanes did not arrive");
         }
         if (!seen) {
             if (p->deferred_pending) {
@@ -2481,6 +2775,9 @@ static int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, co
         if (rc) return rc;
         if (comm->comm) {
             NCCL_TRY(g_nccl.AllGather(p->d_tail_send, p->d_tail_recv, send_bytes / 8, ncclUint64, comm->comm, p->stream));
+        } else if (comm->p2p && comm->nranks > 1) {
+            rc = p2p_allgather(comm, p->d_tail_send, p->d_tail_recv, send_bytes, p->stream);
+            if (rc) return rc;
         } else {
             std::vector<uint64_t> send(send_bytes / 8), recv(send_bytes / 8 * G);
             HIP_TRY(hipMemcpyAsync(send.data(), p->d_tail_send, send_bytes, hipMemcpyDeviceToHost, p->stream));
@@ -2526,7 +2823,8 @@ static int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, co
         }
     }
     // (same reasoning as in sharded_rounds: no polling kernels on a GPU that other ranks of a host transport may share)
-    if (!comm->comm && comm->nranks > 1) p->tail->pipeline_ok = false;
+    p->tail->pipeline_ok = !p->polling_off_by_caller; // (the replicated rounds follow the shard handle's sc_prover_set_polling)
+    if (!comm->comm && comm->nranks > 1 && !(comm->p2p && !comm->p2p_shared_device)) p->tail->pipeline_ok = false;
     std::vector<sch::Fr> ch(k + m);
     rc = sc_internal_run_rounds(p->tail, rng, k + m, out_proof, ch.data());
     if (rc) return rc;

@@ -5,9 +5,18 @@
 // be consumed.  In the saturated 8 x 32-bit Montgomery product (fr_device.hpp) every one of the 128 multiply-adds
 // drags a carry instruction behind it, and every modular add/sub is three serial carry chains.  Here an element
 // is 9 signed limbs of 29 bits (radix 2^29, value = sum l_i 2^(29 i)): a column of the schoolbook product is at
-// most 9 products below 2^59 plus 9 reduction products below 2^58, which fits a signed 64-bit accumulator, so
-// the whole Montgomery product is 171 v_mad_i64_i32 with NO carry instruction, and add/sub are 9 independent
+// most 9 products below 2^59 plus 8 reduction products below 2^58, which fits a signed 64-bit accumulator, so
+// the whole Montgomery product is 153 v_mad_i64_i32 with NO carry instruction, and add/sub are 9 independent
 // v_add/v_sub (lazy: limbs may leave [0, 2^29), they are renormalised only where a bound requires it).
+//
+// SUBTRACTIVE Montgomery steps.  p = 1 (mod 2^29), so the textbook step adds m p with m = -acc mod 2^29 to clear the
+// low limb.  Here the step SUBTRACTS m' p with m' = acc mod 2^29 (a single v_and): column k loses exactly its low 29
+// bits, so "clear, then shift" is the arithmetic shift alone, and every reduction product m' * (-p_l) is a SIGNED
+// multiply-add like the operand products -- one kind of instruction, one accumulator chain per column.  Measured in the
+// ISA of one product: 153 mads + 17 v_lshl_add_u64 + 16 v_ashrrev_i64 + 17 v_and, against 153 + 27 + 16 + 17 + 9 v_sub
+// + 8 v_mov for the additive form (the compiler kept the signed and the unsigned products in separate chains and paid a
+// 64-bit add per column to join them, plus the 64-bit add of m itself).  The result is (T - M p) / 2^261 with
+// 0 <= M < 2^261: congruent to T / 2^261 as before, in (T / 2^261 - p, T / 2^261] instead of [T / 2^261, T / 2^261 + p).
 //
 // Montgomery radix.  9 x 29 = 261, so fe_mul(a, b) = a*b / 2^261 (mod p), while tables hold the reference's
 // R = 2^256 form.  Multiplying two R-form values therefore yields the R-form product times 2^-5.  The kernels
@@ -18,7 +27,7 @@
 //
 // Bounds (|limb| of the two operands of fe_mul): one operand <= 2^30 (a normalised value plus one lazy add or
 // sub), the other <= 2^29 (normalised, or a difference of two normalised values).  Then every column is below
-// 9*2^59 + 9*2^58 + carry < 2^63.  Values (not limbs) stay below 2^259 in magnitude, results below 2^257.
+// 9*2^59 + 8*2^58 + carry < 2^63 in magnitude.  Values (not limbs) stay below 2^259 in magnitude, results below 2^257 + p.
 #pragma once
 #include "fr_device.hpp"
 #include "kernels.h"
@@ -137,7 +146,7 @@ __device__ __forceinline__ void fe_store_f29(uint4 *main, uint64_t entry, const 
     main[f29_chunk(entry, 0)] = make_uint4((uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
     main[f29_chunk(entry, 1)] = make_uint4((uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
 }
-// a * b / 2^261 (mod p), |result value| < 2^257; result limbs 0..7 in [0, 2^29), limb 8 signed and small.
+// a * b / 2^261 (mod p), result value in (a b / 2^261 - p, a b / 2^261], i.e. |.| < 2^257 + p; result limbs 0..7 in [0, 2^29), limb 8 signed and small.
 template <typename B>
 __device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {
     int64_t acc = 0;
@@ -153,15 +162,14 @@ __device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int l = k - j;
-            if (j < k && l >= 1 && l < 9) acc += (int64_t)m[j] * (int64_t)fe_p_limb(l);
+            if (j < k && l >= 1 && l < 9) acc += (int64_t)m[j] * (int64_t)(-fe_p_limb(l));
         }
         if (k < 9) {
-            m[k] = (int32_t)((0u - (uint32_t)acc) & (uint32_t)kFeMask); // -p^-1 = -1 (mod 2^29)
-            acc += m[k];                                                  // p_0 = 1: clears the low 29 bits
+            m[k] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask); // subtracting m p_0 = m clears the low 29 bits: that IS the shift below
         } else {
             r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask);
         }
-        acc >>= 29; // arithmetic shift: exact because the low 29 bits are zero (k < 9) or were just extracted
+        acc >>= 29; // arithmetic shift = floor: drops the low limb (k < 9: subtracted, see above; k >= 9: just extracted)
     }
     r.l[8] = (int32_t)acc;
     return r;
@@ -169,7 +177,7 @@ __device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {
 __device__ __forceinline__ Fe fe_mul(const Fe &a, const Fe &b) { return fe_mul_t<Fe>(a, b); }
 // (a * b + c * d) / 2^261 (mod p) with ONE Montgomery reduction: 162 + 72 multiply-adds instead of 2 x 153.  For sums that are only
 // accumulated (the final products of two pairs of the same evaluation node).  Bounds: all four operands |limb| <= 2^29 + 4, so a
-// column is below 18 * 2^58.01 + 9 * 2^58 + carry < 2^63.
+// column is within 18 * 2^58.01 + 8 * 2^58 + carry < 2^63 in magnitude.
 __device__ __forceinline__ Fe fe_mul2_sum(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
     int64_t acc = 0;
     int32_t m[9];
@@ -187,11 +195,10 @@ __device__ __forceinline__ Fe fe_mul2_sum(const Fe &a, const Fe &b, const Fe &c,
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int l = k - j;
-            if (j < k && l >= 1 && l < 9) acc += (int64_t)m[j] * (int64_t)fe_p_limb(l);
+            if (j < k && l >= 1 && l < 9) acc += (int64_t)m[j] * (int64_t)(-fe_p_limb(l));
         }
         if (k < 9) {
-            m[k] = (int32_t)((0u - (uint32_t)acc) & (uint32_t)kFeMask);
-            acc += m[k];
+            m[k] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask);
         } else {
             r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask);
         }
@@ -204,8 +211,8 @@ __device__ __forceinline__ Fe fe_mul_u(const Fe &a, const FeU &u) { return fe_mu
 
 // d * r (mod p) for the round's fixed challenge r, d the lazy difference of two table entries (|limbs| < 2^29 + 16).
 // C.R[i] = (r * 2^(29 i + 58)) mod p, so S = sum_i d_i * R_i is congruent to d * r * 2^58 and already NINE columns wide: no high
-// half to fold.  Two Montgomery steps (m0, m1; p_0 = 1, -p^-1 = -1 mod 2^29) divide by 2^58:
-//   T = (S + m0 p + m1 p 2^29) / 2^58,   |T| < 2^230 + p (1 + 2^-29),
+// half to fold.  Two (subtractive) Montgomery steps (m0, m1; p_0 = 1) divide by 2^58:
+//   T = (S - m0 p - m1 p 2^29) / 2^58,   |T| < 2^230 + p (1 + 2^-29)   (T in (-p - 2^230, 2^230)),
 // 81 + 16 = 97 multiply-adds instead of the 153 of a general product.  Result limbs 0..7 in [0, 2^29), limb 8 signed, |.| < 2^24.
 // The 81 constants do not fit the SGPR file next to everything else, so the block parks them in LDS, column-major
 // (RT[12 k + i] = R[i][k], kBindLds ints), and every column's nine constants come back with three broadcast ds_read_b128 that
@@ -242,14 +249,12 @@ __device__ __forceinline__ Fe fe_mul_bind(const Fe &d, const int32_t (&RT)[kBind
 #pragma unroll
             for (int i = 0; i < 9; ++i) acc += (int64_t)d.l[i] * (int64_t)c[i];
         }
-        if (k >= 1 && k < 9) acc += (int64_t)m0 * (int64_t)fe_p_limb(k);
-        if (k >= 2) acc += (int64_t)m1 * (int64_t)fe_p_limb(k - 1);
+        if (k >= 1 && k < 9) acc += (int64_t)m0 * (int64_t)(-fe_p_limb(k));
+        if (k >= 2) acc += (int64_t)m1 * (int64_t)(-fe_p_limb(k - 1));
         if (k == 0) {
-            m0 = (int32_t)((0u - (uint32_t)acc) & (uint32_t)kFeMask);
-            acc += m0;
+            m0 = (int32_t)((uint32_t)acc & (uint32_t)kFeMask); // subtractive steps, as in fe_mul_t
         } else if (k == 1) {
-            m1 = (int32_t)((0u - (uint32_t)acc) & (uint32_t)kFeMask);
-            acc += m1;
+            m1 = (int32_t)((uint32_t)acc & (uint32_t)kFeMask);
         } else {
             r.l[k - 2] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask);
         }

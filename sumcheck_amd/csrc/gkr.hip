@@ -41,6 +41,7 @@ int sc_internal_fail(int code, const char *fmt, ...); // api.hip
 void sc_internal_gate_lock(int device);                // api.hip: the device gate (serialises the library's HIP calls per device)
 void sc_internal_gate_unlock(int device);
 int sc_internal_device();                             // api.hip: the calling thread's device (sc_set_device)
+uint64_t sc_internal_cache_limit();                   // api.hip: sc_set_cache_limit
 void sc_internal_release_eval_cache();                // api.hip: sc_poly_evaluate's cached work areas
 void sc_internal_release_handle_pool();               // api.hip: the prover sc_ml_prove keeps between one-shot proofs
 int sc_internal_run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_t *out_msgs, sch::Fr *out_challenges); // api.hip
@@ -483,7 +484,7 @@ static thread_local bool t_holds_cache = false;
 hipError_t DevBuf::reserve(size_t bytes) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!t_holds_cache && g_cache.mu.try_lock()) {
+    if (bytes <= sc_internal_cache_limit() && !t_holds_cache && g_cache.mu.try_lock()) { // (over sc_set_cache_limit: this call's own arena, freed at its end)
         t_holds_cache = true;
         leased = true;
         if (g_cache.device != dev || g_cache.cap < bytes) {

@@ -224,6 +224,27 @@ hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint6
 hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t n, hipStream_t stream);
 hipError_t launch_publish_words(const uint64_t *d_src, uint64_t *h_dst_mapped, int n, uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream);
 // recv[g][u][e] -> tabs[u][g * per + e] (elements of 32 bytes): the all-gathered remainders of G shards become U tables of G * per entries
+// Peer-to-peer all-reduce of a round's lanes (sc_comm_init_p2p): rank r PUSHES its n_words lanes into every peer's inbox (posted
+// writes over xGMI, or plain device memory when ranks share a GPU) as self-validating words (generation << 40 | value: the lanes are
+// sums of 32-bit limbs, far below 2^40), then polls its OWN inbox -- local memory -- until every source's words carry the generation,
+// adds them up, leaves the totals in `lanes` and publishes them to the host-mapped page like k_publish_words.  No collective library,
+// no second launch, no flag/data ordering to get wrong: a word that shows the generation IS the data.
+// inbox layout (uint64 words): [generation & 1][source rank][kP2PWords].
+constexpr int kP2PMaxRanks = 16, kP2PWords = 64;
+constexpr size_t kP2PInboxWords = 2 * (size_t)kP2PMaxRanks * kP2PWords;
+constexpr uint32_t kP2PRetryBit = 0x80000000u; // h_flag = seq | kP2PRetryBit: a peer had not arrived within max_spins (the host launches the kernel again)
+struct P2PArgs {
+    uint64_t *inbox[kP2PMaxRanks]; // every rank's inbox, addressable from this device
+    int nranks, rank, n_words;
+    uint32_t gen;                  // generation of this exchange, 1, 2, ... (24 bits are compared)
+    uint32_t max_spins;
+};
+struct PeerLanes {
+    const uint64_t *p[kP2PMaxRanks];
+    int n;
+};
+hipError_t launch_sum_peer_lanes(const PeerLanes &peers, uint64_t n_words, uint64_t *out, hipStream_t stream); // out[i] = sum_q peers.p[q][i]
+hipError_t launch_p2p_allreduce(const P2PArgs &args, uint64_t *d_lanes, uint64_t *h_dst_mapped, uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream);
 hipError_t launch_gather_to_tables(const uint4 *recv, uint4 *tabs, uint32_t G, uint32_t U, uint32_t per, hipStream_t stream);
 // acc (+)= in (D elements; first: acc = in); last: the sum also goes to d_out / the host-mapped page with its sequence flag (D <= 64)
 hipError_t launch_msg_accumulate(const FrHost *in, FrHost *acc, int D, bool first, bool last, FrHost *d_out, FrHost *h_out_mapped, uint32_t *h_flag_mapped,

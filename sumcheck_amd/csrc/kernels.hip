@@ -294,8 +294,8 @@ struct LoadFactor {
             asm volatile("" : "+v"(e3.l[8]) : "v"(l0.l[8])); // one product at a time: interleaving the two doubles the live constants
             const Fe h0 = fe_add(e2, fe_mul_bind(fe_sub(e3, e2), r));
             if (sl.dst_top || (mode == 3 && stop)) {
-                // internal F29 tables: ONE parallel carry pass, no modular reduction.  The value grows by < p + 2^231 per bind
-                // (fe_mul_bind: r*(e1-e0) comes back in (-2^230, p + 2^230)), i.e. stays below (rounds+1) p < 2^261 for any
+                // internal F29 tables: ONE parallel carry pass, no modular reduction.  The value moves by < p + 2^231 per bind
+                // (fe_mul_bind: r*(e1-e0) comes back in (-p - 2^230, 2^230)), i.e. stays within (rounds+1) p < 2^261 in magnitude for any
                 // nv <= 40, which every consumer tolerates: the multipliers' bounds depend on limb sizes only (limbs 0..7 are
                 // re-tightened here, the top limb stays below 2^28), and fe_to_fr reduces any |v| < 2^260 exactly.
                 lo_out = fe_carry_pass(l0);
@@ -336,11 +336,26 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
     // The live set of these shapes (at most 2 x 5 elements) fits the 168 registers of three resident blocks with 16 spills.  Four
     // multiplicands stay one pair at a time: twelve quadratic coefficients across two pairs spill 47 registers, and the scratch traffic
     // costs round 2 more (+75 us) than the shared reductions save in round 1 (-23 us) -- measured, same box.
-    if constexpr (M == 2 || M == 3 || (M == 4 && kR1)) {
+#ifdef SC_M4_PAIRS // A/B build (tools/build_variant.sh): two pairs per iteration for four multiplicands in the binding rounds too
+    constexpr bool kM4Pairs = true;
+#else
+    constexpr bool kM4Pairs = kR1;
+#endif
+    if constexpr (M == 2 || M == 3 || (M == 4 && kM4Pairs)) {
         for (; b + stride < n_pairs; b += 2 * stride, ++iter) {
             Fe P[M + 1];
             const uint64_t b2 = b + stride;
-            if constexpr (M == 4) { // round 1 only: without the bind path the twelve quadratic coefficients of two pairs (nearly) fit
+            [[maybe_unused]] auto accumulate = [&](const int t, const Fe &v) { // node t's running sum += v (the same schedule of carry passes as below)
+                Fe acc;
+#pragma unroll
+                for (int l = 0; l < 9; ++l) acc.l[l] = my[(9 * t + l) * kBlock];
+                acc = fe_add(acc, v);
+                if (iter & 1u) acc = fe_carry_pass(acc);
+                if ((iter & 31u) == 31u) acc = fe_from_fr(fe_to_fr(acc));
+#pragma unroll
+                for (int l = 0; l < 9; ++l) my[(9 * t + l) * kBlock] = acc.l[l];
+            };
+            if constexpr (M == 4) { // round 1 only: without the bind path the twelve quadratic coefficients of two pairs fit
                 Fe a0, a1, ai, b0, b1, bi, c0, c1, ci, d0, d1, di; // a, b: pair b's two quadratics; c, d: pair b2's
                 {
                     Fe l0, h0, l1, h1;
@@ -377,14 +392,29 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
                     d1 = fe_mul(h2, h3);
                     di = fe_mul(fe_sub(h2, l2), fe_sub(h3, l3));
                 }
-                P[0] = fe_mul2_sum(a0, b0, c0, d0);
-                P[1] = fe_mul2_sum(a1, b1, c1, d1);
-                P[2] = fe_mul2_sum(ai, bi, ci, di);
-                // q(-1) = 2 q(0) + 2 q(inf) - q(1), q(2) = 2 q(1) + 2 q(inf) - q(0), re-tightened for the shared reduction
-                auto qm1 = [](const Fe &q0, const Fe &q1, const Fe &qi) { return fe_carry_pass(fe_sub(fe_add(fe_add(qi, qi), fe_add(q0, q0)), q1)); };
-                auto qp2 = [](const Fe &q0, const Fe &q1, const Fe &qi) { return fe_carry_pass(fe_sub(fe_add(fe_add(qi, qi), fe_add(q1, q1)), q0)); };
-                P[3] = fe_mul2_sum(qm1(a0, a1, ai), qm1(b0, b1, bi), qm1(c0, c1, ci), qm1(d0, d1, di));
-                P[4] = fe_mul2_sum(qp2(a0, a1, ai), qp2(b0, b1, bi), qp2(c0, c1, ci), qp2(d0, d1, di));
+                // Every node's product goes into its running sum as soon as it exists (nothing waits in registers), and BEFORE nodes -1
+                // and 2 each quadratic's three coefficients are replaced by its two extension values -- q(-1) = 2 q(0) + 2 q(inf) - q(1),
+                // q(2) = 2 q(1) + 2 q(inf) - q(0), re-tightened for the shared reduction -- so that those products see eight live
+                // elements instead of twelve coefficients plus four temporaries (the 136 bytes of scratch per lane this path used to need).
+                accumulate(0, fe_mul2_sum(a0, b0, c0, d0));
+                accumulate(1, fe_mul2_sum(a1, b1, c1, d1));
+                accumulate(2, fe_mul2_sum(ai, bi, ci, di));
+                auto extend = [](Fe &q0, Fe &q1, const Fe &qi) { // (q0, q1) <- (q(-1), q(2))
+                    const Fe t = fe_add(qi, qi);
+                    const Fe m1 = fe_carry_pass(fe_sub(fe_add(t, fe_add(q0, q0)), q1));
+                    const Fe p2 = fe_carry_pass(fe_sub(fe_add(t, fe_add(q1, q1)), q0));
+                    q0 = m1;
+                    q1 = p2;
+                };
+                extend(a0, a1, ai);
+                extend(b0, b1, bi);
+                extend(c0, c1, ci);
+                extend(d0, d1, di);
+                fe_pin3(a0, b0, c0);
+                fe_pin3(a1, b1, c1);
+                accumulate(3, fe_mul2_sum(a0, b0, c0, d0));
+                accumulate(4, fe_mul2_sum(a1, b1, c1, d1));
+                continue;
             } else if constexpr (M == 2) {
                 Fe l0, h0, l1, h1, m0, k0, m1, k1;
                 LoadFactor<0, kR1>::run(S, b, r, l0, h0);
@@ -1905,6 +1935,67 @@ __global__ void k_publish_words(const uint64_t *__restrict__ src, uint64_t *__re
 }
 hipError_t launch_publish_words(const uint64_t *d_src, uint64_t *h_dst_mapped, int n, uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream) {
     hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, stream, d_src, h_dst_mapped, n, h_flag_mapped, seq);
+    return hipGetLastError();
+}
+
+// sc_comm_init_p2p: the round's all-reduce as ONE small kernel per rank (kernels.h: P2PArgs)
+__global__ __launch_bounds__(kP2PWords) void k_p2p_allreduce(const P2PArgs A, uint64_t *__restrict__ lanes, uint64_t *__restrict__ h_dst,
+                                                             uint32_t *__restrict__ h_flag, const uint32_t seq) {
+    __shared__ uint32_t missing;
+    const int w = threadIdx.x;
+    const uint64_t tag = (uint64_t)(A.gen & 0xffffffu) << 40, mask = (1ULL << 40) - 1;
+    const size_t half = (size_t)(A.gen & 1u) * kP2PMaxRanks * kP2PWords;
+    if (w == 0) missing = 0;
+    __syncthreads();
+    uint64_t sum = 0;
+    if (w < A.n_words) {
+        const uint64_t mine = lanes[w];
+        for (int q = 0; q < A.nranks; ++q) // push: my word w into slot `rank` of every inbox (my own included: one code path)
+            __hip_atomic_store(A.inbox[q] + half + (size_t)A.rank * kP2PWords + w, tag | (mine & mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint64_t *in = A.inbox[A.rank] + half;
+        for (int q = 0; q < A.nranks; ++q) { // pull from local memory: the poll that sees the generation has fetched the value
+            uint64_t x = 0;
+            uint32_t spins = 0;
+            while (((x = __hip_atomic_load(in + (size_t)q * kP2PWords + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) & ~mask) != tag) {
+                if (++spins > A.max_spins) {
+                    missing = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            sum += x & mask;
+        }
+    }
+    __syncthreads();
+    if (missing) { // nothing is published but the request to run again (pushes are idempotent; what has arrived stays)
+        if (w == 0) __hip_atomic_store(h_flag, seq | kP2PRetryBit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    if (w < A.n_words) {
+        lanes[w] = sum;
+        h_dst[w] = sum;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (w == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_p2p_allreduce(const P2PArgs &args, uint64_t *d_lanes, uint64_t *h_dst_mapped, uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream) {
+    if (args.n_words > kP2PWords || args.nranks > kP2PMaxRanks) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(kP2PWords), 0, stream, args, d_lanes, h_dst_mapped, h_flag_mapped, seq);
+    return hipGetLastError();
+}
+
+// table-sized all-reduce of a p2p group (sharded GKR initialisation): every rank adds up all ranks' lanes, read in place over xGMI
+__global__ __launch_bounds__(kBlock) void k_sum_peer_lanes(const PeerLanes P, const uint64_t n_words, uint64_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * kBlock) {
+        uint64_t s = 0;
+        for (int q = 0; q < P.n; ++q) s += P.p[q][i];
+        out[i] = s;
+    }
+}
+hipError_t launch_sum_peer_lanes(const PeerLanes &peers, uint64_t n_words, uint64_t *out, hipStream_t stream) {
+    const int grid = (int)std::min<uint64_t>((n_words + kBlock - 1) / kBlock, 2048);
+    hipLaunchKernelGGL(k_sum_peer_lanes, dim3(std::max(grid, 1)), dim3(kBlock), 0, stream, peers, n_words, out);
     return hipGetLastError();
 }
 

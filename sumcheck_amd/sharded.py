@@ -291,6 +291,34 @@ class NativeComm:
             pass
 
 
+class P2PComm:
+    """A peer-to-peer communicator (sc_comm_init_p2p): the ranks are THREADS of this process with one GPU each (or, in functional
+    tests, sharing one); a round's all-reduce is one kernel per rank writing into its peers' inboxes.  Every rank's thread calls this
+    constructor with the same group id (the call blocks until all have)."""
+
+    def __init__(self, group_id: int, rank: int, world: int, device=None):
+        self.rank, self.world = rank, world
+        if device is not None:
+            import torch
+            check(lib().sc_set_device(torch.device(device).index or 0))
+        self._h = C.c_void_p()
+        check(lib().sc_comm_init_p2p(group_id, rank, world, C.byref(self._h)))
+
+    def selftest(self):
+        check(lib().sc_comm_selftest(self._h))
+
+    def close(self):
+        if self._h:
+            lib().sc_comm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HostComm:
     """A HOST-transport communicator (sc_comm_init_host): the library hands the (deg+1) x 8 uint64 lanes of a round, and the
     tail's U x 32 bytes, to two Python callables that exchange host buffers.  Two transports are provided: torch.distributed

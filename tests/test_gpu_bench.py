@@ -35,6 +35,11 @@ def test_bench_line_single_gpu():
     # one thread, all cores, all cores with the improved bind, and the CPU model, side by side
     assert cb["one_thread"]["cores"] == 1 and cb["one_thread"]["value"] > 0 and cb["all_cores_improved_bind"]["value"] > 0 and cb["cpu_model"]
     assert d["scaling"] == "strong" and "config 3" in d["config"]["workload"] and d["config"]["round_loop"] == "library"
+    # the line certifies its own parity: the timed proof and one after the timed region against the CPU leg's proof of the same instance
+    par = d["parity"]
+    assert par["ok"] is True and par["rounds"] == 19 and par["rounds_equal"] == 19 and par["rounds_equal_after_timed_region"] == 19
+    assert "phases_s" in cb and cb["phases_s"]["sums"] > 0 and cb["whole_prove"]["value"] > 0
+    assert "traffic_source" in rf
 
 
 def _two_ranks(extra):
@@ -56,5 +61,6 @@ def test_bench_line_two_ranks_one_gpu():
     d = _two_ranks(["--nv", "16"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["cpu_baseline"] is None
     assert d["config"]["nv"] == 16 and d["config"]["nv_per_gpu"] == 15 and d["config"]["round_loop"].startswith("library")
+    assert "self-test passed" in d["config"]["round_loop_reason"].replace("_", "-").replace("sc-comm-selftest", "self-test") and d["parity"]["ok"] is None
     d = _two_ranks(["--config", "4", "--nv", "17"])
     assert d["config"]["tables"] == 3 and d["config"]["nv_per_gpu"] == 16 and "config 4" in d["config"]["workload"]

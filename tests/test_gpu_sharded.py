@@ -75,6 +75,133 @@ def test_sharded_proof_threads_on_one_gpu(G, nv, nt, shapes):
             assert np.array_equal(rand, wrand), f"rank {r}"
 
 
+_P2P_GROUP = [7000]
+
+
+@pytest.mark.parametrize("G,nv,nt,shapes", [
+    (2, 13, 4, [[0, 1, 2], [3, 3], [1]]),
+    (4, 19, 10, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]),
+    (2, 20, 3, [[0, 1, 2]]),
+    (8, 12, 2, [[0, 1], [1]]),
+])
+def test_sharded_proof_peer_to_peer_exchange_threads_on_one_gpu(G, nv, nt, shapes):
+    """sc_comm_init_p2p: the per-round all-reduce as one kernel per rank pushing self-validating words into its peers' inboxes (no RCCL,
+    no host transport), the tail's gather as peer copies.  Functionally on ONE GPU: the G thread ranks share it, so the exchange kernel
+    gives up quickly when a peer's kernels have not run yet and the host launches it again.  Includes the group's self-test (peer
+    all-gather + table-sized peer all-reduce).  Every rank's proof equals the unsharded oracle proof."""
+    tabs, coefs, want, wrand = _oracle(nv, shapes, nt, 4300 + nv)
+    _P2P_GROUP[0] += 1
+    gid = _P2P_GROUP[0]
+    out = [None] * G
+
+    def mk(rank):
+        c = sharded.P2PComm(gid, rank, G, "cuda:0")
+        c.selftest()
+        return c
+
+    ts = [threading.Thread(target=_thread_rank, args=(r, G, nv, shapes, tabs, coefs, mk, 0, out)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    for r in range(G):
+        assert not isinstance(out[r], Exception) and out[r] is not None, out[r]
+        for proof, rand in out[r]:
+            assert np.array_equal(proof, want), f"rank {r}"
+            assert np.array_equal(rand, wrand), f"rank {r}"
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_proof_peer_to_peer_one_thread_per_gpu(world):
+    """the same on distinct GPUs (xGMI peer writes, pipelined late rounds): skipped below `world` visible GPUs"""
+    if _n_gpus() < world:
+        pytest.skip(f"needs {world} visible GPUs")
+    nv, shapes, nt = 21, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10
+    tabs, coefs, want, wrand = _oracle(nv, shapes, nt, 97)
+    _P2P_GROUP[0] += 1
+    gid = _P2P_GROUP[0]
+    out = [None] * world
+    ts = [threading.Thread(target=lambda r=r: _thread_rank(r, world, nv, shapes, tabs, coefs, lambda rank: sharded.P2PComm(gid, rank, world, f"cuda:{rank}"), r, out))
+          for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    for r in range(world):
+        assert not isinstance(out[r], Exception), out[r]
+        for proof, rand in out[r]:
+            assert np.array_equal(proof, want) and np.array_equal(rand, wrand)
+
+
+def test_sharded_proof_host_transport_with_delays_and_reordering():
+    """lock-order shake-out: four thread ranks on one GPU over a host transport that sleeps a random time before and after every
+    exchange and lets the ranks enter in a random order, while a fifth thread keeps proving on the same GPU through the ordinary
+    (pipelined, persistent-tail) path -- the per-device gate, the tail slot and the transport must never wait on each other in a cycle.
+    Every proof equals the oracle's."""
+    import random
+    import time
+    G, nv, nt, shapes = 4, 17, 4, [[0, 1, 2], [3, 3], [1]]
+    tabs, coefs, want, wrand = _oracle(nv, shapes, nt, 4400)
+    ex = sharded.ThreadExchange(G)
+    rnd = random.Random(5)
+
+    def jitter_comm(rank):
+        base = ex.comm
+        inner_ar, inner_ag = {}, {}
+
+        def allreduce(a):
+            time.sleep(rnd.random() * 2e-3)
+            parts = ex._exchange(rank, a)
+            time.sleep(rnd.random() * 1e-3)
+            tot = np.zeros_like(a)
+            for x in parts:
+                tot += x
+            return tot
+
+        def allgather(b):
+            time.sleep(rnd.random() * 2e-3)
+            got = np.concatenate(ex._exchange(rank, b))
+            time.sleep(rnd.random() * 1e-3)
+            return got
+
+        return sharded.HostComm(rank, G, allreduce, allgather)
+
+    out = [None] * G
+    stop = threading.Event()
+    side = {"n": 0, "err": None}
+
+    def side_prover():
+        try:
+            _lib.check(sc.lib().sc_set_device(0))
+            stabs = [cref.synth_table(4401, s, 1 << 14) for s in range(3)]
+            scoefs = cref.synth_table(4401, 1000, 1)
+            swant, _ = cref.ml_prove(H.desc_from(14, [[0, 1, 2]], stabs, scoefs), threads=1)
+            poly, _ = H.hip_poly_from(14, [[0, 1, 2]], stabs, scoefs, device="cuda:0")
+            while not stop.is_set():
+                proof = sc.MLSumcheck.prove(poly)
+                assert np.array_equal(np.stack([m.evaluations for m in proof]), swant)
+                side["n"] += 1
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            side["err"] = f"{e}\n{traceback.format_exc()}"
+
+    st = threading.Thread(target=side_prover)
+    st.start()
+    ts = [threading.Thread(target=_thread_rank, args=(r, G, nv, shapes, tabs, coefs, jitter_comm, 0, out, 3)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    stop.set()
+    st.join(timeout=120)
+    assert side["err"] is None, side["err"]
+    assert side["n"] > 0
+    for r in range(G):
+        assert not isinstance(out[r], Exception) and out[r] is not None, out[r]
+        for proof, rand in out[r]:
+            assert np.array_equal(proof, want) and np.array_equal(rand, wrand), f"rank {r}"
+
+
 def test_sharded_rounds_every_local_round_in_the_library():
     """sc_ml_prove_sharded stops sharding once the global instance is latency-bound (it gathers early), so most of a small test
     instance's rounds are replicated.  This drives ALL local rounds through the sharded loop (sc_ml_prove_sharded_rounds: per-round

@@ -144,6 +144,67 @@ def test_library_host_transport_between_threads():
     assert not errs, errs
 
 
+def test_library_host_transport_between_threads_with_delays_and_reordering():
+    """gloo-free lock-order shake-out of the library's host-transport path: eight thread ranks run the collective self-test 40 times
+    over a transport stub that sleeps a random time before and after every exchange, so that the ranks enter the library's
+    collectives (which let go of the per-device gate around the callbacks: GateYield) in a different order every time, while other
+    threads of the process hammer the same gate through host-only entry points.  Nothing may deadlock, every sum must be right."""
+    import random
+    import threading
+    import time
+    from sumcheck_amd import sharded
+    import sumcheck_amd as sc
+    world, rounds = 8, 40
+    ex = sharded.ThreadExchange(world)
+    rnd = random.Random(11)
+    errs, done = [], threading.Event()
+
+    def comm_for(rank):
+        def allreduce(a):
+            time.sleep(rnd.random() * 1e-3)
+            parts = ex._exchange(rank, a)
+            time.sleep(rnd.random() * 5e-4)
+            tot = np.zeros_like(a)
+            for x in parts:
+                tot += x
+            return tot
+
+        def allgather(b):
+            time.sleep(rnd.random() * 1e-3)
+            got = np.concatenate(ex._exchange(rank, b))
+            time.sleep(rnd.random() * 5e-4)
+            return got
+        return sharded.HostComm(rank, world, allreduce, allgather)
+
+    def run(rank):
+        try:
+            c = comm_for(rank)
+            for _ in range(rounds):
+                c.selftest()
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    def bystander():  # host-only library calls from other threads while the collectives run
+        r = sc.Blake2b512Rng.setup()
+        while not done.is_set():
+            r.feed(b"x" * 200)
+            r.sample_fr()
+            sc.lib().sc_release_caches()
+
+    by = [threading.Thread(target=bystander) for _ in range(2)]
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in by + ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    done.set()
+    for t in by:
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in ts), "a rank is stuck"
+    assert not errs, errs
+
+
 def test_sharded_entry_point_validates_before_touching_a_device():
     import ctypes as C
     import sumcheck_amd as sc

@@ -1,8 +1,10 @@
-# same-box A/B of two library builds: tools/ab/libsumcheck_hip_prev.so (the previous kernels) vs the current one
-timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu -k "random_shapes or golden_rounds or full_size_fiat" 2>&1 | tail -3
+# same-box A/B of library builds: tools/ab/libsumcheck_hip_prev.so (HEAD~) vs the current one vs named variants in tools/ab/
+cat /sys/fs/cgroup/cpu.max /sys/fs/cgroup/cpuset.cpus.effective 2>/dev/null | head -3
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu -k "random_shapes or golden or full_size_fiat or field_arithmetic or two_adic or streamed" 2>&1 | tail -3
+LIBS="tools/ab/libsumcheck_hip_prev.so sumcheck_amd/libsumcheck_hip.so $AB_EXTRA"
 for rep in 1 2 3; do
-  for L in tools/ab/libsumcheck_hip_prev.so sumcheck_amd/libsumcheck_hip.so; do
+  for L in $LIBS; do
     echo -n "$L  "; SC_LIB_PATH=$PWD/$L timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), round(d['ms_per_step_min'],4), round(d['roofline']['avg_launch_ms'],4))"
   done
 done
-for L in tools/ab/libsumcheck_hip_prev.so sumcheck_amd/libsumcheck_hip.so; do echo "== $L"; SC_LIB_PATH=$PWD/$L timeout 120 python tools/round_times.py 24 2>&1 | sed -n '3,9p'; done
+for L in $LIBS; do echo "== $L"; SC_LIB_PATH=$PWD/$L timeout 120 python tools/round_times.py 24 2>&1 | sed -n '3,12p'; done
