@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 3 /* 3: sc_prover_set_polling, SC_NO_DEVICE_POLLING, sc_set_cache_limit, sc_comm_init_p2p (additions only) */
+#define SC_ABI_VERSION 3 /* 3: sc_prover_set_polling, sc_prover_set_resident, SC_NO_DEVICE_POLLING, sc_set_cache_limit, sc_comm_init_p2p (additions only) */
 #define SC_API __attribute__((visibility("default")))
 
 enum sc_status {
@@ -94,13 +94,21 @@ SC_API int sc_prover_init(const sc_poly_desc *desc, sc_prover **out);
  * overlapping the kernels of the previous one; from round 2 on the bound tables -- half the input -- are resident and everything
  * proceeds as usual.  HBM footprint: 0.84 x the tables (bound-table buffers) + 2 x U x 2^chunk_log2 x 32 bytes, instead of 2.7 x.
  * The input crosses PCIe twice (rounds 1 and 2 both need it and the challenge between them comes from the verifier).
- * Needs the merged big-round kernel: at most 12 products of at most 4 multiplicands (SC_ERR_BAD_ARG otherwise); below 2^11 entries
- * per table the handle silently copies instead.  Every other call (sc_prove_round, sc_ml_prove_handle, sc_prover_state,
- * sc_prover_reset with host tables or NULL) works on the handle unchanged. */
+ * Any product shape: up to 12 products of at most 4 multiplicands walk a chunk in one launch (the merged big-round kernel); other
+ * shapes bind the chunk table by table and sum product by product.  Below 2^11 entries per table the handle silently copies instead.
+ * Every other call (sc_prove_round, sc_prove_round_partial / sc_ml_prove_sharded -- each rank of a multi-GPU proof may stream its own
+ * shard --, sc_ml_prove_handle, sc_prover_state, sc_prover_reset with host tables or NULL) works on the handle unchanged. */
 SC_API int sc_prover_init_streamed(const sc_poly_desc *desc, uint32_t chunk_log2, sc_prover **out);
 /* r_or_null: NULL exactly on the first call, else the previous round's challenge (4 limbs).
  * out_evals: (max_multiplicands+1) x 4 limbs = [P(0), P(1), ..., P(deg)] (ProverMsg, prover.rs:13-17). */
 SC_API int sc_prove_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals);
+/* (Late rounds -- at most 2048 pairs -- of this round-by-round protocol do not pay a launch sequence each: the first of them launches
+ * one kernel for all remaining rounds, which stays on the GPU polling a host-mapped mailbox; every following sc_prove_round posts
+ * its challenge and takes the next message.  The kernel's patience is short, `patience_polls` polls of ~2 us (default 256; 0 = never
+ * use a resident kernel): a verifier that takes longer finds it gone -- it leaves after the last round it completed -- and the call
+ * proceeds with ordinary launches.  Any other call on the handle makes it leave first.  Not used while sc_prover_set_timing is on,
+ * on a caller's stream, with sc_prover_set_polling(p, 0) / SC_PIPELINE=0, or with SC_RESIDENT=0 in the environment.) */
+SC_API int sc_prover_set_resident(sc_prover *p, uint32_t patience_polls);
 /* MLSumcheck::prove_as_subprotocol pushes the final challenge without binding it (mod.rs:65-67). */
 SC_API int sc_prover_push_randomness(sc_prover *p, const uint64_t *r);
 /* Copy ProverState back to the host.  randomness: up to num_vars x 4 limbs (may be NULL);
@@ -153,7 +161,8 @@ SC_API int sc_prover_bind_final(sc_prover *p, const uint64_t *r, uint64_t *d_out
  * sc_ml_prove_sharded = MLSumcheck::prove_as_subprotocol (mod.rs:50-70) for the GLOBAL instance of nv_total variables: the
  * nv_total - log2(nranks) local rounds, then bind + all-gather + the last log2(nranks) rounds on the gathered tables.
  * p: this rank's shard, at round 0.  out_proof: nv_total x (deg+1) x 4, out_randomness: nv_total x 4 -- identical on every
- * rank.  rng_or_null: NULL = a fresh transcript.  nranks must be a power of two.
+ * rank.  rng_or_null: NULL = a fresh transcript.  nranks must be a power of two.  Every rank of a group uses the same kind of handle
+ * (all resident or all streamed: the point where the sharding stops depends on it).
  * sc_ml_prove_sharded_rounds: only the first n_rounds local rounds (PolynomialInfo of the global instance is fed first). */
 typedef struct sc_comm sc_comm;
 typedef int (*sc_allreduce_u64_fn)(void *ctx, uint64_t *inout, size_t count);

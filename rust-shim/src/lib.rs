@@ -87,6 +87,7 @@ extern "C" {
     pub fn sc_release_caches() -> c_int;
     pub fn sc_set_cache_limit(bytes: u64) -> c_int;
     pub fn sc_prover_set_polling(p: *mut sc_prover, allow: c_int) -> c_int;
+    pub fn sc_prover_set_resident(p: *mut sc_prover, patience_polls: u32) -> c_int;
     pub fn sc_fix_variables(input: *const u64, nv: u32, point: *const u64, k: u32, out: *mut u64, flags: u32) -> c_int;
     pub fn sc_poly_evaluate(desc: *const sc_poly_desc, point: *const u64, out_value: *mut u64, out_table_values_or_null: *mut u64) -> c_int;
     pub fn sc_sparse_evaluate(idx: *const u64, vals: *const u64, nnz: u64, num_vars: u32, point: *const u64, out: *mut u64) -> c_int;

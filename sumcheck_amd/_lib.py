@@ -63,6 +63,7 @@ SIGNATURES = {
     "sc_prover_free": (None, [_V]),
     "sc_prover_set_stream": (C.c_int, [_V, _V, C.c_int]),
     "sc_prover_set_polling": (C.c_int, [_V, C.c_int]),
+    "sc_prover_set_resident": (C.c_int, [_V, C.c_uint32]),
     "sc_set_cache_limit": (C.c_int, [C.c_uint64]),
     "sc_prove_round_partial": (C.c_int, [_V, _V, _V]),
     "sc_wide_reduce": (C.c_int, [_V, C.c_uint32, _V]),

@@ -232,6 +232,13 @@ struct sc_prover {
     uint32_t n_retries = 0;         // proofs repeated after an expired device-side wait (sc_ml_prove_handle)
     bool pipeline_ok = true;        // cleared when the wait-value path is unavailable (or SC_PIPELINE=0, SC_NO_DEVICE_POLLING, sc_prover_set_polling(p, 0))
     bool polling_off_by_caller = false; // ... by the caller: survives what re-enables pipeline_ok internally
+    // the interactive sc_prove_round's resident kernel (k_tail_rounds kept across calls: see resident_start)
+    struct Resident {
+        bool active = false;
+        bool first_has_bind = false;
+        uint32_t seq0 = 0, sig0 = 0, n_rounds = 0, done = 0; // done: rounds whose message the host has taken
+    } res;
+    uint32_t resident_spins = 256;  // its patience for the next call, in polls of the host-mapped mailbox (~2 us each); 0: not used
     bool deferred_pending = false;  // a round is enqueued behind the wait and still needs its challenge
     bool fused_finalize = false;    // experiments, SC_FUSED_FIN=1: the merged big-round launch finalizes in-kernel (measured: slower than the k_finalize launch)
     bool use_tail = true;           // sc_ml_prove* / GKR: the latency-bound rounds run in the persistent tail kernel (SC_TAIL=0: pipelined launches)
@@ -263,8 +270,10 @@ struct sc_prover {
     double rounds_ms = 0.0;            // accumulated ev0..ev1 (all kernels of a round incl. finalize)
 };
 
+static int resident_quiesce(sc_prover *p); // the interactive protocol's resident kernel leaves before anything else touches the handle
 static void prover_destroy(sc_prover *p) {
     if (!p) return;
+    (void)resident_quiesce(p);
     DeviceGate gate_(p->device);
     (void)hipSetDevice(p->device);
     if (p->deferred_pending && p->sig) { // release a stream that still waits for a challenge before synchronising it
@@ -312,6 +321,7 @@ static void prover_destroy(sc_prover *p) {
 
 static bool handle_pool_offer(sc_prover *p);
 extern "C" void sc_prover_free(sc_prover *p) {
+    if (p) (void)resident_quiesce(p);
     if (p && handle_pool_offer(p)) return; // (a handle sc_ml_prove built: kept for the next proof of the same shape)
     prover_destroy(p);
 }
@@ -477,8 +487,6 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     const uint64_t n = 1ULL << p->nv;
     // streamed: only where it can matter (>= 2^11 entries) and where the merged big-round kernel applies (it is what walks the chunks)
     const bool streamed = !on_device && (d->flags & SC_TABLES_STREAM) && p->nv >= 11;
-    if (streamed && !(p->merge_rounds && !p->any_generic))
-        return fail(SC_ERR_BAD_ARG, "streamed tables need at most %d products of at most 4 multiplicands", scd::kMaxRoundProds);
     const bool small_foot = borrow || streamed; // the caller's tables are only read: the handle holds the bound tables alone
     const uint64_t s0 = small_foot ? std::max<uint64_t>(n >> 1, 1) : n;
     const uint64_t s1 = small_foot ? std::max<uint64_t>(n >> 2, 1) : std::max<uint64_t>(n >> 1, 1);
@@ -559,9 +567,9 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
         HIP_TRY(hipMemcpyAsync(p->d_slot_table, slot_table.data(), slot_table.size() * 4, hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipMemcpyAsync(p->d_slot_exp, slot_exp.data(), slot_exp.size() * 4, hipMemcpyHostToDevice, p->stream));
     }
-    if (p->any_generic) {
-        HIP_TRY(hipMalloc(&p->d_cur_tables, p->U * sizeof(void *)));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_cur_tables), p->U * sizeof(void *), hipHostMallocDefault));
+    if (p->any_generic) { // (two sets: a streamed handle's chunks alternate between them, as between the staging slots)
+        HIP_TRY(hipMalloc(&p->d_cur_tables, 2 * p->U * sizeof(void *)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_cur_tables), 2 * p->U * sizeof(void *), hipHostMallocDefault));
     }
     HIP_TRY(hipStreamSynchronize(p->stream)); // inputs are copied: the caller may drop them now (prover.rs:55-59)
     return SC_OK;
@@ -620,6 +628,8 @@ extern "C" int sc_prover_init_streamed(const sc_poly_desc *desc, uint32_t chunk_
 
 extern "C" int sc_prover_set_stream(sc_prover *p, void *hip_stream, int use_own) {
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    int rc_q = resident_quiesce(p);
+    if (rc_q) return rc_q;
     DeviceGate gate_(p->device);
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -792,7 +802,7 @@ static void make_bind_const(const sch::Fr &r, scd::BindConst &rc) {
 // big-round kernel runs on the slot (round 1: sums only; round 2: bind + sums, the bound half-chunk written to its place in the
 // resident table), k_finalize turns the chunk's partials into a message and k_msg_accumulate adds it to the round's.  After round 2 the
 // bound tables (half the input) are resident and the ordinary path takes over.
-static int launch_round_streamed(sc_prover *p, const uint64_t *r_or_null, bool publish_to_host) {
+static int launch_round_streamed(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool publish_to_host) {
     if (p->exhausted) return fail(SC_ERR_NOT_ACTIVE, "Prover is not active");
     if (r_or_null && p->round == 0) return fail(SC_ERR_FIRST_ROUND_HAS_MSG, "first round should be prover first.");
     if (!r_or_null && p->round > 0) return fail(SC_ERR_MISSING_MSG, "verifier message is empty");
@@ -812,7 +822,10 @@ static int launch_round_streamed(sc_prover *p, const uint64_t *r_or_null, bool p
     if (bind) make_bind_const(r, rc);
     const uint64_t C = 1ULL << p->chunk_log2, n = 1ULL << p->nv, n_chunks = n / C;
     const uint64_t pairs_per_chunk = bind ? C / 4 : C / 2; // round 2 reads four entries per pair of the bound table
-    const int grid = std::min(scd::grid_for_pairs(pairs_per_chunk), scd::kRoundTreeGrid);
+    const bool merged = p->merge_rounds && !p->any_generic; // one launch per chunk (k_round_tree*); otherwise one launch per product
+    const int grid = merged ? std::min(scd::grid_for_pairs(pairs_per_chunk), scd::kRoundTreeGrid) : scd::grid_for_pairs(pairs_per_chunk);
+    sch::Fr r32v = sch::zero(); // (no product kernel of the per-product path binds: the chunk is bound by k_fix first)
+    const FrHost r32 = to_dev(r32v);
     p->seq += 1;
     for (uint64_t c = 0; c < n_chunks; ++c) {
         const int q = (int)(c & 1);
@@ -822,50 +835,101 @@ static int launch_round_streamed(sc_prover *p, const uint64_t *r_or_null, bool p
                                    p->copy_stream));
         HIP_TRY(hipEventRecord(p->ev_copied[q], p->copy_stream));
         HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_copied[q], 0));
-        scd::RoundArgs ra;
-        std::memset(&ra, 0, sizeof(ra));
-        ra.n_prod = (int)p->K;
-        std::vector<uint8_t> bound(p->U, 0);
-        for (uint32_t k = 0; k < p->K; ++k) {
-            const Product &pr = p->prods[k];
-            scd::TreeProd &tp = ra.prod[k];
-            tp.M = pr.M;
-            tp.partial_off = pr.partial_off;
-            int f = 0;
-            for (size_t s = 0; s < pr.tables.size(); ++s) {
-                const uint32_t u = pr.tables[s];
-                Table &t = p->tabs[u];
-                for (uint32_t rep = 0; rep < pr.exps[s]; ++rep, ++f) {
-                    scd::Slot &sl = tp.slot[f];
-                    sl.exp = 1;
-                    sl.src = reinterpret_cast<const uint4 *>(static_cast<char *>(p->ring[q]) + (((size_t)u << p->chunk_log2) * 32));
-                    sl.src_top = nullptr;
-                    if (!bind) {
-                        sl.mode = 0;
-                    } else if (!bound[u]) { // this chunk's half of the bound table, in place (F29 blocks of 128 entries stay aligned: C / 2 >= 512)
-                        sl.mode = 1;
-                        sl.dst = t.buf[0] + 2 * (c * (C / 2));
-                        sl.dst_top = p->use_f29 ? t.buf_top[0] + c * (C / 2) : nullptr;
-                        bound[u] = 1;
-                    } else {
-                        sl.mode = 3;
-                        sl.dst_top = p->use_f29 ? t.buf_top[0] : nullptr;
+        auto ring_tab = [&](uint32_t u) { return reinterpret_cast<const uint4 *>(static_cast<char *>(p->ring[q]) + (((size_t)u << p->chunk_log2) * 32)); };
+        if (merged) {
+            scd::RoundArgs ra;
+            std::memset(&ra, 0, sizeof(ra));
+            ra.n_prod = (int)p->K;
+            std::vector<uint8_t> bound(p->U, 0);
+            for (uint32_t k = 0; k < p->K; ++k) {
+                const Product &pr = p->prods[k];
+                scd::TreeProd &tp = ra.prod[k];
+                tp.M = pr.M;
+                tp.partial_off = pr.partial_off;
+                int f = 0;
+                for (size_t s = 0; s < pr.tables.size(); ++s) {
+                    const uint32_t u = pr.tables[s];
+                    Table &t = p->tabs[u];
+                    for (uint32_t rep = 0; rep < pr.exps[s]; ++rep, ++f) {
+                        scd::Slot &sl = tp.slot[f];
+                        sl.exp = 1;
+                        sl.src = ring_tab(u);
+                        sl.src_top = nullptr;
+                        if (!bind) {
+                            sl.mode = 0;
+                        } else if (!bound[u]) { // this chunk's half of the bound table, in place (F29 blocks of 128 entries stay aligned: C / 2 >= 512)
+                            sl.mode = 1;
+                            sl.dst = t.buf[0] + 2 * (c * (C / 2));
+                            sl.dst_top = p->use_f29 ? t.buf_top[0] + c * (C / 2) : nullptr;
+                            bound[u] = 1;
+                        } else {
+                            sl.mode = 3;
+                            sl.dst_top = p->use_f29 ? t.buf_top[0] : nullptr;
+                        }
                     }
                 }
             }
-        }
-        HIP_TRY(scd::launch_round_tree(ra, rc, pairs_per_chunk, p->d_partials, grid, p->stream, true));
-        if (bind) { // tables no product refers to still follow the state machine
-            for (uint32_t u = 0; u < p->U; ++u)
-                if (!bound[u])
-                    HIP_TRY(scd::launch_fix(reinterpret_cast<const uint4 *>(static_cast<char *>(p->ring[q]) + (((size_t)u << p->chunk_log2) * 32)),
-                                            p->tabs[u].buf[0] + 2 * (c * (C / 2)), to_dev(r), C / 2, p->stream));
+            HIP_TRY(scd::launch_round_tree(ra, rc, pairs_per_chunk, p->d_partials, grid, p->stream, true));
+            if (bind) { // tables no product refers to still follow the state machine
+                for (uint32_t u = 0; u < p->U; ++u)
+                    if (!bound[u]) HIP_TRY(scd::launch_fix(ring_tab(u), p->tabs[u].buf[0] + 2 * (c * (C / 2)), to_dev(r), C / 2, p->stream));
+            }
+        } else {
+            // Any other shape (more than 12 products, more than four multiplicands): the chunk is bound table by table (k_fix, into its
+            // place in the resident table, canonical reference layout) and every product then sums over what it needs -- the staged chunk
+            // in round 1, the freshly bound half-chunk in round 2 -- with the kernel launch_round would give it.
+            std::vector<const uint4 *> src(p->U);
+            for (uint32_t u = 0; u < p->U; ++u) {
+                if (bind) {
+                    uint4 *dst = p->tabs[u].buf[0] + 2 * (c * (C / 2));
+                    HIP_TRY(scd::launch_fix(ring_tab(u), dst, to_dev(r), C / 2, p->stream));
+                    src[u] = dst;
+                } else {
+                    src[u] = ring_tab(u);
+                }
+            }
+            bool ptrs_uploaded = false;
+            for (uint32_t k = 0; k < p->K; ++k) {
+                const Product &pr = p->prods[k];
+                FrHost *partials = p->d_partials + pr.partial_off;
+                ProdArgs a;
+                std::memset(&a, 0, sizeof(a));
+                if (pr.fused && p->kernel_variant == 3 && pr.M <= 4) { // product tree: one slot per FACTOR
+                    a.n_slots = (int)pr.M;
+                    int f = 0;
+                    for (size_t s2 = 0; s2 < pr.tables.size(); ++s2)
+                        for (uint32_t rep = 0; rep < pr.exps[s2]; ++rep, ++f) {
+                            a.slot[f].exp = 1;
+                            a.slot[f].mode = 0;
+                            a.slot[f].src = src[pr.tables[s2]];
+                        }
+                    HIP_TRY(scd::launch_prod_tree((int)pr.M, a, rc, pairs_per_chunk, partials, grid, p->stream));
+                } else if (pr.fused) { // node by node, carry-free arithmetic: one slot per distinct table
+                    a.n_slots = (int)pr.tables.size();
+                    for (size_t s2 = 0; s2 < pr.tables.size(); ++s2) {
+                        a.slot[s2].exp = pr.exps[s2];
+                        a.slot[s2].mode = 0;
+                        a.slot[s2].src = src[pr.tables[s2]];
+                    }
+                    HIP_TRY(scd::launch_prod_round_fe((int)pr.M, a, r32, pairs_per_chunk, partials, grid, p->stream));
+                } else { // any number of multiplicands: table pointers through device memory, one set per staging slot
+                    if (!ptrs_uploaded) {
+                        const uint4 **h = p->h_cur_tables + (size_t)q * p->U;
+                        if (c >= 2) HIP_TRY(hipEventSynchronize(p->ev_consumed[q])); // the pinned set's previous upload (chunk c - 2) has been read
+                        for (uint32_t u = 0; u < p->U; ++u) h[u] = src[u];
+                        HIP_TRY(hipMemcpyAsync(p->d_cur_tables + (size_t)q * p->U, h, p->U * sizeof(void *), hipMemcpyHostToDevice, p->stream));
+                        ptrs_uploaded = true;
+                    }
+                    HIP_TRY(scd::launch_sum_generic(p->d_cur_tables + (size_t)q * p->U, p->d_slot_table + pr.slot_off, p->d_slot_exp + pr.slot_off, (int)pr.tables.size(),
+                                                    (int)pr.M, pairs_per_chunk, partials, grid, p->stream));
+                }
+            }
         }
         HIP_TRY(scd::launch_finalize(p->d_finprods, p->h_finprods.empty() ? nullptr : p->h_finprods.data(), p->d_W, (int)p->K, (int)p->D, grid, p->d_partials,
                                      p->d_scratch, p->d_chunk_msg, nullptr, nullptr, nullptr, 0, 1, p->d_fin_mb_counter, p->stream));
         const bool last = c + 1 == n_chunks;
-        HIP_TRY(scd::launch_msg_accumulate(p->d_chunk_msg, p->d_chunk_msg + p->D, (int)p->D, c == 0, last, p->d_out, (last && publish_to_host) ? p->h_out_dev : nullptr,
-                                           (last && publish_to_host) ? p->h_flag_dev : nullptr, p->seq, p->stream));
+        HIP_TRY(scd::launch_msg_accumulate(p->d_chunk_msg, p->d_chunk_msg + p->D, (int)p->D, c == 0, last, p->d_out, last ? d_wide : nullptr,
+                                           (last && publish_to_host) ? p->h_out_dev : nullptr, (last && publish_to_host) ? p->h_flag_dev : nullptr, p->seq, p->stream));
         HIP_TRY(hipEventRecord(p->ev_consumed[q], p->stream));
     }
     if (bind) { // everything is resident now
@@ -875,7 +939,7 @@ static int launch_round_streamed(sc_prover *p, const uint64_t *r_or_null, bool p
             for (const Product &pr : p->prods)
                 for (uint32_t tt : pr.tables) referenced |= tt == u;
             t.cur = t.buf[0];
-            t.cur_top = (p->use_f29 && referenced) ? t.buf_top[0] : nullptr;
+            t.cur_top = (merged && p->use_f29 && referenced) ? t.buf_top[0] : nullptr;
             t.next = 1;
         }
     }
@@ -901,10 +965,14 @@ struct SlowCallProbe {
     }
 };
 static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool publish_to_host, bool deferred = false) {
+    if (p->res.active) { // (sc_prove_round_partial after interactive rounds)
+        int rc_q = resident_quiesce(p);
+        if (rc_q) return rc_q;
+    }
     DeviceGate gate(p->device);
     if (p->streamed && p->round < 2 && !p->exhausted) { // the inputs are still in host memory: the round is computed chunk by chunk
-        if (d_wide || deferred) return fail(SC_ERR_BAD_ARG, "streamed tables: rounds 1 and 2 are neither sharded nor pipelined");
-        return launch_round_streamed(p, r_or_null, publish_to_host);
+        if (deferred) return fail(SC_ERR_BAD_ARG, "streamed tables: rounds 1 and 2 are not pipelined");
+        return launch_round_streamed(p, r_or_null, d_wide, publish_to_host);
     }
     // validation, same precedence as the reference's panics (prover.rs:78-98)
     if (p->exhausted) return fail(SC_ERR_NOT_ACTIVE, "Prover is not active");
@@ -1197,9 +1265,14 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
 
 static int await_round(sc_prover *p, uint64_t *out_evals, uint32_t want);
 
+static int resident_start(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals);
+static int resident_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals);
 extern "C" int sc_prove_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals) {
     if (!p || !out_evals) return fail(SC_ERR_BAD_ARG, "null argument");
-    int rc = launch_round(p, r_or_null, nullptr, true);
+    // late rounds of the interactive protocol: a kernel that stays on the GPU between calls (see resident_start)
+    int rc = p->res.active ? resident_round(p, r_or_null, out_evals) : resident_start(p, r_or_null, out_evals);
+    if (rc != -1 /* kResidentGone */) return rc;
+    rc = launch_round(p, r_or_null, nullptr, true);
     if (rc) return rc;
     return await_round(p, out_evals, p->seq);
 }
@@ -1283,23 +1356,10 @@ static bool tail_possible(sc_prover *p) {
     return p->tail_max_blocks > 0;
 }
 
-// n_rounds rounds (prove_round, feed, sample) starting at the handle's next round; r_or_null = the challenge that round binds
-static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, const sch::Fr *r_or_null, uint64_t *out_msgs, sch::Fr *out_challenges) {
-    gate_lock(p->device); // until the kernel is launched; the host loop below makes no HIP calls
-    struct Unlock {
-        const int device;
-        bool held = true;
-        void release() {
-            if (held) gate_unlock(device);
-            held = false;
-        }
-        ~Unlock() { release(); }
-    } gate{p->device};
-    HIP_TRY(hipSetDevice(p->device));
-    int rc_t = collect_timing(p);
-    if (rc_t) return rc_t;
+// Launch k_tail_rounds for the handle's next n_rounds rounds (the caller holds the device gate and the device's tail slot);
+// r_or_null = the challenge the first of them binds; max_spins = how long block 0 waits for each later challenge.
+static int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null, uint32_t max_spins, scd::TailArgs &A, int &grid) {
     const uint32_t D = p->D;
-    scd::TailArgs A;
     std::memset(&A, 0, sizeof(A));
     for (uint32_t u = 0; u < p->U; ++u) {
         Table &t = p->tabs[u];
@@ -1327,11 +1387,11 @@ static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, co
     A.sig = p->sig_dev;
     A.mail_host = reinterpret_cast<const uint64_t *>(p->h_mail_dev) + 16; // the tagged slots (byte offset 128)
     A.sig0 = p->sig_seq;
-    A.max_spins = scd::wait_spins_default();
+    A.max_spins = max_spins;
     scd::FinMeta fm;
     std::memset(&fm, 0, sizeof(fm));
     std::memcpy(fm.prod, p->h_finprods.data(), (size_t)p->K * sizeof(FinProd));
-    int grid = 1; // (the kernel's tail_active_blocks for the first round)
+    grid = 1; // (the kernel's tail_active_blocks for the first round)
     if (A.first_pairs > (uint64_t)scd::kTailFlatPairs) {
         const uint64_t bind_blocks = (2 * A.first_pairs * p->U + scd::kBlock - 1) / scd::kBlock;
         const uint64_t sum_blocks = ((A.first_pairs + scd::kBlock - 1) / scd::kBlock) * (uint64_t)p->n_combos;
@@ -1339,6 +1399,49 @@ static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, co
     }
     HIP_TRY(scd::launch_zero_words(p->d_tail_sync, (uint32_t)((kTailSyncBytes + 64) / 4), p->stream));
     HIP_TRY(scd::launch_tail_rounds(A, p->meta, fm, grid, p->stream));
+    return SC_OK;
+}
+// where the tables are after a tail kernel that did `nb` binds
+static void tail_epilogue_tables(sc_prover *p, uint32_t nb) {
+    if (nb == 0) return;
+    for (uint32_t u = 0; u < p->U; ++u) {
+        Table &t = p->tabs[u];
+        uint4 *b0 = t.buf[t.next], *b1 = t.buf[t.next ^ 1];
+        t.cur = (nb & 1) ? b0 : b1;
+        t.cur_top = nullptr;
+        if (nb & 1) t.next ^= 1;
+    }
+}
+// the host writes challenge `vm` for the poll that waits for tag `sv`: 32-bit limb i, tagged -- every word validates itself, the
+// device's poll IS the fetch
+static void tail_post_challenge(sc_prover *p, uint32_t sv, const sch::Fr &vm) {
+    uint64_t *slot = reinterpret_cast<uint64_t *>(p->h_mail) + 16 + 8 * (sv & 1u);
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t limb = (uint32_t)(vm.l[i >> 1] >> (32 * (i & 1)));
+        __atomic_store_n(slot + i, ((uint64_t)limb << 32) | sv, __ATOMIC_RELEASE);
+    }
+}
+
+// n_rounds rounds (prove_round, feed, sample) starting at the handle's next round; r_or_null = the challenge that round binds
+static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, const sch::Fr *r_or_null, uint64_t *out_msgs, sch::Fr *out_challenges) {
+    gate_lock(p->device); // until the kernel is launched; the host loop below makes no HIP calls
+    struct Unlock {
+        const int device;
+        bool held = true;
+        void release() {
+            if (held) gate_unlock(device);
+            held = false;
+        }
+        ~Unlock() { release(); }
+    } gate{p->device};
+    HIP_TRY(hipSetDevice(p->device));
+    int rc_t = collect_timing(p);
+    if (rc_t) return rc_t;
+    const uint32_t D = p->D;
+    scd::TailArgs A;
+    int grid = 1;
+    int rc_l = tail_launch(p, n_rounds, r_or_null, scd::wait_spins_default(), A, grid);
+    if (rc_l) return rc_l;
     gate.release();
     p->seq += n_rounds;
     p->sig_seq += n_rounds - 1;
@@ -1384,12 +1487,7 @@ static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, co
             if (out_challenges) out_challenges[j] = vm;
         }
         if (j + 1 < n_rounds) { // (on the error path: a zero challenge, so that the kernel runs to its end and the stream drains)
-            const uint32_t sv = A.sig0 + j + 1;
-            uint64_t *slot = reinterpret_cast<uint64_t *>(p->h_mail) + 16 + 8 * (sv & 1u);
-            for (int i = 0; i < 8; ++i) { // 32-bit limb i, tagged: every word validates itself, the device's poll IS the fetch
-                const uint32_t limb = (uint32_t)(vm.l[i >> 1] >> (32 * (i & 1)));
-                __atomic_store_n(slot + i, ((uint64_t)limb << 32) | sv, __ATOMIC_RELEASE);
-            }
+            tail_post_challenge(p, A.sig0 + j + 1, vm);
             if (rc == SC_OK) p->randomness.push_back(vm);
         }
     }
@@ -1401,18 +1499,138 @@ static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, co
     }
     // the handle's state after the tail: rounds done, challenges bound, where the tables are
     p->round += n_rounds;
-    const uint32_t nb = n_rounds - 1 + (r_or_null ? 1 : 0);
-    if (nb > 0) {
-        for (uint32_t u = 0; u < p->U; ++u) {
-            Table &t = p->tabs[u];
-            uint4 *b0 = t.buf[t.next], *b1 = t.buf[t.next ^ 1];
-            t.cur = (nb & 1) ? b0 : b1;
-            t.cur_top = nullptr;
-            if (nb & 1) t.next ^= 1;
-        }
-    }
+    tail_epilogue_tables(p, n_rounds - 1 + (r_or_null ? 1 : 0));
     p->timed = false;
     return SC_OK;
+}
+
+// ---- the resident kernel of the INTERACTIVE protocol ---------------------------------------------------------------------------
+// IPForMLSumcheck::prove_round called round by round (prover.rs:74-77; mod.rs:59-64 with a caller's own FeedableRNG) pays a launch
+// sequence per late round: bind, sums, finalize -- 26-30 us for a few microseconds of arithmetic.  Instead, the first late-round call
+// launches the persistent tail kernel for ALL remaining rounds and returns its first message; the kernel stays on the GPU polling the
+// host-mapped mailbox, and every following sc_prove_round only posts its challenge and waits for the next message.  The kernel's
+// patience is short (resident_spins polls, ~0.5 ms): a verifier that does not answer in time finds the kernel gone -- it leaves cleanly
+// after the last round it completed, tables consistent -- and the call proceeds as if there had never been one (a launch sequence, or a
+// new resident kernel).  Every other entry point that touches the handle's stream or tables quiesces it first (a tagged stop word).
+constexpr int kResidentGone = -1; // internal: no resident kernel serves this round; take the ordinary path
+static bool resident_release_slot(sc_prover *p) {
+    g_tail_busy[(unsigned)p->device & 63u].store(0, std::memory_order_release);
+    return true;
+}
+// the kernel has exited (all rounds done, patience expired, or stop word): fold what it did into the handle
+static int resident_finish(sc_prover *p) {
+    if (!p->res.active) return SC_OK;
+    DeviceGate gate_(p->device);
+    (void)hipSetDevice(p->device);
+    const hipError_t e = hipStreamSynchronize(p->stream);
+    const sc_prover::Resident r = p->res;
+    p->res.active = false;
+    p->seq = r.seq0 - 1 + r.done;
+    p->sig_seq = r.sig0 + r.done; // past every tag a word of the mailbox may carry (an unconsumed challenge, the stop word)
+    if (p->sig) __atomic_store_n(p->sig + 1, 0u, __ATOMIC_RELEASE); // its exit marker is not a voided proof
+    resident_release_slot(p);
+    if (e != hipSuccess) {
+        p->exhausted = true;
+        return fail(SC_ERR_HIP, "the resident round kernel failed: %s", hipGetErrorString(e));
+    }
+    if (r.done == 0) { // it never published: the tables may be half bound
+        p->exhausted = true;
+        return fail(SC_ERR_HIP, "the resident round kernel left before its first message");
+    }
+    tail_epilogue_tables(p, r.done - 1 + (r.first_has_bind ? 1 : 0));
+    p->timed = false;
+    return SC_OK;
+}
+// ask it to leave (any entry point other than sc_prove_round), then fold
+static int resident_quiesce(sc_prover *p) {
+    if (!p || !p->res.active) return SC_OK;
+    if (p->res.done < p->res.n_rounds) { // it is (or will be) polling for the challenge tagged sig0 + done: word 0 with the stop bit
+        const uint32_t want = p->res.sig0 + p->res.done;
+        uint64_t *slot = reinterpret_cast<uint64_t *>(p->h_mail) + 16 + 8 * (want & 1u);
+        __atomic_store_n(slot, (uint64_t)(want ^ 0x80000000u), __ATOMIC_RELEASE);
+    }
+    return resident_finish(p);
+}
+// wait for the message of the kernel's round j.  SC_OK: in out_evals; kResidentGone: the kernel left before computing it
+static int resident_wait(sc_prover *p, uint32_t j, uint64_t *out_evals) {
+    const uint32_t want = p->res.seq0 + j;
+    uint64_t spins = 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    for (;;) {
+        if (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) == want) break;
+        if ((++spins & 0xff) == 0) {
+            if (wait_gave_up(p)) { // (re-check the flag: the message may have been published just before an exit for another reason)
+                if (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) == want) break;
+                int rc = resident_finish(p);
+                return rc ? rc : kResidentGone;
+            }
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) {
+                (void)resident_quiesce(p);
+                p->exhausted = true;
+                return fail(SC_ERR_HIP, "the resident round kernel did not publish its message within 20 s");
+            }
+        }
+    }
+    std::memcpy(out_evals, p->h_out, (size_t)p->D * 32);
+    p->res.done = j + 1;
+    p->round += 1;
+    if (p->res.done == p->res.n_rounds) return resident_finish(p); // the last round: the kernel ends by itself
+    return SC_OK;
+}
+static bool resident_enabled(sc_prover *p) {
+    static const bool env_on = !(std::getenv("SC_RESIDENT") && std::atoi(std::getenv("SC_RESIDENT")) == 0);
+    return env_on && p->resident_spins > 0 && !p->timing && p->stream == p->own_stream;
+}
+// first late-round call: launch the kernel for every remaining round, return its first message
+static int resident_start(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals) {
+    // argument errors keep the reference's precedence: the ordinary path reports them
+    if ((r_or_null && p->round == 0) || (!r_or_null && p->round > 0)) return kResidentGone;
+    sch::Fr r = sch::zero();
+    if (r_or_null) {
+        std::memcpy(&r, r_or_null, 32);
+        if (sch::geq_p(r)) return kResidentGone;
+    }
+    if (!resident_enabled(p) || !tail_possible(p)) return kResidentGone;
+    int expect = 0;
+    if (!g_tail_busy[(unsigned)p->device & 63u].compare_exchange_strong(expect, 1, std::memory_order_acquire)) return kResidentGone;
+    const uint32_t n_rounds = p->nv - p->round;
+    scd::TailArgs A;
+    int grid = 1;
+    {
+        DeviceGate gate_(p->device);
+        int rc = hipSetDevice(p->device) == hipSuccess ? tail_launch(p, n_rounds, r_or_null ? &r : nullptr, p->resident_spins, A, grid) : SC_ERR_HIP;
+        if (rc) {
+            resident_release_slot(p);
+            return rc;
+        }
+    }
+    p->res.active = true;
+    p->res.first_has_bind = r_or_null != nullptr;
+    p->res.seq0 = A.seq0;
+    p->res.sig0 = A.sig0;
+    p->res.n_rounds = n_rounds;
+    p->res.done = 0;
+    if (r_or_null) p->randomness.push_back(r);
+    int rc = resident_wait(p, 0, out_evals);
+    if (rc == kResidentGone) { // cannot be: round 0 of the kernel waits for nobody
+        p->exhausted = true;
+        return fail(SC_ERR_HIP, "the resident round kernel left before its first message");
+    }
+    return rc;
+}
+// a following call: post the challenge, take the next message
+static int resident_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals) {
+    if (!r_or_null) return fail(SC_ERR_MISSING_MSG, "verifier message is empty"); // (round > 0 here; the kernel keeps waiting)
+    sch::Fr r;
+    std::memcpy(&r, r_or_null, 32);
+    if (sch::geq_p(r)) return fail(SC_ERR_BAD_ARG, "challenge is not a canonical field element");
+    const uint32_t j = p->res.done; // the kernel's round this call completes
+    tail_post_challenge(p, p->res.sig0 + j, r);
+    const size_t n_rand = p->randomness.size();
+    p->randomness.push_back(r);
+    int rc = resident_wait(p, j, out_evals);
+    if (rc == kResidentGone) p->randomness.resize(n_rand); // the ordinary path records it again
+    return rc;
 }
 
 // Rounds first..last-1 (0-based) of the reference's prove loop (mod.rs:57-64): prove_round, feed, sample.  Late rounds are
@@ -1488,8 +1706,11 @@ extern "C" int sc_prove_round_partial(sc_prover *p, const uint64_t *r_or_null, u
 // Bind the challenge `r` into every table once more and write the results back to back (table u at d_out + u * n * 4 limbs, n =
 // 2^(num_vars - round) entries each, canonical form whatever the tables' internal format).  After this the handle is exhausted.
 static int prover_bind_out(sc_prover *p, const uint64_t *r, uint64_t *d_out) {
+    int rc_q = resident_quiesce(p);
+    if (rc_q) return rc_q;
     DeviceGate gate_(p->device);
     if (p->exhausted || p->round == 0 || p->round > p->nv) return fail(SC_ERR_NOT_ACTIVE, "bind needs a prover that has run at least one round");
+    if (p->streamed && p->round < 2) return fail(SC_ERR_NOT_ACTIVE, "a streamed handle's tables are resident from round 2 on: nothing to bind yet");
     sch::Fr rr;
     std::memcpy(&rr, r, 32);
     if (sch::geq_p(rr)) return fail(SC_ERR_BAD_ARG, "challenge is not a canonical field element");
@@ -1527,6 +1748,10 @@ extern "C" int sc_prover_push_randomness(sc_prover *p, const uint64_t *r) {
 
 extern "C" int sc_prover_state(sc_prover *p, uint64_t *randomness, uint32_t *n_randomness, uint64_t *tables_out, uint32_t *round) {
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    if (tables_out) {
+        int rc_q = resident_quiesce(p);
+        if (rc_q) return rc_q;
+    }
     DeviceGate gate_(p->device);
     if (randomness && !p->randomness.empty()) std::memcpy(randomness, p->randomness.data(), p->randomness.size() * 32);
     if (n_randomness) *n_randomness = (uint32_t)p->randomness.size();
@@ -1567,6 +1792,8 @@ extern "C" int sc_prover_last_round_ms(sc_prover *p, float *ms) {
 
 extern "C" int sc_prover_set_timing(sc_prover *p, int on) {
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    int rc_q = resident_quiesce(p);
+    if (rc_q) return rc_q;
     DeviceGate gate_(p->device);
     HIP_TRY(hipSetDevice(p->device));
     if (on && p->prod_ev.empty()) {
@@ -1601,6 +1828,7 @@ extern "C" int sc_prover_get_timing(sc_prover *p, double *ms_per_product, uint64
 // (host pointers, or device pointers when flags has SC_TABLES_ON_DEVICE).
 extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_null, uint32_t flags) {
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    (void)resident_quiesce(p); // (a failed resident kernel leaves the handle exhausted: exactly what a reset repairs)
     DeviceGate gate_(p->device);
     HIP_TRY(hipSetDevice(p->device));
     abandon_deferred(p);
@@ -2039,9 +2267,19 @@ extern "C" int sc_set_cache_limit(uint64_t bytes) {
     return bytes < before ? sc_release_caches() : SC_OK;
 }
 
+extern "C" int sc_prover_set_resident(sc_prover *p, uint32_t patience_polls) {
+    if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    int rc_q = resident_quiesce(p);
+    if (rc_q) return rc_q;
+    p->resident_spins = patience_polls;
+    return SC_OK;
+}
+
 extern "C" int sc_prover_set_polling(sc_prover *p, int allow) {
     if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
     if (p->deferred_pending) return fail(SC_ERR_BAD_ARG, "a pipelined round is waiting for its challenge");
+    int rc_q = resident_quiesce(p);
+    if (rc_q) return rc_q;
     p->pipeline_ok = allow != 0;
     p->polling_off_by_caller = allow == 0;
     return SC_OK;
@@ -2842,7 +3080,11 @@ extern "C" int sc_ml_prove_sharded(sc_prover *p, sc_comm *comm, sc_rng *rng_or_n
     sc_rng local;
     sch::Blake2b512Rng &rng = rng_or_null ? rng_or_null->rng : local.rng;
     rng.feed_poly_info(p->max_mult, nv_total); // mod.rs:54: the GLOBAL instance's info
-    const uint32_t m = sharded_tail_m(p->nv, k), nl = p->nv - m; // nl sharded rounds, then m + k replicated ones
+    uint32_t m = sharded_tail_m(p->nv, k);
+    // a streamed shard's tables only exist in HBM once round 2 has bound them: at least two local rounds before the gather (every rank
+    // of a group uses the same kind of handle, so every rank computes the same m)
+    if (p->streamed && p->nv >= 2) m = std::min(m, p->nv - 2);
+    const uint32_t nl = p->nv - m; // nl sharded rounds, then m + k replicated ones
     int rc = sharded_rounds(p, comm, rng, nl, out_proof, out_randomness);
     if (rc) return rc;
     const uint64_t *last = out_randomness + (size_t)(nl - 1) * 4;

@@ -247,8 +247,8 @@ hipError_t launch_sum_peer_lanes(const PeerLanes &peers, uint64_t n_words, uint6
 hipError_t launch_p2p_allreduce(const P2PArgs &args, uint64_t *d_lanes, uint64_t *h_dst_mapped, uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream);
 hipError_t launch_gather_to_tables(const uint4 *recv, uint4 *tabs, uint32_t G, uint32_t U, uint32_t per, hipStream_t stream);
 // acc (+)= in (D elements; first: acc = in); last: the sum also goes to d_out / the host-mapped page with its sequence flag (D <= 64)
-hipError_t launch_msg_accumulate(const FrHost *in, FrHost *acc, int D, bool first, bool last, FrHost *d_out, FrHost *h_out_mapped, uint32_t *h_flag_mapped,
-                                 uint32_t seq, hipStream_t stream);
+hipError_t launch_msg_accumulate(const FrHost *in, FrHost *acc, int D, bool first, bool last, FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped,
+                                 uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream);
 // F29 table -> canonical reference layout (state export)
 hipError_t launch_f29_to_sat(const uint4 *src, const int32_t *src_top, uint4 *dst, uint64_t n, hipStream_t stream);
 hipError_t launch_fr_elementwise(int op, const uint4 *a, const uint4 *b, const FrHost &u, uint4 *out, uint64_t n, hipStream_t stream);

@@ -1396,12 +1396,24 @@ __device__ __forceinline__ Fr combo_term(const uint4 *p, const int32_t nv, const
     return fr_add(lo, fr_mul(fr_sub(hi, lo), tf));
 }
 
+#ifdef SC_TAIL_CLOCKS // tools/build_variant.sh tail_clocks -DSC_TAIL_CLOCKS: where a tail round's time goes (100 MHz wall clock, block 0)
+__device__ uint64_t g_tail_clk[64 * 8];
+#define TAIL_STAMP(j, i)                                                                                                                  \
+    do {                                                                                                                                  \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (j) < 64) g_tail_clk[8 * (j) + (i)] = wall_clock64();                                  \
+    } while (0)
+#else
+#define TAIL_STAMP(j, i)
+#endif
 __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const ComboMeta meta, const FinMeta fin) {
     __shared__ uint32_t sm[kBlock / 64][8];
     __shared__ uint64_t r_sh[4];
     __shared__ uint32_t stop_sh;
     extern __shared__ uint4 fin_lds[];
     const uint32_t G = gridDim.x;
+    // (the barriers' bound guards against blocks that are never scheduled, not against a slow host: never shorter than ~a second of polls,
+    // however short the patience for the next challenge is)
+    const uint32_t bar_spins = A.max_spins > (1u << 20) ? A.max_spins : (1u << 20);
     uint32_t gen = 0;
     uint64_t n_pairs = A.first_pairs;
     int binds = 0; // binds done so far: table u's current evaluations are cur0 (0), b0 (odd), b1 (even > 0)
@@ -1416,6 +1428,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
         // the later rounds synchronise a handful of blocks instead of one per CU, and the last rounds run in block 0 alone.
         const uint32_t Gj = tail_active_blocks(n_pairs, A.n_tables, A.n_combos, G);
         if (blockIdx.x >= Gj) return;
+        TAIL_STAMP(j, 0); // round start (block 0 has this round's challenge)
         const bool solo = Gj == 1; // no other block left: block barriers are enough
         if (j > 0 || A.first_has_bind) {
             // ---- this round's challenge: round 0's came with the launch; block 0 fetched the later ones from the host itself (below)
@@ -1424,11 +1437,12 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                 if (threadIdx.x < 4) r_sh[threadIdx.x] = A.r0.l[threadIdx.x];
             } else if (blockIdx.x != 0) {
                 if (threadIdx.x == 0) {
-                    // (block 0's own poll of the host is bounded by max_spins; twice that covers it, and a block 0 that is gone for good)
+                    // (block 0's own poll of the host is bounded by max_spins polls over PCIe, slower ones than these; four times that and a
+                    // floor cover it, and a block 0 that is gone for good)
                     uint32_t spins = 0;
                     bool expired = false;
                     while (__hip_atomic_load(A.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)j) {
-                        if (++spins > 2 * (A.max_spins / 2 + 1)) { expired = true; break; }
+                        if (++spins > 16u * (A.max_spins / 4 + 1) + 4096u) { expired = true; break; } // (far beyond block 0's own patience)
                         __builtin_amdgcn_s_sleep(2);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1472,10 +1486,11 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
             binds += 1;
             if (solo) {
                 __syncthreads();
-            } else if (!grid_barrier(A.sync, gen, Gj, A.max_spins, A.sig + 1, A.sig0 + (uint32_t)j + 1u, stop_sh)) {
+            } else if (!grid_barrier(A.sync, gen, Gj, bar_spins, A.sig + 1, A.sig0 + (uint32_t)j + 1u, stop_sh)) {
                 return;
             }
         }
+        TAIL_STAMP(j, 1); // bound (and barrier passed)
         if (solo) {
             // ---- flat mode: lane i of the block = (combination i / n_pairs, pair i % n_pairs); the pairs of a combination are
             // n_pairs adjacent lanes of one wavefront, summed by log2(n_pairs) shuffles; the sums go straight to finalize's scratch
@@ -1506,6 +1521,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                 }
             }
             __syncthreads();
+            TAIL_STAMP(j, 2); // node sums ready
             finalize_message<kBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 0, w_pre);
         } else {
             // ---- sums: virtual blocks (vx, combo) of the k_sum_combos launch this round would have been -------------------------
@@ -1515,7 +1531,8 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                 const uint32_t cy = v / vgx, vx = v % vgx;
                 sum_combo_body(tab, meta.combo[cy], meta.slot_table, meta.slot_exp, n_pairs, A.partials, sm, vx, vgx);
             }
-            if (!grid_barrier(A.sync, gen, Gj, A.max_spins, A.sig + 1, A.sig0 + (uint32_t)j + 1u, stop_sh)) return;
+            if (!grid_barrier(A.sync, gen, Gj, bar_spins, A.sig + 1, A.sig0 + (uint32_t)j + 1u, stop_sh)) return;
+            TAIL_STAMP(j, 2); // partial sums ready (barrier passed)
             // (vgx <= kTailMaxPairs / kBlock = 8 partials per combination: block 0 adds them up itself)
             if (blockIdx.x == 0) {
                 finalize_body<kBlock>(prod_of, A.Wm, A.K, A.D, (int)vgx, A.partials, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag,
@@ -1525,6 +1542,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
         // ---- block 0: the next challenge.  The host stores, for limb i of the challenge, the 64-bit word (limb << 32 | tag) into
         // slot word i, tag = the low 32 bits of sig0 + j + 1 xor-ed into nothing else: eight lanes poll one word each until its
         // tag matches, so the challenge arrives with the poll that sees it (no second trip over PCIe to fetch it).
+        TAIL_STAMP(j, 3); // message published
         if (blockIdx.x == 0 && j + 1 < A.n_rounds) {
             const uint32_t want = A.sig0 + (uint32_t)(j + 1);
             if (threadIdx.x < 64) {
@@ -1535,6 +1553,9 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                     if (lane < 8) w = __hip_atomic_load(A.mail_host + 8 * (want & 1u) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     const bool mine = lane >= 8 || (uint32_t)w == want;
                     if (__all(mine)) { seen = true; break; }
+                    // word 0 tagged with the stop bit: the host asks the kernel to leave (the interactive protocol's resident kernel is
+                    // quiesced before any other entry point touches the handle) -- same clean exit as an expired wait
+                    if (__any(lane == 0 && (uint32_t)w == (want ^ 0x80000000u))) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (!seen && lane == 0) { // gave up: tell the host (it voids the proof) and let every block leave
@@ -1554,6 +1575,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     __hip_atomic_store(A.sync + 2, (uint32_t)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                TAIL_STAMP(j, 4); // next challenge fetched and released
             }
         }
     }
@@ -2020,7 +2042,8 @@ hipError_t launch_gather_to_tables(const uint4 *recv, uint4 *tabs, uint32_t G, u
 
 // streamed tables: a round is computed chunk by chunk; every chunk's message (D elements) is added into `acc`, the last one publishes
 __global__ void k_msg_accumulate(const uint4 *__restrict__ in, uint4 *__restrict__ acc, const int D, const int first, const int last,
-                                 uint4 *__restrict__ d_out, uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag, const uint32_t seq) {
+                                 uint4 *__restrict__ d_out, uint64_t *__restrict__ out_wide, uint4 *__restrict__ h_out, uint32_t *__restrict__ h_flag,
+                                 const uint32_t seq) {
     const int t = threadIdx.x;
     if (t < D) {
         Fr a = fr_load(in + 2 * t);
@@ -2029,6 +2052,8 @@ __global__ void k_msg_accumulate(const uint4 *__restrict__ in, uint4 *__restrict
         if (last) {
             if (d_out) fr_store(d_out + 2 * t, a);
             if (h_out) fr_store(h_out + 2 * t, a);
+            if (out_wide) // a sharded round's lanes: the eight 32-bit limbs zero-extended (summable across ranks)
+                for (int j = 0; j < 8; ++j) out_wide[8 * t + j] = (uint64_t)a.v[j];
         }
     }
     if (last && h_flag) {
@@ -2037,10 +2062,10 @@ __global__ void k_msg_accumulate(const uint4 *__restrict__ in, uint4 *__restrict
         if (t == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-hipError_t launch_msg_accumulate(const FrHost *in, FrHost *acc, int D, bool first, bool last, FrHost *d_out, FrHost *h_out_mapped, uint32_t *h_flag_mapped,
-                                 uint32_t seq, hipStream_t stream) {
+hipError_t launch_msg_accumulate(const FrHost *in, FrHost *acc, int D, bool first, bool last, FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped,
+                                 uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream) {
     hipLaunchKernelGGL(k_msg_accumulate, dim3(1), dim3(64), 0, stream, (const uint4 *)in, (uint4 *)acc, D, first ? 1 : 0, last ? 1 : 0, (uint4 *)d_out,
-                       (uint4 *)h_out_mapped, h_flag_mapped, seq);
+                       d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq);
     return hipGetLastError();
 }
 
@@ -2061,6 +2086,11 @@ hipError_t launch_bench_modmul(uint64_t n_threads, uint32_t reps, uint32_t varia
 
 } // namespace scd
 
+#ifdef SC_TAIL_CLOCKS
+extern "C" __attribute__((visibility("default"))) int sc_debug_tail_clocks(uint64_t *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scd::g_tail_clk), sizeof(uint64_t) * 64 * 8);
+}
+#endif
 #ifdef SC_FIN_CLOCKS
 extern "C" __attribute__((visibility("default"))) int sc_debug_fin_clocks(uint64_t *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scd::g_fin_clk), sizeof(uint64_t) * 12);

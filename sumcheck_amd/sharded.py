@@ -42,7 +42,10 @@ class HipShardEngine:
     """One shard on one GPU: an sc_prover over the shard's local tables, driven through
     sc_prove_round_partial / sc_prover_bind_final on torch's current stream."""
 
-    def __init__(self, nv_local: int, shapes: Sequence[Sequence[int]], coeffs: np.ndarray, tables, device, borrow: bool = True):
+    def __init__(self, nv_local: int, shapes: Sequence[Sequence[int]], coeffs: np.ndarray, tables, device, borrow: bool = True,
+                 streamed_chunk_log2: Optional[int] = None):
+        """streamed_chunk_log2 (0 = the library's default): the shard's tables are HOST arrays that stay in host memory and are pulled
+        through HBM chunk by chunk in rounds 1 and 2 (sc_prover_init_streamed): out-of-core x multi-GPU."""
         import torch
         self.torch = torch
         self.device = torch.device(device)
@@ -50,7 +53,12 @@ class HipShardEngine:
         self.U = len(tables)
         self.D = max(len(s) for s in shapes) + 1
         self._tables = []
+        self._streamed = streamed_chunk_log2 is not None
         for t in tables:
+            if self._streamed:
+                t = t.numpy().view(np.uint64) if isinstance(t, torch.Tensor) else t
+                self._tables.append(np.ascontiguousarray(t, dtype=np.uint64))
+                continue
             if not isinstance(t, torch.Tensor):
                 t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.uint64).view(np.int64))
             self._tables.append(t.to(self.device).contiguous())
@@ -61,7 +69,7 @@ class HipShardEngine:
             offs.append(len(idx))
         offsets = np.asarray(offs, dtype=np.uint32)
         indices = np.asarray(idx, dtype=np.uint32)
-        tabs = (C.c_void_p * self.U)(*[t.data_ptr() for t in self._tables])
+        tabs = (C.c_void_p * self.U)(*[(t.ctypes.data if self._streamed else t.data_ptr()) for t in self._tables])
         d = PolyDesc()
         d.num_vars, d.max_multiplicands, d.n_products = nv_local, self.D - 1, len(shapes)
         d.coeffs = coeffs.ctypes.data_as(C.POINTER(C.c_uint64))
@@ -69,11 +77,14 @@ class HipShardEngine:
         d.prod_indices = indices.ctypes.data_as(C.POINTER(C.c_uint32))
         d.n_tables = self.U
         d.tables = C.cast(tabs, C.POINTER(C.c_void_p))
-        d.flags = SC_TABLES_ON_DEVICE | (SC_TABLES_BORROW if borrow else 0)
+        d.flags = 0 if self._streamed else (SC_TABLES_ON_DEVICE | (SC_TABLES_BORROW if borrow else 0))
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(lib().sc_set_device(self.device.index or 0))
-            check(lib().sc_prover_init(C.byref(d), C.byref(self._h)))
+            if self._streamed:
+                check(lib().sc_prover_init_streamed(C.byref(d), int(streamed_chunk_log2), C.byref(self._h)))
+            else:
+                check(lib().sc_prover_init(C.byref(d), C.byref(self._h)))
             check(lib().sc_prover_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), 0))
 
     def round_partial(self, r: Optional[np.ndarray]):

@@ -609,6 +609,9 @@ def test_gkr_scratch_cache_release_and_reuse():
     (13, 2, [[0, 1], [1]], 13),                              # one chunk
     (18, 3, [[0, 1, 2]], 0),                                 # default chunk (clamped to the table): one chunk, big rounds after it
     (9, 3, [[0, 1, 2]], 10),                                 # too small to stream: silently the copying handle
+    (13, 4, [[0, 0, 1, 2, 3], [1, 2]], 11),                  # five multiplicands: per-product launches per chunk (node-by-node kernel), 4 chunks
+    (12, 3, [[0, 1, 2, 0, 1, 2, 0, 1, 2, 0], [2]], 10),      # ten multiplicands: the generic kernel over per-chunk pointer sets
+    (12, 4, [[i % 4, (i + 1) % 4] for i in range(14)], 10),   # fourteen products: more than the merged launch takes
 ])
 def test_streamed_host_tables_match_oracle(nv, nt, shapes, chunk):
     """out-of-core mode (sc_prover_init_streamed): the tables stay in host memory and rounds 1 and 2 are computed chunk by chunk
@@ -641,11 +644,66 @@ def test_streamed_host_tables_match_oracle(nv, nt, shapes, chunk):
     assert np.array_equal(st.randomness, wrand)
     for m, t in zip(mles, tabs):  # the streamed inputs are only read
         assert np.array_equal(m.evaluations, t)
-    if nv >= 11:  # longer products than the merged big-round kernel takes are refused, not mis-computed
-        p5 = sc.ListOfProductsOfPolynomials(nv)
-        p5.add_product([mles[0]] * 5, coefs[0])
-        with pytest.raises(sc.SumcheckError, match="streamed tables need"):
-            sc.IPForMLSumcheck.prover_init(p5, streamed_chunk_log2=chunk)
+
+
+@pytest.mark.parametrize("nv,nt,shapes", [(14, 10, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]), (9, 3, [[0, 1, 2], [2, 2]]), (13, 2, [[0, 1]])])
+def test_interactive_rounds_resident_kernel(nv, nt, shapes):
+    """IPForMLSumcheck::prove_round round by round (prover.rs:74-77): the late rounds are served by ONE kernel that stays on the GPU
+    between calls.  Every message against the oracle's, through every way the dialogue can go: back to back; a verifier that takes
+    longer than the kernel's patience (it leaves, the call launches afresh); a state export in the middle (it is asked to leave);
+    a misuse error in the middle (MISSING_MSG: the kernel keeps waiting); a reset in the middle; the handle freed while it waits; and
+    with the resident kernel switched off (sc_prover_set_resident(p, 0)).  Bound tables and randomness compared where exported."""
+    import time
+    tabs = [cref.synth_table(7100 + nv, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(7100 + nv, 1000, len(shapes))
+    chal = cref.synth_table(7100 + nv, 2000, nv)
+    d = H.desc_from(nv, shapes, tabs, coefs)
+    op = cref.Prover(d, threads=4)
+    want, wtabs = [], {}
+    for i in range(nv):
+        want.append(op.prove_round(None if i == 0 else chal[i - 1]))
+        wtabs[i + 1] = op.state()[1]
+    poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device="cuda:0")
+    vmsg = [None] + [sc.VerifierMsg(chal[i]) for i in range(nv - 1)]
+
+    def dialogue(st, pause_at=(), export_at=(), misuse_at=(), stop_after=None):
+        got = []
+        for i in range(nv):
+            if i in pause_at:
+                time.sleep(0.02)  # far beyond the patience of ~0.5 ms
+            if i in misuse_at and i > 0:
+                with pytest.raises(sc.SumcheckError, match="verifier message is empty"):
+                    sc.IPForMLSumcheck.prove_round(st, None)
+            got.append(sc.IPForMLSumcheck.prove_round(st, vmsg[i]).evaluations)
+            assert np.array_equal(got[-1], want[i]), f"round {i + 1}"
+            if (i + 1) in export_at:
+                for u, t in enumerate(st.flattened_ml_extensions):
+                    assert np.array_equal(t.evaluations, wtabs[i + 1][u]), f"table {u} after round {i + 1}"
+                assert st.round == i + 1 and np.array_equal(st.randomness, chal[:i])
+            if stop_after is not None and i + 1 == stop_after:
+                return got
+        assert st.round == nv and np.array_equal(st.randomness, chal[: nv - 1])
+        for u, t in enumerate(st.flattened_ml_extensions):
+            assert np.array_equal(t.evaluations, wtabs[nv][u])
+        return got
+
+    st = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+    dialogue(st)                                                     # back to back
+    st.reset(); dialogue(st, pause_at={nv - 3, nv - 1})              # the kernel's patience expires twice
+    st.reset(); dialogue(st, export_at={max(nv - 5, 1), nv - 2})     # quiesced for a state export, twice
+    st.reset(); dialogue(st, misuse_at={nv - 4, nv - 2})             # errors in between do not disturb it
+    st.reset(); dialogue(st, stop_after=nv - 2)                      # abandoned two rounds before the end ...
+    st.reset(); dialogue(st)                                         # ... reset while it waits, and proved again
+    _lib.check(sc.lib().sc_prover_set_resident(st._h, 0))
+    st.reset(); dialogue(st, export_at={nv - 3})                     # without the resident kernel: the launch sequence per round
+    _lib.check(sc.lib().sc_prover_set_resident(st._h, 256))
+    st.reset(); dialogue(st, stop_after=nv - 1)
+    st.close()                                                       # freed while the kernel waits for the last challenge
+    st2 = sc.IPForMLSumcheck.prover_init(poly, borrow=True)          # (the pool hands the same handle back)
+    dialogue(st2)
+    with pytest.raises(sc.SumcheckError, match="Prover is not active"):
+        sc.IPForMLSumcheck.prove_round(st2, vmsg[1])
+    st2.close()
 
 
 def test_provers_on_several_threads_share_one_gpu():

@@ -202,6 +202,49 @@ def test_sharded_proof_host_transport_with_delays_and_reordering():
             assert np.array_equal(proof, want) and np.array_equal(rand, wrand), f"rank {r}"
 
 
+@pytest.mark.parametrize("G,nv,nt,shapes,chunk", [
+    (2, 14, 3, [[0, 1, 2]], 11),                              # 2 ranks x 4 chunks, merged kernel per chunk
+    (4, 15, 4, [[0, 0, 1, 2, 3], [1, 2]], 11),                # 4 ranks x 4 chunks, per-product launches per chunk
+])
+def test_sharded_proof_with_streamed_shards(G, nv, nt, shapes, chunk):
+    """out-of-core x multi-GPU: every rank keeps its shard of the tables in HOST memory and streams it through HBM chunk by chunk in
+    rounds 1 and 2 (sc_prover_init_streamed on the shard), the sharded loop all-reducing the streamed rounds' lanes like any other round;
+    whole proof vs the unsharded oracle, twice on the rewound handles (reference site of what this replaces: prover.rs:55-59, the deep
+    copy of tables that do not fit)"""
+    tabs, coefs, want, wrand = _oracle(nv, shapes, nt, 4500 + nv)
+    ex = sharded.ThreadExchange(G)
+    out = [None] * G
+    n_loc = (1 << nv) // G
+
+    def run(rank):
+        try:
+            _lib.check(sc.lib().sc_set_device(0))
+            eng = sharded.HipShardEngine(nv - (G.bit_length() - 1), shapes, coefs, [np.ascontiguousarray(t[rank * n_loc:(rank + 1) * n_loc]) for t in tabs],
+                                         "cuda:0", streamed_chunk_log2=chunk)
+            comm = ex.comm(rank)
+            res = []
+            for _ in range(2):
+                eng.reset()
+                res.append(sharded.prove_sharded_library(eng, comm, nv))
+            comm.close()
+            eng.close()
+            out[rank] = res
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            out[rank] = RuntimeError(f"rank {rank}: {e}\n{traceback.format_exc()}")
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    for r in range(G):
+        assert not isinstance(out[r], Exception) and out[r] is not None, out[r]
+        for proof, rand in out[r]:
+            assert np.array_equal(proof, want), f"rank {r}"
+            assert np.array_equal(rand, wrand), f"rank {r}"
+
+
 def test_sharded_rounds_every_local_round_in_the_library():
     """sc_ml_prove_sharded stops sharding once the global instance is latency-bound (it gathers early), so most of a small test
     instance's rounds are replicated.  This drives ALL local rounds through the sharded loop (sc_ml_prove_sharded_rounds: per-round

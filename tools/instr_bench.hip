@@ -50,14 +50,17 @@ KERNEL(k_mad_u32_u16, "v_mad_u32_u16 %0, %1, %2, %0\n", "memory")
 KERNEL(k_dot4_u32_u8, "v_dot4_u32_u8 %0, %1, %2, %0\n", "memory")
 KERNEL(k_mad_i32_i24, "v_mad_i32_i24 %0, %1, %2, %0\n", "memory")
 
+KERNEL(k_madi64_dep, "v_mad_i64_i32 %4, s[20:21], %1, %2, %4\n", "s20", "s21") // one DEPENDENT chain (latency when few waves share a SIMD)
+KERNEL(k_madi64_2dep, "v_mad_i64_i32 %4, s[20:21], %1, %2, %4\nv_mad_i64_i32 %5, s[22:23], %0, %3, %5\n", "s20", "s21", "s22", "s23")
+
 template <typename K>
-static double run(K kern, const char *name, int per_iter, double ref) {
+static double run(K kern, const char *name, int per_iter, double ref, int blocks_per_cu = 8) {
     uint32_t *d;
     hipMalloc(&d, 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    const int blocks = 256 * 8, reps = 4000;
+    const int blocks = 256 * blocks_per_cu, reps = 4000;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, 50u, d);
     hipDeviceSynchronize();
     float best = 1e30f;
@@ -88,5 +91,14 @@ int main() {
     R(k_lshl_add_u64, 1); R(k_lshrrev_b64, 1); R(k_fma_f64, 1); R(k_mul_f64, 1);
     R(k_mad_u32_u24, 1); R(k_mul_u32_u24, 1); R(k_mul_hi_u32_u24, 1); R(k_mad_i32_i24, 1); R(k_mad_u32_u16, 1); R(k_dot4_u32_u8, 1); R(k_pk_add_u16, 1);
     R(k_add_nop0, 1); R(k_add_nop1, 1);
+    // dependent multiply-add chains at 1, 2, 3 wavefronts per SIMD (blocks of 256 threads = one wavefront on each of a CU's four SIMDs):
+    // "ns per wave-instruction per SIMD" here is latency-limited; where it meets the saturated figure above, that many waves hide the latency
+    for (int w = 1; w <= 4; ++w) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "madi64 1 chain, %d w/SIMD", w);
+        run(k_madi64_dep, nm, 1, ref, w);
+        snprintf(nm, sizeof nm, "madi64 2 chains, %d w/SIMD", w);
+        run(k_madi64_2dep, nm, 2, ref, w);
+    }
     return 0;
 }
