@@ -146,6 +146,22 @@ __device__ __forceinline__ void fe_store_f29(uint4 *main, uint64_t entry, const 
     main[f29_chunk(entry, 0)] = make_uint4((uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
     main[f29_chunk(entry, 1)] = make_uint4((uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
 }
+// One multiply-add of a column.  SC_MAD_CHAIN (A/B build): the instruction is written out, so that every multiply-add of a product
+// accumulates into ONE register pair in program order -- the compiler otherwise starts each column's chain from zero and joins it to the
+// carry with a 64-bit add (17 v_lshl_add_u64 per product).  A dependent v_mad_i64_i32 issues back to back (tools/instr_bench.hip: one
+// dependent chain on one wavefront per SIMD runs at 87 % of the saturated rate, at two wavefronts at 100 %), so the chain costs nothing.
+#ifdef SC_MAD_CHAIN
+__device__ __forceinline__ void fe_mad(int64_t &acc, const int32_t a, const int32_t b) {
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void fe_mad_k(int64_t &acc, const int32_t a, const int32_t k) { // k: a compile-time constant (an SGPR)
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(k) : "vcc");
+}
+#else
+__device__ __forceinline__ void fe_mad(int64_t &acc, const int32_t a, const int32_t b) { acc += (int64_t)a * (int64_t)b; }
+__device__ __forceinline__ void fe_mad_k(int64_t &acc, const int32_t a, const int32_t k) { acc += (int64_t)a * (int64_t)k; }
+#endif
+
 // a * b / 2^261 (mod p), result value in (a b / 2^261 - p, a b / 2^261], i.e. |.| < 2^257 + p; result limbs 0..7 in [0, 2^29), limb 8 signed and small.
 template <typename B>
 __device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {
@@ -157,12 +173,12 @@ __device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int j = k - i;
-            if (j >= 0 && j < 9) acc += (int64_t)a.l[i] * (int64_t)b.l[j];
+            if (j >= 0 && j < 9) fe_mad(acc, a.l[i], b.l[j]);
         }
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int l = k - j;
-            if (j < k && l >= 1 && l < 9) acc += (int64_t)m[j] * (int64_t)(-fe_p_limb(l));
+            if (j < k && l >= 1 && l < 9) fe_mad_k(acc, m[j], -fe_p_limb(l));
         }
         if (k < 9) {
             m[k] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask); // subtracting m p_0 = m clears the low 29 bits: that IS the shift below
@@ -188,14 +204,14 @@ __device__ __forceinline__ Fe fe_mul2_sum(const Fe &a, const Fe &b, const Fe &c,
         for (int i = 0; i < 9; ++i) {
             const int j = k - i;
             if (j >= 0 && j < 9) {
-                acc += (int64_t)a.l[i] * (int64_t)b.l[j];
-                acc += (int64_t)c.l[i] * (int64_t)d.l[j];
+                fe_mad(acc, a.l[i], b.l[j]);
+                fe_mad(acc, c.l[i], d.l[j]);
             }
         }
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int l = k - j;
-            if (j < k && l >= 1 && l < 9) acc += (int64_t)m[j] * (int64_t)(-fe_p_limb(l));
+            if (j < k && l >= 1 && l < 9) fe_mad_k(acc, m[j], -fe_p_limb(l));
         }
         if (k < 9) {
             m[k] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask);
@@ -247,10 +263,10 @@ __device__ __forceinline__ Fe fe_mul_bind(const Fe &d, const int32_t (&RT)[kBind
                 n2 = q[12 * (k + 1) + 8];
             }
 #pragma unroll
-            for (int i = 0; i < 9; ++i) acc += (int64_t)d.l[i] * (int64_t)c[i];
+            for (int i = 0; i < 9; ++i) fe_mad(acc, d.l[i], c[i]);
         }
-        if (k >= 1 && k < 9) acc += (int64_t)m0 * (int64_t)(-fe_p_limb(k));
-        if (k >= 2) acc += (int64_t)m1 * (int64_t)(-fe_p_limb(k - 1));
+        if (k >= 1 && k < 9) fe_mad_k(acc, m0, -fe_p_limb(k));
+        if (k >= 2) fe_mad_k(acc, m1, -fe_p_limb(k - 1));
         if (k == 0) {
             m0 = (int32_t)((uint32_t)acc & (uint32_t)kFeMask); // subtractive steps, as in fe_mul_t
         } else if (k == 1) {

@@ -824,6 +824,46 @@ __global__ __launch_bounds__(kBlock) void k_f29_to_sat(const uint4 *__restrict__
         fr_store(dst + 2 * i, fe_to_fr(fe_load_f29(src, i, stop[i])));
 }
 
+// The product of one (product, node) combination at pair b: prod_s line_s(node)^exp_s over the combination's slots.
+// A latency-bound round is a chain of dependent memory accesses per slot -- which table (slot_table), where it is (tab), its two entries
+// -- followed by a dependent multiplication; walking the slots one after the other made a late round's sums cost ~3 us PER SLOT
+// (profiles/r3f_tail_clocks.txt: 9.2 us for four multiplicands against 3.3 us for two, with a single pair).  So the slots' entries are
+// fetched four at a time BEFORE anything is multiplied: the loads of a group are in flight together.
+template <typename SlotsT, typename TabFn>
+__device__ __forceinline__ Fr combo_product(const TabFn &tab, const Combo &c, const SlotsT slot_table, const SlotsT slot_exp, const uint64_t b,
+                                            const int32_t nv, const Fr &tf) {
+    Fr prod = fr_zero();
+    bool first = true;
+    for (uint32_t s0 = 0; s0 < c.n_slots; s0 += 4) {
+        const uint32_t ns = c.n_slots - s0 < 4u ? c.n_slots - s0 : 4u;
+        Fr lo[4], hi[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            if (q < ns) {
+                const uint4 *p = tab(slot_table[c.slot_off + s0 + q]) + 4 * b;
+                if (nv != 1) lo[q] = fr_load(p);
+                if (nv != 0) hi[q] = fr_load(p + 2);
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            if (q < ns) {
+                Fr val;
+                if (nv == 0) val = lo[q];
+                else if (nv == 1) val = hi[q];
+                else if (nv == kNodeInf) val = fr_sub(hi[q], lo[q]);
+                else if (nv == -1) val = fr_sub(fr_add(lo[q], lo[q]), hi[q]); // the line at -1 and at 2: two modular adds, no product
+                else if (nv == 2) val = fr_sub(fr_add(hi[q], hi[q]), lo[q]);
+                else val = fr_add(lo[q], fr_mul(fr_sub(hi[q], lo[q]), tf));
+                uint32_t k = 0;
+                if (first) { prod = val; k = 1; first = false; }
+                for (const uint32_t e = slot_exp[c.slot_off + s0 + q]; k < e; ++k) prod = fr_mul(prod, val);
+            }
+        }
+    }
+    return prod;
+}
+
 // one (product, node) combination over the block's pairs; the metadata comes from device memory or from a kernel argument.
 // `tab(u)` gives table u's current evaluations; (vbx, vgx) = this block's index and the block count along the pair axis (the
 // launch's blockIdx.x / gridDim.x, or the virtual ones of the persistent tail kernel).
@@ -835,27 +875,7 @@ __device__ __forceinline__ void sum_combo_body(const TabFn &tab, const Combo c, 
     const Fr tf = node_constant(nv);
     Fr acc = fr_zero();
     const uint64_t stride = (uint64_t)vgx * kBlock;
-    for (uint64_t b = (uint64_t)vbx * kBlock + threadIdx.x; b < n_pairs; b += stride) {
-        Fr prod;
-        bool first = true;
-        for (uint32_t s = 0; s < c.n_slots; ++s) {
-            const uint4 *p = tab(slot_table[c.slot_off + s]) + 4 * b;
-            Fr val;
-            if (nv == 0) val = fr_load(p);
-            else if (nv == 1) val = fr_load(p + 2);
-            else {
-                const Fr lo = fr_load(p), hi = fr_load(p + 2);
-                if (nv == kNodeInf) val = fr_sub(hi, lo);
-                else if (nv == -1) val = fr_sub(fr_add(lo, lo), hi); // the line at -1 and at 2: two modular adds, no product
-                else if (nv == 2) val = fr_sub(fr_add(hi, hi), lo);
-                else val = fr_add(lo, fr_mul(fr_sub(hi, lo), tf));
-            }
-            uint32_t k = 0;
-            if (first) { prod = val; k = 1; first = false; }
-            for (; k < slot_exp[c.slot_off + s]; ++k) prod = fr_mul(prod, val);
-        }
-        acc = fr_add(acc, prod);
-    }
+    for (uint64_t b = (uint64_t)vbx * kBlock + threadIdx.x; b < n_pairs; b += stride) acc = fr_add(acc, combo_product(tab, c, slot_table, slot_exp, b, nv, tf));
     const Fr s = block_sum(acc, sm);
     if (threadIdx.x == 0) fr_store(partials + 2 * (c.partial_off + (uint64_t)t * vgx + vbx), s);
 }
@@ -1386,16 +1406,6 @@ __device__ __forceinline__ uint32_t tail_active_blocks(const uint64_t n_pairs, c
     return (uint32_t)min((uint64_t)G, max(bind_blocks, sum_blocks));
 }
 
-__device__ __forceinline__ Fr combo_term(const uint4 *p, const int32_t nv, const Fr &tf) { // the line through (lo, hi) at node nv
-    if (nv == 0) return fr_load(p);
-    if (nv == 1) return fr_load(p + 2);
-    const Fr lo = fr_load(p), hi = fr_load(p + 2);
-    if (nv == kNodeInf) return fr_sub(hi, lo);
-    if (nv == -1) return fr_sub(fr_add(lo, lo), hi);
-    if (nv == 2) return fr_sub(fr_add(hi, hi), lo);
-    return fr_add(lo, fr_mul(fr_sub(hi, lo), tf));
-}
-
 #ifdef SC_TAIL_CLOCKS // tools/build_variant.sh tail_clocks -DSC_TAIL_CLOCKS: where a tail round's time goes (100 MHz wall clock, block 0)
 __device__ uint64_t g_tail_clk[64 * 8];
 #define TAIL_STAMP(j, i)                                                                                                                  \
@@ -1419,6 +1429,24 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
     int binds = 0; // binds done so far: table u's current evaluations are cur0 (0), b0 (odd), b1 (even > 0)
     auto tab = [&](uint32_t u) -> const uint4 * { return binds == 0 ? A.t.cur0[u] : (binds & 1) ? A.t.b0[u] : A.t.b1[u]; };
     auto prod_of = [&](int k) -> FinProd { return fin.prod[k]; };
+    // The round metadata and the current table pointers live in LDS: as kernel arguments, a per-lane index into them (flat mode: every
+    // lane has its own combination) is a load from memory -- two of them in a row before a slot's entries can even be requested.
+    __shared__ Combo combo_sh[kMetaCombos];
+    __shared__ uint32_t slot_table_sh[kMetaSlots], slot_exp_sh[kMetaSlots];
+    __shared__ const uint4 *tab_sh[kMaxSmallTables];
+    __shared__ int prod_index_sh[kMetaCombos]; // the position (in fin.prod) of each combination's product
+    for (int i = threadIdx.x; i < kMetaCombos; i += kBlock) {
+        combo_sh[i] = meta.combo[i];
+        int k = 0;
+        if (i < A.n_combos)
+            while (k < A.K - 1 && fin.prod[k].partial_off != meta.combo[i].partial_off) ++k;
+        prod_index_sh[i] = k;
+    }
+    for (int i = threadIdx.x; i < kMetaSlots; i += kBlock) {
+        slot_table_sh[i] = meta.slot_table[i];
+        slot_exp_sh[i] = meta.slot_exp[i];
+    }
+    auto tab_lds = [&](uint32_t u) -> const uint4 * { return tab_sh[u]; };
     if (threadIdx.x == 0) stop_sh = 0;
     // (keeping block 0's Lagrange weights in registers for the whole launch was measured: eight more live registers, the first spills
     // of this kernel, no change in the round time -- the weights are L2 hits after the first round)
@@ -1490,6 +1518,8 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                 return;
             }
         }
+        if (threadIdx.x < (uint32_t)A.n_tables) tab_sh[threadIdx.x] = tab(threadIdx.x); // where this round's tables are
+        __syncthreads();
         TAIL_STAMP(j, 1); // bound (and barrier passed)
         if (solo) {
             // ---- flat mode: lane i of the block = (combination i / n_pairs, pair i % n_pairs); the pairs of a combination are
@@ -1499,26 +1529,15 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
             for (uint32_t i0 = 0; i0 < items; i0 += kBlock) { // block-uniform trip count
                 const uint32_t i = i0 + threadIdx.x;
                 const bool live = i < items;
-                const Combo c = meta.combo[live ? (i >> shp) : 0];
+                const uint32_t ci = live ? (i >> shp) : 0;
+                const Combo c = combo_sh[ci];
                 const uint64_t b = i & (uint32_t)(n_pairs - 1);
                 const int32_t nv = node_value((int)c.t);
                 const Fr tf = node_constant(nv);
                 Fr prod = fr_zero();
-                if (live) {
-                    bool first = true;
-                    for (uint32_t sl = 0; sl < c.n_slots; ++sl) {
-                        const Fr val = combo_term(tab(meta.slot_table[c.slot_off + sl]) + 4 * b, nv, tf);
-                        uint32_t k = 0;
-                        if (first) { prod = val; k = 1; first = false; }
-                        for (; k < meta.slot_exp[c.slot_off + sl]; ++k) prod = fr_mul(prod, val);
-                    }
-                }
+                if (live) prod = combo_product(tab_lds, c, slot_table_sh, slot_exp_sh, b, nv, tf);
                 for (uint32_t off = (uint32_t)n_pairs >> 1; off >= 1; off >>= 1) prod = fr_add(prod, fr_shfl_down(prod, (int)off));
-                if (live && b == 0) { // scratch[k * D + t]: the product index k = position of this combination's product
-                    int k = 0;
-                    while (fin.prod[k].partial_off != c.partial_off) ++k;
-                    fr_store(fin_lds + 2 * (k * A.D + (int)c.t), prod);
-                }
+                if (live && b == 0) fr_store(fin_lds + 2 * (prod_index_sh[ci] * A.D + (int)c.t), prod); // scratch[k * D + t]
             }
             __syncthreads();
             TAIL_STAMP(j, 2); // node sums ready
@@ -1529,7 +1548,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
             const uint32_t n_virtual = vgx * (uint32_t)A.n_combos;
             for (uint32_t v = blockIdx.x; v < n_virtual; v += Gj) {
                 const uint32_t cy = v / vgx, vx = v % vgx;
-                sum_combo_body(tab, meta.combo[cy], meta.slot_table, meta.slot_exp, n_pairs, A.partials, sm, vx, vgx);
+                sum_combo_body(tab_lds, combo_sh[cy], slot_table_sh, slot_exp_sh, n_pairs, A.partials, sm, vx, vgx);
             }
             if (!grid_barrier(A.sync, gen, Gj, bar_spins, A.sig + 1, A.sig0 + (uint32_t)j + 1u, stop_sh)) return;
             TAIL_STAMP(j, 2); // partial sums ready (barrier passed)

@@ -21,18 +21,31 @@ from .gkr_round_sumcheck import DenseMultilinearExtension, SparseMultilinearExte
 
 
 def initialize_phase_one_sharded(comm, f1_local: SparseMultilinearExtension, f3: DenseMultilinearExtension, g):
-    """-> (h_g complete on every rank, this rank's part of f1(g,.,.)); `comm`: sharded.NativeComm / HostComm (None = one rank)"""
+    """-> (h_g complete on every rank, this rank's part of f1(g,.,.)); `comm`: sharded.NativeComm / P2PComm / HostComm (None = one rank).
+    Host arrays, or -- all of f1_local and f3 -- torch tensors on the GPU: the library then reads them in place and leaves its outputs in
+    device memory too (SC_TABLES_ON_DEVICE)."""
     dim = f3.num_vars
-    assert f1_local.num_vars == 3 * dim and not f1_local.on_device and not f3.on_device
+    assert f1_local.num_vars == 3 * dim
+    on_dev = bool(f1_local.on_device and f3.on_device)
+    assert on_dev or not (f1_local.on_device or f3.on_device), "f1 and f3 must both be host arrays or both be device tensors"
     g = _np64(g).reshape(-1, 4)
     nnz = f1_local.nnz
+    n1 = C.c_uint64()
+    i_ptr, v_ptr = f1_local._ptrs()
+    h = comm._h if comm is not None else None
+    if on_dev:
+        import torch
+        dev = f3.evaluations.device
+        h_g = torch.empty((1 << dim, 4), dtype=torch.int64, device=dev)
+        oi = torch.empty(max(nnz, 1), dtype=torch.int64, device=dev)
+        ov = torch.empty((max(nnz, 1), 4), dtype=torch.int64, device=dev)
+        check(lib().sc_gkr_phase_one_sharded(h, i_ptr, v_ptr, nnz, dim, _dense_ptr(f3), _ptr(g), SC_TABLES_ON_DEVICE, C.c_void_p(h_g.data_ptr()), None,
+                                             C.c_void_p(oi.data_ptr()), C.c_void_p(ov.data_ptr()), C.byref(n1)))
+        return DenseMultilinearExtension(dim, h_g), SparseMultilinearExtension(2 * dim, oi[: n1.value].contiguous(), ov[: n1.value].contiguous())
     h_g = np.empty((1 << dim, 4), dtype=np.uint64)
     oi = np.empty(max(nnz, 1), dtype=np.uint64)
     ov = np.empty((max(nnz, 1), 4), dtype=np.uint64)
-    n1 = C.c_uint64()
-    i_ptr, v_ptr = f1_local._ptrs()
-    check(lib().sc_gkr_phase_one_sharded(comm._h if comm is not None else None, i_ptr, v_ptr, nnz, dim, _dense_ptr(f3), _ptr(g), 0, _ptr(h_g), None,
-                                         _ptr(oi), _ptr(ov), C.byref(n1)))
+    check(lib().sc_gkr_phase_one_sharded(h, i_ptr, v_ptr, nnz, dim, _dense_ptr(f3), _ptr(g), 0, _ptr(h_g), None, _ptr(oi), _ptr(ov), C.byref(n1)))
     return DenseMultilinearExtension(dim, h_g), SparseMultilinearExtension(2 * dim, oi[: n1.value].copy(), ov[: n1.value].copy())
 
 
@@ -40,9 +53,15 @@ def initialize_phase_two_sharded(comm, f1_g_local: SparseMultilinearExtension, u
     u = _np64(u).reshape(-1, 4)
     dim = u.shape[0]
     assert f1_g_local.num_vars == 2 * dim
-    out = np.empty((1 << dim, 4), dtype=np.uint64)
     i_ptr, v_ptr = f1_g_local._ptrs()
-    check(lib().sc_gkr_phase_two_sharded(comm._h if comm is not None else None, i_ptr, v_ptr, f1_g_local.nnz, dim, _ptr(u), 0, _ptr(out), None))
+    h = comm._h if comm is not None else None
+    if f1_g_local.on_device:
+        import torch
+        out = torch.empty((1 << dim, 4), dtype=torch.int64, device=f1_g_local.values.device)
+        check(lib().sc_gkr_phase_two_sharded(h, i_ptr, v_ptr, f1_g_local.nnz, dim, _ptr(u), SC_TABLES_ON_DEVICE, C.c_void_p(out.data_ptr()), None))
+        return DenseMultilinearExtension(dim, out)
+    out = np.empty((1 << dim, 4), dtype=np.uint64)
+    check(lib().sc_gkr_phase_two_sharded(h, i_ptr, v_ptr, f1_g_local.nnz, dim, _ptr(u), 0, _ptr(out), None))
     return DenseMultilinearExtension(dim, out)
 
 

@@ -167,3 +167,70 @@ print("RETRIED-OK" if ok and ok2 else "MISMATCH")
     assert r.returncode == 0, r.stderr[-2000:]
     assert "RETRIED-OK" in r.stdout, r.stdout + r.stderr[-500:]
     assert "proving again without pipelining" in r.stderr, r.stderr[-1500:]
+
+
+HAMMER_WORKER = r'''
+import ctypes as C, sys, threading, time
+import numpy as np
+import torch
+import sumcheck_amd as sc
+from oracle import cref
+from sumcheck_amd import _lib
+from tests import helpers as H
+nv, shapes, nt = 16, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10
+tabs = [cref.synth_table(8800, s, 1 << nv) for s in range(nt)]
+coefs = cref.synth_table(8800, 1000, len(shapes))
+want, _ = cref.ml_prove(H.desc_from(nv, shapes, tabs, coefs), threads=4)
+poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device="cuda:0")
+hip = C.CDLL("libamdhip64.so")  # the runtime torch (and therefore the library) already mapped
+stop, calls = threading.Event(), [0]
+def hammer():  # foreign HIP traffic on the same device: allocation, a synchronous copy, a (device-synchronising) free, in a tight loop
+    host = (C.c_char * (1 << 20))()
+    while not stop.is_set():
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), 1 << 20) == 0
+        assert hip.hipMemcpy(p, host, 1 << 20, 1) == 0
+        assert hip.hipFree(p) == 0
+        calls[0] += 1
+th = [threading.Thread(target=hammer) for _ in range(2)]
+for t in th: t.start()
+t0 = time.time()
+st = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+n_ok = 0
+for i in range(int(sys.argv[1])):           # device-side waits allowed: a stalled host costs a repeated proof, never a wrong one
+    st.reset()
+    assert np.array_equal(np.asarray(st.prove()).reshape(want.shape), want), i
+    n_ok += 1
+_lib.check(sc.lib().sc_prover_set_polling(st._h, 0))
+for i in range(int(sys.argv[2])):           # the foreign-host setting: no kernel ever waits for the host
+    st.reset()
+    assert np.array_equal(np.asarray(st.prove()).reshape(want.shape), want), i
+    n_ok += 1
+chal = cref.synth_table(8801, 1, nv)
+op = cref.Prover(H.desc_from(nv, shapes, tabs, coefs), threads=4)
+st.reset()
+_lib.check(sc.lib().sc_prover_set_polling(st._h, 1))
+v = None
+for i in range(nv):                         # the interactive protocol (resident kernel, short patience) under the same traffic
+    got = sc.IPForMLSumcheck.prove_round(st, v).evaluations
+    assert np.array_equal(got, op.prove_round(None if v is None else v.randomness)), i
+    v = sc.VerifierMsg(chal[i])
+stop.set()
+for t in th: t.join()
+print("HAMMER-OK", n_ok, "proofs,", calls[0], "foreign malloc/copy/free cycles,", round(time.time() - t0, 1), "s")
+'''
+
+
+def test_foreign_hip_traffic_never_voids_or_corrupts_a_proof():
+    """sumcheck_hip.h's interference contract: two threads of the process hammer hipMalloc / hipMemcpy / hipFree on the prover's
+    device while it proves 200 times with device-side waits enabled (a borrowing handle: an expired wait is answered by proving
+    again inside the call), 50 times with sc_prover_set_polling(p, 0) (nothing ever waits for the host), and once interactively
+    (resident kernel).  Slower is fine; void or wrong is not.  The wait bound is shortened (SC_WAIT_SPINS) so that a stall costs
+    milliseconds, not seconds, of test time."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if not k.startswith("SC_")}
+    e["SC_WAIT_SPINS"] = "20000"
+    r = subprocess.run([sys.executable, "-c", HAMMER_WORKER, "200", "50"], capture_output=True, text=True, timeout=900, cwd=root, env=e)
+    assert r.returncode == 0 and "HAMMER-OK 250 proofs" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
