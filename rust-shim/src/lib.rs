@@ -210,6 +210,15 @@ impl<F: Limbs4> HipProverState<F> {
         check(unsafe { sc_prover_state(self.handle, core::ptr::null_mut(), core::ptr::null_mut(), core::ptr::null_mut(), &mut r) });
         r as usize
     }
+    /// A host that runs HIP work of its own on the device: `false` = no kernel of this handle ever waits for the host (every round is
+    /// launched after its challenge is known); see the interference contract in `sumcheck_hip.h`.
+    pub fn set_polling(&mut self, allow: bool) {
+        check(unsafe { sc_prover_set_polling(self.handle, allow as c_int) });
+    }
+    /// Patience (in ~2 us polls; 0 = off) of the kernel that serves the late rounds of `prove_round` called round by round.
+    pub fn set_resident(&mut self, patience_polls: u32) {
+        check(unsafe { sc_prover_set_resident(self.handle, patience_polls) });
+    }
     /// the reference's `ProverState`: randomness, product list, the (partially bound) tables, round
     pub fn to_prover_state(&self) -> ProverState<F> {
         let round = self.round();
@@ -309,6 +318,10 @@ pub fn prove<F: Limbs4>(polynomial: &ListOfProductsOfPolynomials<F>) -> Proof<F>
 /// 16 GiB of bound-table buffers), the work areas of `evaluate` / `fix_variables`, the GKR scratch.  This gives all of it back.
 pub fn release_caches() {
     check(unsafe { sc_release_caches() });
+}
+/// Upper bound (bytes of device memory) of what each of those caches may keep between calls; 0 = nothing is kept.
+pub fn set_cache_limit(bytes: u64) {
+    check(unsafe { sc_set_cache_limit(bytes) });
 }
 
 /// `ListOfProductsOfPolynomials::evaluate` (reference `src/ml_sumcheck/data_structures.rs:99-109`): the oracle query that

@@ -1067,6 +1067,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         SlowCallProbe pr_sum("launch k_sum_combos");
         if (p->has_meta) HIP_TRY(scd::launch_sum_combos_meta(tp, p->meta, p->n_combos, n_pairs, p->d_partials, grid, p->stream));
         else HIP_TRY(scd::launch_sum_combos(tp, p->d_combos, p->n_combos, p->d_slot_table, p->d_slot_exp, n_pairs, p->d_partials, grid, p->stream));
+        scaled = 1; // products of up to kMaxFusedM multiplicands are summed in carry-free arithmetic (2^261 radix) there too
         bind = false;
     }
     if (bind && p->any_generic) { // generic products read bound tables: bind everything up front

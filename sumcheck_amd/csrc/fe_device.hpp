@@ -73,6 +73,22 @@ __device__ __forceinline__ FeU feu_from_host(const FrHost &h) {
     return u;
 }
 
+// 32 * a as nine 29-bit limbs, a < 2^256 given as 8 x u32 (uniform): the challenge as the carry-free bind takes it (fe_mul divides by
+// 2^261, the tables hold the R = 2^256 form, so r * 2^5 makes r * (hi - lo) land in R-form).  The value 32 a < 2^261 is NOT reduced
+// mod p: as a multiplier it only has to have limbs below 2^29.
+__device__ __forceinline__ FeU feu_shl5(const uint32_t (&v)[8]) {
+    FeU u;
+    u.l[0] = (int32_t)((v[0] << 5) & (uint32_t)kFeMask);
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const int s = 29 * i - 5, w = s >> 5, off = s & 31; // bits [s, s + 29) of a
+        uint32_t x = v[w] >> off;
+        if (off > 3 && w + 1 < 8) x |= v[w + 1] << (32 - off);
+        u.l[i] = (int32_t)(x & (uint32_t)kFeMask);
+    }
+    return u;
+}
+
 __device__ __forceinline__ Fe fe_zero() {
     Fe r;
 #pragma unroll
@@ -146,24 +162,32 @@ __device__ __forceinline__ void fe_store_f29(uint4 *main, uint64_t entry, const 
     main[f29_chunk(entry, 0)] = make_uint4((uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
     main[f29_chunk(entry, 1)] = make_uint4((uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
 }
-// One multiply-add of a column.  SC_MAD_CHAIN (A/B build): the instruction is written out, so that every multiply-add of a product
-// accumulates into ONE register pair in program order -- the compiler otherwise starts each column's chain from zero and joins it to the
-// carry with a 64-bit add (17 v_lshl_add_u64 per product).  A dependent v_mad_i64_i32 issues back to back (tools/instr_bench.hip: one
-// dependent chain on one wavefront per SIMD runs at 87 % of the saturated rate, at two wavefronts at 100 %), so the chain costs nothing.
-#ifdef SC_MAD_CHAIN
+// One multiply-add of a column.  kChain: the instruction is written out, so that every multiply-add of a product accumulates into ONE
+// register pair in program order -- the compiler otherwise starts each column's chain from zero and joins it to the carry with a 64-bit
+// add (17 v_lshl_add_u64 per product).  A dependent v_mad_i64_i32 issues back to back (tools/instr_bench.hip: one dependent chain on
+// one wavefront per SIMD runs at 87 % of the saturated rate, at two wavefronts at 100 %), so the chain itself costs nothing, and it needs
+// fewer registers (round 1: 158 instead of 168 + 28 bytes of scratch).  Measured per round (profiles/r3g_ab.txt): the kernels that read
+// canonical tables gain (round 1 -5.6 %, round 2 -2.9 %); the rounds that stream the internal format lose 2-6 % (their few instructions
+// per byte leave the memory pipe in charge, and the independent column chains give the scheduler more to overlap with it) -- so the chain
+// is a template parameter: on for round 1 and for the first binding round, off elsewhere.
+template <bool kChain>
 __device__ __forceinline__ void fe_mad(int64_t &acc, const int32_t a, const int32_t b) {
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+    if constexpr (kChain) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+    else acc += (int64_t)a * (int64_t)b;
 }
+template <bool kChain>
 __device__ __forceinline__ void fe_mad_k(int64_t &acc, const int32_t a, const int32_t k) { // k: a compile-time constant (an SGPR)
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(k) : "vcc");
+    if constexpr (kChain) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(k) : "vcc");
+    else acc += (int64_t)a * (int64_t)k;
 }
+#ifdef SC_MAD_CHAIN // A/B build: the written-out chain everywhere
+constexpr bool kChainDefault = true;
 #else
-__device__ __forceinline__ void fe_mad(int64_t &acc, const int32_t a, const int32_t b) { acc += (int64_t)a * (int64_t)b; }
-__device__ __forceinline__ void fe_mad_k(int64_t &acc, const int32_t a, const int32_t k) { acc += (int64_t)a * (int64_t)k; }
+constexpr bool kChainDefault = false;
 #endif
 
 // a * b / 2^261 (mod p), result value in (a b / 2^261 - p, a b / 2^261], i.e. |.| < 2^257 + p; result limbs 0..7 in [0, 2^29), limb 8 signed and small.
-template <typename B>
+template <typename B, bool kChain = kChainDefault>
 __device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {
     int64_t acc = 0;
     int32_t m[9];
@@ -173,12 +197,12 @@ __device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int j = k - i;
-            if (j >= 0 && j < 9) fe_mad(acc, a.l[i], b.l[j]);
+            if (j >= 0 && j < 9) fe_mad<kChain>(acc, a.l[i], b.l[j]);
         }
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int l = k - j;
-            if (j < k && l >= 1 && l < 9) fe_mad_k(acc, m[j], -fe_p_limb(l));
+            if (j < k && l >= 1 && l < 9) fe_mad_k<kChain>(acc, m[j], -fe_p_limb(l));
         }
         if (k < 9) {
             m[k] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask); // subtracting m p_0 = m clears the low 29 bits: that IS the shift below
@@ -190,10 +214,12 @@ __device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {
     r.l[8] = (int32_t)acc;
     return r;
 }
-__device__ __forceinline__ Fe fe_mul(const Fe &a, const Fe &b) { return fe_mul_t<Fe>(a, b); }
+template <bool kChain = kChainDefault>
+__device__ __forceinline__ Fe fe_mul(const Fe &a, const Fe &b) { return fe_mul_t<Fe, kChain>(a, b); }
 // (a * b + c * d) / 2^261 (mod p) with ONE Montgomery reduction: 162 + 72 multiply-adds instead of 2 x 153.  For sums that are only
 // accumulated (the final products of two pairs of the same evaluation node).  Bounds: all four operands |limb| <= 2^29 + 4, so a
 // column is within 18 * 2^58.01 + 8 * 2^58 + carry < 2^63 in magnitude.
+template <bool kChain = kChainDefault>
 __device__ __forceinline__ Fe fe_mul2_sum(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
     int64_t acc = 0;
     int32_t m[9];
@@ -204,14 +230,14 @@ __device__ __forceinline__ Fe fe_mul2_sum(const Fe &a, const Fe &b, const Fe &c,
         for (int i = 0; i < 9; ++i) {
             const int j = k - i;
             if (j >= 0 && j < 9) {
-                fe_mad(acc, a.l[i], b.l[j]);
-                fe_mad(acc, c.l[i], d.l[j]);
+                fe_mad<kChain>(acc, a.l[i], b.l[j]);
+                fe_mad<kChain>(acc, c.l[i], d.l[j]);
             }
         }
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int l = k - j;
-            if (j < k && l >= 1 && l < 9) fe_mad_k(acc, m[j], -fe_p_limb(l));
+            if (j < k && l >= 1 && l < 9) fe_mad_k<kChain>(acc, m[j], -fe_p_limb(l));
         }
         if (k < 9) {
             m[k] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask);
@@ -223,7 +249,8 @@ __device__ __forceinline__ Fe fe_mul2_sum(const Fe &a, const Fe &b, const Fe &c,
     r.l[8] = (int32_t)acc;
     return r;
 }
-__device__ __forceinline__ Fe fe_mul_u(const Fe &a, const FeU &u) { return fe_mul_t<FeU>(a, u); }
+template <bool kChain = kChainDefault>
+__device__ __forceinline__ Fe fe_mul_u(const Fe &a, const FeU &u) { return fe_mul_t<FeU, kChain>(a, u); }
 
 // d * r (mod p) for the round's fixed challenge r, d the lazy difference of two table entries (|limbs| < 2^29 + 16).
 // C.R[i] = (r * 2^(29 i + 58)) mod p, so S = sum_i d_i * R_i is congruent to d * r * 2^58 and already NINE columns wide: no high
@@ -241,6 +268,7 @@ __device__ __forceinline__ void bind_consts_to_lds(const BindConst &C, int32_t (
     }
     __syncthreads();
 }
+template <bool kChain = kChainDefault>
 __device__ __forceinline__ Fe fe_mul_bind(const Fe &d, const int32_t (&RT)[kBindLds]) {
     uint32_t off = 0;
     asm volatile("" : "+v"(off)); // keep the constant loads inside the pair loop (hoisted, they would pin 81 VGPRs)
@@ -263,10 +291,10 @@ __device__ __forceinline__ Fe fe_mul_bind(const Fe &d, const int32_t (&RT)[kBind
                 n2 = q[12 * (k + 1) + 8];
             }
 #pragma unroll
-            for (int i = 0; i < 9; ++i) fe_mad(acc, d.l[i], c[i]);
+            for (int i = 0; i < 9; ++i) fe_mad<kChain>(acc, d.l[i], c[i]);
         }
-        if (k >= 1 && k < 9) fe_mad_k(acc, m0, -fe_p_limb(k));
-        if (k >= 2) fe_mad_k(acc, m1, -fe_p_limb(k - 1));
+        if (k >= 1 && k < 9) fe_mad_k<kChain>(acc, m0, -fe_p_limb(k));
+        if (k >= 2) fe_mad_k<kChain>(acc, m1, -fe_p_limb(k - 1));
         if (k == 0) {
             m0 = (int32_t)((uint32_t)acc & (uint32_t)kFeMask); // subtractive steps, as in fe_mul_t
         } else if (k == 1) {

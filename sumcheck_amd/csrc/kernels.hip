@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
 // ------------------------------------------------------------------------------------------------
 // factor F of the product at pair b: its line's two end points (lo, hi), binding / storing as the slot's mode says
 // kR1: round 1 of a proof -- every factor is read from the caller's canonical table, nothing is bound (k_round1_tree)
-template <int F, bool kR1 = false>
+template <int F, bool kR1 = false, bool kChain = kChainDefault>
 struct LoadFactor {
     static __device__ __forceinline__ void run(const Slot *S, const uint64_t b, const int32_t (&r)[kBindLds], Fe &lo_out, Fe &hi_out) {
         const Slot &sl = S[F];
@@ -290,9 +290,9 @@ struct LoadFactor {
             } else {
                 e0 = fe_from_fr(fr_load(p)); e1 = fe_from_fr(fr_load(p + 2)); e2 = fe_from_fr(fr_load(p + 4)); e3 = fe_from_fr(fr_load(p + 6));
             }
-            const Fe l0 = fe_add(e0, fe_mul_bind(fe_sub(e1, e0), r));
+            const Fe l0 = fe_add(e0, fe_mul_bind<kChain>(fe_sub(e1, e0), r));
             asm volatile("" : "+v"(e3.l[8]) : "v"(l0.l[8])); // one product at a time: interleaving the two doubles the live constants
-            const Fe h0 = fe_add(e2, fe_mul_bind(fe_sub(e3, e2), r));
+            const Fe h0 = fe_add(e2, fe_mul_bind<kChain>(fe_sub(e3, e2), r));
             if (sl.dst_top || (mode == 3 && stop)) {
                 // internal F29 tables: ONE parallel carry pass, no modular reduction.  The value moves by < p + 2^231 per bind
                 // (fe_mul_bind: r*(e1-e0) comes back in (-p - 2^230, 2^230)), i.e. stays within (rounds+1) p < 2^261 in magnitude for any
@@ -320,7 +320,7 @@ struct LoadFactor {
 };
 
 // one product's pass of a block over its share of the pairs: row = this block's M+1 partial sums of that product
-template <int M, bool kR1 = false>
+template <int M, bool kR1 = false, bool kChain = kChainDefault>
 __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBindLds], const uint64_t n_pairs, uint4 *__restrict__ row, uint32_t (*sm)[8],
                                           int32_t *lacc) {
     // The M+1 running sums live in LDS (limb-planar, one column per thread: lacc[(9 t + limb) * kBlock + tid], conflict-free and
@@ -359,46 +359,46 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
                 Fe a0, a1, ai, b0, b1, bi, c0, c1, ci, d0, d1, di; // a, b: pair b's two quadratics; c, d: pair b2's
                 {
                     Fe l0, h0, l1, h1;
-                    LoadFactor<0, kR1>::run(S, b, r, l0, h0);
-                    LoadFactor<1, kR1>::run(S, b, r, l1, h1);
-                    a0 = fe_mul(l0, l1);
-                    a1 = fe_mul(h0, h1);
-                    ai = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
+                    LoadFactor<0, kR1, kChain>::run(S, b, r, l0, h0);
+                    LoadFactor<1, kR1, kChain>::run(S, b, r, l1, h1);
+                    a0 = fe_mul<kChain>(l0, l1);
+                    a1 = fe_mul<kChain>(h0, h1);
+                    ai = fe_mul<kChain>(fe_sub(h0, l0), fe_sub(h1, l1));
                 }
                 fe_pin3(a0, a1, ai);
                 {
                     Fe l2, h2, l3, h3;
-                    LoadFactor<2, kR1>::run(S, b, r, l2, h2);
-                    LoadFactor<3, kR1>::run(S, b, r, l3, h3);
-                    b0 = fe_mul(l2, l3);
-                    b1 = fe_mul(h2, h3);
-                    bi = fe_mul(fe_sub(h2, l2), fe_sub(h3, l3));
+                    LoadFactor<2, kR1, kChain>::run(S, b, r, l2, h2);
+                    LoadFactor<3, kR1, kChain>::run(S, b, r, l3, h3);
+                    b0 = fe_mul<kChain>(l2, l3);
+                    b1 = fe_mul<kChain>(h2, h3);
+                    bi = fe_mul<kChain>(fe_sub(h2, l2), fe_sub(h3, l3));
                 }
                 fe_pin3(b0, b1, bi);
                 {
                     Fe l0, h0, l1, h1;
-                    LoadFactor<0, kR1>::run(S, b2, r, l0, h0);
-                    LoadFactor<1, kR1>::run(S, b2, r, l1, h1);
-                    c0 = fe_mul(l0, l1);
-                    c1 = fe_mul(h0, h1);
-                    ci = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
+                    LoadFactor<0, kR1, kChain>::run(S, b2, r, l0, h0);
+                    LoadFactor<1, kR1, kChain>::run(S, b2, r, l1, h1);
+                    c0 = fe_mul<kChain>(l0, l1);
+                    c1 = fe_mul<kChain>(h0, h1);
+                    ci = fe_mul<kChain>(fe_sub(h0, l0), fe_sub(h1, l1));
                 }
                 fe_pin3(c0, c1, ci);
                 {
                     Fe l2, h2, l3, h3;
-                    LoadFactor<2, kR1>::run(S, b2, r, l2, h2);
-                    LoadFactor<3, kR1>::run(S, b2, r, l3, h3);
-                    d0 = fe_mul(l2, l3);
-                    d1 = fe_mul(h2, h3);
-                    di = fe_mul(fe_sub(h2, l2), fe_sub(h3, l3));
+                    LoadFactor<2, kR1, kChain>::run(S, b2, r, l2, h2);
+                    LoadFactor<3, kR1, kChain>::run(S, b2, r, l3, h3);
+                    d0 = fe_mul<kChain>(l2, l3);
+                    d1 = fe_mul<kChain>(h2, h3);
+                    di = fe_mul<kChain>(fe_sub(h2, l2), fe_sub(h3, l3));
                 }
                 // Every node's product goes into its running sum as soon as it exists (nothing waits in registers), and BEFORE nodes -1
                 // and 2 each quadratic's three coefficients are replaced by its two extension values -- q(-1) = 2 q(0) + 2 q(inf) - q(1),
                 // q(2) = 2 q(1) + 2 q(inf) - q(0), re-tightened for the shared reduction -- so that those products see eight live
                 // elements instead of twelve coefficients plus four temporaries (the 136 bytes of scratch per lane this path used to need).
-                accumulate(0, fe_mul2_sum(a0, b0, c0, d0));
-                accumulate(1, fe_mul2_sum(a1, b1, c1, d1));
-                accumulate(2, fe_mul2_sum(ai, bi, ci, di));
+                accumulate(0, fe_mul2_sum<kChain>(a0, b0, c0, d0));
+                accumulate(1, fe_mul2_sum<kChain>(a1, b1, c1, d1));
+                accumulate(2, fe_mul2_sum<kChain>(ai, bi, ci, di));
                 auto extend = [](Fe &q0, Fe &q1, const Fe &qi) { // (q0, q1) <- (q(-1), q(2))
                     const Fe t = fe_add(qi, qi);
                     const Fe m1 = fe_carry_pass(fe_sub(fe_add(t, fe_add(q0, q0)), q1));
@@ -412,48 +412,48 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
                 extend(d0, d1, di);
                 fe_pin3(a0, b0, c0);
                 fe_pin3(a1, b1, c1);
-                accumulate(3, fe_mul2_sum(a0, b0, c0, d0));
-                accumulate(4, fe_mul2_sum(a1, b1, c1, d1));
+                accumulate(3, fe_mul2_sum<kChain>(a0, b0, c0, d0));
+                accumulate(4, fe_mul2_sum<kChain>(a1, b1, c1, d1));
                 continue;
             } else if constexpr (M == 2) {
                 Fe l0, h0, l1, h1, m0, k0, m1, k1;
-                LoadFactor<0, kR1>::run(S, b, r, l0, h0);
-                LoadFactor<1, kR1>::run(S, b, r, l1, h1);
-                LoadFactor<0, kR1>::run(S, b2, r, m0, k0);
-                LoadFactor<1, kR1>::run(S, b2, r, m1, k1);
-                P[0] = fe_mul2_sum(l0, l1, m0, m1);
-                P[1] = fe_mul2_sum(h0, h1, k0, k1);
-                P[2] = fe_mul2_sum(fe_sub(h0, l0), fe_sub(h1, l1), fe_sub(k0, m0), fe_sub(k1, m1));
+                LoadFactor<0, kR1, kChain>::run(S, b, r, l0, h0);
+                LoadFactor<1, kR1, kChain>::run(S, b, r, l1, h1);
+                LoadFactor<0, kR1, kChain>::run(S, b2, r, m0, k0);
+                LoadFactor<1, kR1, kChain>::run(S, b2, r, m1, k1);
+                P[0] = fe_mul2_sum<kChain>(l0, l1, m0, m1);
+                P[1] = fe_mul2_sum<kChain>(h0, h1, k0, k1);
+                P[2] = fe_mul2_sum<kChain>(fe_sub(h0, l0), fe_sub(h1, l1), fe_sub(k0, m0), fe_sub(k1, m1));
             } else {
                 Fe q0, q1, qi, l2, h2;
                 {
                     Fe l0, h0, l1, h1;
-                    LoadFactor<0, kR1>::run(S, b, r, l0, h0);
-                    LoadFactor<1, kR1>::run(S, b, r, l1, h1);
-                    q0 = fe_mul(l0, l1);
-                    q1 = fe_mul(h0, h1);
-                    qi = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
+                    LoadFactor<0, kR1, kChain>::run(S, b, r, l0, h0);
+                    LoadFactor<1, kR1, kChain>::run(S, b, r, l1, h1);
+                    q0 = fe_mul<kChain>(l0, l1);
+                    q1 = fe_mul<kChain>(h0, h1);
+                    qi = fe_mul<kChain>(fe_sub(h0, l0), fe_sub(h1, l1));
                 }
                 fe_pin3(q0, q1, qi);
-                LoadFactor<2, kR1>::run(S, b, r, l2, h2);
+                LoadFactor<2, kR1, kChain>::run(S, b, r, l2, h2);
                 Fe s0, s1, si, m2, k2;
                 {
                     Fe l0, h0, l1, h1;
-                    LoadFactor<0, kR1>::run(S, b2, r, l0, h0);
-                    LoadFactor<1, kR1>::run(S, b2, r, l1, h1);
-                    s0 = fe_mul(l0, l1);
-                    s1 = fe_mul(h0, h1);
-                    si = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
+                    LoadFactor<0, kR1, kChain>::run(S, b2, r, l0, h0);
+                    LoadFactor<1, kR1, kChain>::run(S, b2, r, l1, h1);
+                    s0 = fe_mul<kChain>(l0, l1);
+                    s1 = fe_mul<kChain>(h0, h1);
+                    si = fe_mul<kChain>(fe_sub(h0, l0), fe_sub(h1, l1));
                 }
                 fe_pin3(s0, s1, si);
-                LoadFactor<2, kR1>::run(S, b2, r, m2, k2);
-                P[0] = fe_mul2_sum(l2, q0, m2, s0);
-                P[1] = fe_mul2_sum(h2, q1, k2, s1);
-                P[2] = fe_mul2_sum(fe_sub(h2, l2), qi, fe_sub(k2, m2), si);
+                LoadFactor<2, kR1, kChain>::run(S, b2, r, m2, k2);
+                P[0] = fe_mul2_sum<kChain>(l2, q0, m2, s0);
+                P[1] = fe_mul2_sum<kChain>(h2, q1, k2, s1);
+                P[2] = fe_mul2_sum<kChain>(fe_sub(h2, l2), qi, fe_sub(k2, m2), si);
                 // node -1: f2(-1) = 2 lo - hi (re-tightened: the shared reduction needs both operands within 2^29), q(-1) = 2 q(0) + 2 q(inf) - q(1)
                 const Fe qm1 = fe_carry_pass(fe_sub(fe_add(fe_add(qi, qi), fe_add(q0, q0)), q1));
                 const Fe sm1 = fe_carry_pass(fe_sub(fe_add(fe_add(si, si), fe_add(s0, s0)), s1));
-                P[3] = fe_mul2_sum(fe_carry_pass(fe_sub(fe_add(l2, l2), h2)), qm1, fe_carry_pass(fe_sub(fe_add(m2, m2), k2)), sm1);
+                P[3] = fe_mul2_sum<kChain>(fe_carry_pass(fe_sub(fe_add(l2, l2), h2)), qm1, fe_carry_pass(fe_sub(fe_add(m2, m2), k2)), sm1);
             }
 #pragma unroll
             for (int t = 0; t <= M; ++t) {
@@ -473,59 +473,59 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
         // half-products: a0/a1/ai of factors 0,1 are formed before factors 2,3 are touched.
         Fe P[M + 1];
         if constexpr (M == 1) {
-            LoadFactor<0, kR1>::run(S, b, r, P[0], P[1]);
+            LoadFactor<0, kR1, kChain>::run(S, b, r, P[0], P[1]);
         } else if constexpr (M == 2) {
             Fe l0, h0, l1, h1;
-            LoadFactor<0, kR1>::run(S, b, r, l0, h0);
-            LoadFactor<1, kR1>::run(S, b, r, l1, h1);
-            P[0] = fe_mul(l0, l1);
-            P[1] = fe_mul(h0, h1);
-            P[2] = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
+            LoadFactor<0, kR1, kChain>::run(S, b, r, l0, h0);
+            LoadFactor<1, kR1, kChain>::run(S, b, r, l1, h1);
+            P[0] = fe_mul<kChain>(l0, l1);
+            P[1] = fe_mul<kChain>(h0, h1);
+            P[2] = fe_mul<kChain>(fe_sub(h0, l0), fe_sub(h1, l1));
         } else if constexpr (M == 3) {
             Fe q0, q1, qi;
             {
                 Fe l0, h0, l1, h1;
-                LoadFactor<0, kR1>::run(S, b, r, l0, h0);
-                LoadFactor<1, kR1>::run(S, b, r, l1, h1);
-                q0 = fe_mul(l0, l1);
-                q1 = fe_mul(h0, h1);
-                qi = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
+                LoadFactor<0, kR1, kChain>::run(S, b, r, l0, h0);
+                LoadFactor<1, kR1, kChain>::run(S, b, r, l1, h1);
+                q0 = fe_mul<kChain>(l0, l1);
+                q1 = fe_mul<kChain>(h0, h1);
+                qi = fe_mul<kChain>(fe_sub(h0, l0), fe_sub(h1, l1));
             }
             fe_pin3(q0, q1, qi);
             const Fe qm1 = fe_carry_pass(fe_sub(fe_add(fe_add(qi, qi), fe_add(q0, q0)), q1)); // q(-1) = 2 q(0) + 2 q(inf) - q(1)
             Fe l2, h2;
-            LoadFactor<2, kR1>::run(S, b, r, l2, h2);
-            P[0] = fe_mul(l2, q0);
-            P[1] = fe_mul(h2, q1);
-            P[2] = fe_mul(fe_sub(h2, l2), qi);
-            P[3] = fe_mul(fe_sub(fe_add(l2, l2), h2), qm1); // f2(-1) = 2 lo - hi
+            LoadFactor<2, kR1, kChain>::run(S, b, r, l2, h2);
+            P[0] = fe_mul<kChain>(l2, q0);
+            P[1] = fe_mul<kChain>(h2, q1);
+            P[2] = fe_mul<kChain>(fe_sub(h2, l2), qi);
+            P[3] = fe_mul<kChain>(fe_sub(fe_add(l2, l2), h2), qm1); // f2(-1) = 2 lo - hi
         } else {
             static_assert(M == 4, "the tree kernels take products of at most four multiplicands");
             Fe a0, a1, ai, b0, b1, bi;
             {
                 Fe l0, h0, l1, h1;
-                LoadFactor<0, kR1>::run(S, b, r, l0, h0);
-                LoadFactor<1, kR1>::run(S, b, r, l1, h1);
-                a0 = fe_mul(l0, l1);
-                a1 = fe_mul(h0, h1);
-                ai = fe_mul(fe_sub(h0, l0), fe_sub(h1, l1));
+                LoadFactor<0, kR1, kChain>::run(S, b, r, l0, h0);
+                LoadFactor<1, kR1, kChain>::run(S, b, r, l1, h1);
+                a0 = fe_mul<kChain>(l0, l1);
+                a1 = fe_mul<kChain>(h0, h1);
+                ai = fe_mul<kChain>(fe_sub(h0, l0), fe_sub(h1, l1));
             }
             fe_pin3(a0, a1, ai);
             {
                 Fe l2, h2, l3, h3;
-                LoadFactor<2, kR1>::run(S, b, r, l2, h2);
-                LoadFactor<3, kR1>::run(S, b, r, l3, h3);
-                b0 = fe_mul(l2, l3);
-                b1 = fe_mul(h2, h3);
-                bi = fe_mul(fe_sub(h2, l2), fe_sub(h3, l3));
+                LoadFactor<2, kR1, kChain>::run(S, b, r, l2, h2);
+                LoadFactor<3, kR1, kChain>::run(S, b, r, l3, h3);
+                b0 = fe_mul<kChain>(l2, l3);
+                b1 = fe_mul<kChain>(h2, h3);
+                bi = fe_mul<kChain>(fe_sub(h2, l2), fe_sub(h3, l3));
             }
             // a quadratic from its values at 0, 1 and its leading coefficient: q(-1) = 2 q(0) + 2 q(inf) - q(1), q(2) = 2 q(1) + 2 q(inf) - q(0)
             const Fe a2i = fe_add(ai, ai), b2i = fe_add(bi, bi);
-            P[0] = fe_mul(a0, b0);
-            P[1] = fe_mul(a1, b1);
-            P[2] = fe_mul(ai, bi);
-            P[3] = fe_mul(fe_carry_pass(fe_sub(fe_add(a2i, fe_add(a0, a0)), a1)), fe_carry_pass(fe_sub(fe_add(b2i, fe_add(b0, b0)), b1)));
-            P[4] = fe_mul(fe_carry_pass(fe_sub(fe_add(a2i, fe_add(a1, a1)), a0)), fe_carry_pass(fe_sub(fe_add(b2i, fe_add(b1, b1)), b0)));
+            P[0] = fe_mul<kChain>(a0, b0);
+            P[1] = fe_mul<kChain>(a1, b1);
+            P[2] = fe_mul<kChain>(ai, bi);
+            P[3] = fe_mul<kChain>(fe_carry_pass(fe_sub(fe_add(a2i, fe_add(a0, a0)), a1)), fe_carry_pass(fe_sub(fe_add(b2i, fe_add(b0, b0)), b1)));
+            P[4] = fe_mul<kChain>(fe_carry_pass(fe_sub(fe_add(a2i, fe_add(a1, a1)), a0)), fe_carry_pass(fe_sub(fe_add(b2i, fe_add(b1, b1)), b0)));
         }
 #pragma unroll
         for (int t = 0; t <= M; ++t) {
@@ -798,22 +798,23 @@ hipError_t launch_wait_challenge(uint32_t *flag_dev, uint32_t want, const FrHost
 // the device-memory mailbox that k_wait_challenge, the kernel in front of this one, filled
 __global__ __launch_bounds__(kBlock) void k_fix_multi(const TablePtrs tp, const FrHost r_h, const FrHost *__restrict__ r_mail, const uint64_t n_out) {
     const FrU r = fru_from_host(r_mail ? *r_mail : r_h); // uniform: scalar loads either way
+    const FeU r32 = feu_shl5(r.v);                       // carry-free bind: one chain of multiply-adds, no carry instruction (fe_device.hpp)
     const uint4 *__restrict__ src = tp.src[blockIdx.y];
     uint4 *__restrict__ dst = tp.dst[blockIdx.y];
     const int32_t *__restrict__ stop = tp.src_top[blockIdx.y];
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_out; b += stride) {
         const uint4 *p = src + 4 * b;
-        Fr lo, hi;
-        if (stop) { // first latency-bound round after the big rounds: the table arrives in F29, leaves canonical
+        Fe lo, hi;
+        if (stop) { // first latency-bound round after the big rounds: the table arrives in F29 (used as it is), leaves canonical
             const int2 t = *reinterpret_cast<const int2 *>(stop + 2 * b);
-            lo = fe_to_fr(fe_load_f29(src, 2 * b, t.x));
-            hi = fe_to_fr(fe_load_f29(src, 2 * b + 1, t.y));
+            lo = fe_load_f29(src, 2 * b, t.x);
+            hi = fe_load_f29(src, 2 * b + 1, t.y);
         } else {
-            lo = fr_load(p);
-            hi = fr_load(p + 2);
+            lo = fe_from_fr(fr_load(p));
+            hi = fe_from_fr(fr_load(p + 2));
         }
-        fr_store(dst + 2 * b, fr_add(lo, fr_mul_u(fr_sub(hi, lo), r)));
+        fr_store(dst + 2 * b, fe_to_fr(fe_add(lo, fe_mul_u<true>(fe_sub(hi, lo), r32))));
     }
 }
 
@@ -864,6 +865,58 @@ __device__ __forceinline__ Fr combo_product(const TabFn &tab, const Combo &c, co
     return prod;
 }
 
+// the line through (lo, hi) at node nv (0, 1, inf, -1, 2, -2, 3, ...), limbs re-tightened to [-4, 2^29 + 4): fits either operand of fe_mul
+__device__ __forceinline__ Fe fe_line(const Fe &lo, const Fe &hi, const int32_t nv) {
+    if (nv == 0) return lo;
+    if (nv == 1) return hi;
+    const Fe step = fe_sub(hi, lo); // limbs in (-2^29, 2^29)
+    if (nv == kNodeInf) return step;
+    Fe cur;
+    if (nv < 0) {
+        cur = fe_sub(lo, step); // -1: 2 lo - hi, within 2^30
+        for (int32_t k = -1; k > nv; --k) cur = fe_sub(fe_carry_pass(cur), step);
+    } else {
+        cur = fe_add(hi, step); // 2: 2 hi - lo
+        for (int32_t k = 2; k < nv; ++k) cur = fe_add(fe_carry_pass(cur), step);
+    }
+    return fe_carry_pass(cur);
+}
+// combo_product in CARRY-FREE arithmetic (fe_device.hpp), for products of at most kMaxFusedM multiplicands: a dependent chain of
+// saturated Comba products costs a lone wavefront ~2 us each (every multiply-add drags a carry instruction with wait states behind it);
+// the 9 x 29-bit product is one chain of 153 back-to-back multiply-adds.  The result carries 2^(-5(M-1)) like the big rounds' partial
+// sums do (fe_device.hpp: Montgomery radix 2^261); the finalize step's scaled weights remove it.
+template <typename SlotsT, typename TabFn>
+__device__ __forceinline__ Fe combo_product_fe(const TabFn &tab, const Combo &c, const SlotsT slot_table, const SlotsT slot_exp, const uint64_t b,
+                                               const int32_t nv) {
+    Fe prod = fe_zero();
+    bool first = true;
+    for (uint32_t s0 = 0; s0 < c.n_slots; s0 += 4) {
+        const uint32_t ns = c.n_slots - s0 < 4u ? c.n_slots - s0 : 4u;
+        Fr lo[4], hi[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            if (q < ns) {
+                const uint4 *p = tab(slot_table[c.slot_off + s0 + q]) + 4 * b;
+                if (nv != 1) lo[q] = fr_load(p);
+                if (nv != 0) hi[q] = fr_load(p + 2);
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            if (q < ns) {
+                Fe val;
+                if (nv == 0) val = fe_from_fr(lo[q]);
+                else if (nv == 1) val = fe_from_fr(hi[q]);
+                else val = fe_line(fe_from_fr(lo[q]), fe_from_fr(hi[q]), nv);
+                uint32_t k = 0;
+                if (first) { prod = val; k = 1; first = false; }
+                for (const uint32_t e = slot_exp[c.slot_off + s0 + q]; k < e; ++k) prod = fe_mul<true>(val, prod);
+            }
+        }
+    }
+    return prod;
+}
+
 // one (product, node) combination over the block's pairs; the metadata comes from device memory or from a kernel argument.
 // `tab(u)` gives table u's current evaluations; (vbx, vgx) = this block's index and the block count along the pair axis (the
 // launch's blockIdx.x / gridDim.x, or the virtual ones of the persistent tail kernel).
@@ -875,7 +928,17 @@ __device__ __forceinline__ void sum_combo_body(const TabFn &tab, const Combo c, 
     const Fr tf = node_constant(nv);
     Fr acc = fr_zero();
     const uint64_t stride = (uint64_t)vgx * kBlock;
-    for (uint64_t b = (uint64_t)vbx * kBlock + threadIdx.x; b < n_pairs; b += stride) acc = fr_add(acc, combo_product(tab, c, slot_table, slot_exp, b, nv, tf));
+    if (c.M <= (uint32_t)kMaxFusedM) { // carry-free arithmetic (the sums come out scaled by 2^(-5(M-1)): finalize is told so)
+        Fe a = fe_zero();
+        uint32_t iter = 0;
+        for (uint64_t b = (uint64_t)vbx * kBlock + threadIdx.x; b < n_pairs; b += stride, ++iter) {
+            a = fe_carry_pass(fe_add(a, combo_product_fe(tab, c, slot_table, slot_exp, b, nv)));
+            if ((iter & 31u) == 31u) a = fe_from_fr(fe_to_fr(a)); // keep the top limb far from 2^31 on long grid-stride loops
+        }
+        acc = fe_to_fr(a);
+    } else {
+        for (uint64_t b = (uint64_t)vbx * kBlock + threadIdx.x; b < n_pairs; b += stride) acc = fr_add(acc, combo_product(tab, c, slot_table, slot_exp, b, nv, tf));
+    }
     const Fr s = block_sum(acc, sm);
     if (threadIdx.x == 0) fr_store(partials + 2 * (c.partial_off + (uint64_t)t * vgx + vbx), s);
 }
@@ -1284,13 +1347,20 @@ __global__ __launch_bounds__(kBlock, 3) void k_round1_tree_split(const RoundArgs
     __shared__ int32_t lacc[9 * 5 * kBlock];
     const TreeProd &T = R.prod[blockIdx.y];
     uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x);
+#ifdef SC_NO_CHAIN_R1 // A/B build
+    constexpr bool kC1 = false;
+#else
+    constexpr bool kC1 = true;
+#endif
     switch (T.M) {
-    case 1: tree_pass<1, true>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    case 2: tree_pass<2, true>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    case 3: tree_pass<3, true>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    default: tree_pass<4, true>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 1: tree_pass<1, true, kC1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 2: tree_pass<2, true, kC1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 3: tree_pass<3, true, kC1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    default: tree_pass<4, true, kC1>(T.slot, rt, n_pairs, row, sm, lacc); break;
     }
 }
+// kChain: single-chain multiply-adds (fe_device.hpp) -- the instantiation for a proof's first binding round, whose sources are canonical
+template <bool kChain>
 __global__ __launch_bounds__(kBlock, 3) void k_round_tree_split(const RoundArgs R, const BindConst r, const uint64_t n_pairs, uint4 *__restrict__ partials) {
     __shared__ uint32_t sm[kBlock / 64][8];
     __shared__ int32_t rt[kBindLds];
@@ -1299,10 +1369,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_round_tree_split(const RoundArgs 
     const TreeProd &T = R.prod[blockIdx.y];
     uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x);
     switch (T.M) {
-    case 1: tree_pass<1>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    case 2: tree_pass<2>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    case 3: tree_pass<3>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    default: tree_pass<4>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 1: tree_pass<1, false, kChain>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 2: tree_pass<2, false, kChain>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 3: tree_pass<3, false, kChain>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    default: tree_pass<4, false, kChain>(T.slot, rt, n_pairs, row, sm, lacc); break;
     }
 }
 
@@ -1489,7 +1559,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
             FrHost rh;
 #pragma unroll
             for (int i = 0; i < 4; ++i) rh.l[i] = r_sh[i];
-            const FrU r = fru_from_host(rh);
+            const FeU r32 = feu_shl5(fru_from_host(rh).v); // the carry-free bind's multiplier: r * 2^5 as 29-bit limbs
             // ---- bind: out[b] = in[2b] + r (in[2b+1] - in[2b]), 2 n_pairs outputs per table ------------------------------------
             const uint64_t n_out = 2 * n_pairs; // a power of two
             const int sh = 63 - __builtin_clzll(n_out);
@@ -1499,17 +1569,17 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                 const uint64_t b = i & (n_out - 1);
                 const uint4 *src = tab(u);
                 uint4 *dst = (binds & 1) ? A.t.b1[u] : A.t.b0[u];
-                Fr lo, hi;
+                Fe lo, hi;
                 const int32_t *stop = binds == 0 ? A.t.cur0_top[u] : nullptr;
                 if (stop) { // the table arrives from the big rounds in F29, leaves canonical
                     const int2 t = *reinterpret_cast<const int2 *>(stop + 2 * b);
-                    lo = fe_to_fr(fe_load_f29(src, 2 * b, t.x));
-                    hi = fe_to_fr(fe_load_f29(src, 2 * b + 1, t.y));
+                    lo = fe_load_f29(src, 2 * b, t.x);
+                    hi = fe_load_f29(src, 2 * b + 1, t.y);
                 } else {
-                    lo = fr_load(src + 4 * b);
-                    hi = fr_load(src + 4 * b + 2);
+                    lo = fe_from_fr(fr_load(src + 4 * b));
+                    hi = fe_from_fr(fr_load(src + 4 * b + 2));
                 }
-                fr_store(dst + 2 * b, fr_add(lo, fr_mul_u(fr_sub(hi, lo), r)));
+                fr_store(dst + 2 * b, fe_to_fr(fe_add(lo, fe_mul_u<true>(fe_sub(hi, lo), r32))));
             }
             binds += 1;
             if (solo) {
@@ -1535,13 +1605,16 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                 const int32_t nv = node_value((int)c.t);
                 const Fr tf = node_constant(nv);
                 Fr prod = fr_zero();
-                if (live) prod = combo_product(tab_lds, c, slot_table_sh, slot_exp_sh, b, nv, tf);
+                if (live) {
+                    if (c.M <= (uint32_t)kMaxFusedM) prod = fe_to_fr(combo_product_fe(tab_lds, c, slot_table_sh, slot_exp_sh, b, nv));
+                    else prod = combo_product(tab_lds, c, slot_table_sh, slot_exp_sh, b, nv, tf);
+                }
                 for (uint32_t off = (uint32_t)n_pairs >> 1; off >= 1; off >>= 1) prod = fr_add(prod, fr_shfl_down(prod, (int)off));
                 if (live && b == 0) fr_store(fin_lds + 2 * (prod_index_sh[ci] * A.D + (int)c.t), prod); // scratch[k * D + t]
             }
             __syncthreads();
             TAIL_STAMP(j, 2); // node sums ready
-            finalize_message<kBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 0, w_pre);
+            finalize_message<kBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 1, w_pre);
         } else {
             // ---- sums: virtual blocks (vx, combo) of the k_sum_combos launch this round would have been -------------------------
             const uint32_t vgx = (uint32_t)((n_pairs + kBlock - 1) / kBlock);
@@ -1555,7 +1628,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
             // (vgx <= kTailMaxPairs / kBlock = 8 partials per combination: block 0 adds them up itself)
             if (blockIdx.x == 0) {
                 finalize_body<kBlock>(prod_of, A.Wm, A.K, A.D, (int)vgx, A.partials, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag,
-                                      A.seq0 + (uint32_t)j, 0, w_pre);
+                                      A.seq0 + (uint32_t)j, 1, w_pre);
             }
         }
         // ---- block 0: the next challenge.  The host stores, for limb i of the challenge, the 64-bit word (limb << 32 | tag) into
@@ -1838,8 +1911,17 @@ hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64
     (void)split;
     (void)extra_lds;
 #endif
+    // the first binding round reads canonical tables like round 1 does (every source without a limb-8 array): the single-chain instantiation
+#ifdef SC_NO_CHAIN_R2 // A/B build: the single-chain instantiation for round 1 only
+    bool canonical_sources = false;
+#else
+    bool canonical_sources = !round1;
+#endif
+    for (int q = 0; q < args.n_prod && canonical_sources; ++q)
+        for (uint32_t f = 0; f < args.prod[q].M; ++f) canonical_sources = canonical_sources && args.prod[q].slot[f].src_top == nullptr;
     if (round1) hipLaunchKernelGGL(k_round1_tree_split, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, n_pairs, (uint4 *)d_partials);
-    else hipLaunchKernelGGL(k_round_tree_split, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
+    else if (canonical_sources) hipLaunchKernelGGL(k_round_tree_split<true>, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
+    else hipLaunchKernelGGL(k_round_tree_split<kChainDefault>, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
     return hipGetLastError();
 }
 
