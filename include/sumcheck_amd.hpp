@@ -262,6 +262,10 @@ class ProverState { // prover.rs:19-33, tables resident in HBM
         return out;
     }
     sc_prover *raw() { return h_; }
+    // library policy (no reference counterpart): false = no kernel of this handle ever waits for the host (a host with HIP streams of its
+    // own: see the interference contract in sumcheck_hip.h); patience of the resident kernel behind prove_round called round by round
+    void set_polling(bool allow) { check(sc_prover_set_polling(h_, allow ? 1 : 0)); }
+    void set_resident(uint32_t patience_polls) { check(sc_prover_set_resident(h_, patience_polls)); }
 
   private:
     sc_prover *h_ = nullptr;
@@ -271,6 +275,7 @@ class ProverState { // prover.rs:19-33, tables resident in HBM
 // The library keeps device memory between calls (the last prover it built, the work areas of evaluate / fix_variables, the GKR
 // scratch) so that one-shot calls cost what kept state costs; this returns all of it.
 inline void release_caches() { check(sc_release_caches()); }
+inline void set_cache_limit(uint64_t bytes) { check(sc_set_cache_limit(bytes)); } // what each of those caches may keep; 0 = nothing
 
 struct IPForMLSumcheck {
     static ProverState prover_init(const ListOfProductsOfPolynomials &polynomial) { // prover.rs:49-69

@@ -271,6 +271,43 @@ static void test_verifier_refuses_non_canonical(Blake2b512Rng &rng) {
     }));
 }
 
+// library policy switches (no reference counterpart): the hand-driven protocol of test.rs:77-97 gives the same messages with the
+// device-side waits off, with the resident kernel off, with nothing cached -- and through prove_as_subprotocol with polling off
+static void test_policy_switches_do_not_change_a_proof(Blake2b512Rng &rng) {
+    auto [poly, asserted_sum] = random_list_of_products(11, 2, 4, 3, rng);
+    std::vector<Fr> chal;
+    for (size_t i = 0; i < poly.num_variables; ++i) chal.push_back(rng.rand_fr());
+    auto dialogue = [&](int mode) {
+        ProverState ps = IPForMLSumcheck::prover_init(poly);
+        if (mode == 1) ps.set_polling(false);
+        if (mode == 2) ps.set_resident(0);
+        Proof msgs;
+        std::optional<VerifierMsg> vm;
+        for (size_t i = 0; i < poly.num_variables; ++i) {
+            msgs.push_back(IPForMLSumcheck::prove_round(ps, vm));
+            vm = VerifierMsg{chal[i]};
+            if (mode == 3 && i == 7) (void)ps.flattened_ml_extensions(); // asks the resident kernel to leave in the middle
+        }
+        return msgs;
+    };
+    const Proof ref = dialogue(0);
+    EXPECT(ref[0].evaluations[0] + ref[0].evaluations[1] == asserted_sum);
+    for (int mode = 1; mode <= 3; ++mode) {
+        const Proof got = dialogue(mode);
+        bool same = got.size() == ref.size();
+        for (size_t i = 0; same && i < ref.size(); ++i) same = got[i].evaluations == ref[i].evaluations;
+        EXPECT(same);
+    }
+    set_cache_limit(0); // nothing kept between calls
+    const Proof a = MLSumcheck::prove(poly);
+    set_cache_limit(16ull << 30);
+    const Proof b = MLSumcheck::prove(poly);
+    bool same = a.size() == b.size();
+    for (size_t i = 0; same && i < a.size(); ++i) same = a[i].evaluations == b[i].evaluations;
+    EXPECT(same);
+    EXPECT(evaluate(poly, MLSumcheck::verify(poly.info(), asserted_sum, a).point) == MLSumcheck::verify(poly.info(), asserted_sum, a).expected_evaluation);
+}
+
 int main() {
     if (sc_device_count() <= 0) {
         std::printf("no HIP device: these tests need a GPU\n");
@@ -289,6 +326,7 @@ int main() {
         {"test_shared_reference", [&] { test_shared_reference(rng); }},
         {"prover state machine panics", [&] { test_prover_state_machine(rng); }},
         {"verifier refuses non-canonical encodings and short messages", [&] { test_verifier_refuses_non_canonical(rng); }},
+        {"policy switches (polling, resident kernel, cache limit) do not change a proof", [&] { test_policy_switches_do_not_change_a_proof(rng); }},
         {"gkr test_extract (dim 6)", [&] { test_gkr_extract(rng, 6); }},
         {"gkr test_small shape (dim 9)", [&] { test_gkr_extract(rng, 9); }},
     };

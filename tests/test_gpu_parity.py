@@ -646,6 +646,41 @@ def test_streamed_host_tables_match_oracle(nv, nt, shapes, chunk):
         assert np.array_equal(m.evaluations, t)
 
 
+def test_cache_limit_and_polling_switch_do_not_change_results():
+    """sc_set_cache_limit(0): nothing is kept between calls (every call allocates and frees its own) -- same proofs, same evaluation,
+    same GKR proof as with the caches; SC_NO_DEVICE_POLLING / sc_prover_set_polling(p, 0): every round launched after its challenge."""
+    nv, nt, shapes = 15, 4, [[0, 1, 2], [3, 3], [1]]
+    tabs = [cref.synth_table(7300, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(7300, 1000, len(shapes))
+    d = H.desc_from(nv, shapes, tabs, coefs)
+    want, wrand = cref.ml_prove(d, threads=4)
+    point = cref.synth_table(7300, 2000, nv)
+    poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device="cuda:0")
+    try:
+        for limit in (0, 1 << 20, 16 << 30):
+            _lib.check(sc.lib().sc_set_cache_limit(limit))
+            for _ in range(2):
+                assert np.array_equal(np.stack([m.evaluations for m in sc.MLSumcheck.prove(poly)]), want)
+                assert np.array_equal(poly.evaluate(point), cref.poly_evaluate(d, point))
+    finally:
+        _lib.check(sc.lib().sc_set_cache_limit(16 << 30))
+    st = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+    _lib.check(sc.lib().sc_prover_set_polling(st._h, 0))
+    assert np.array_equal(st.prove(sc.Blake2b512Rng.setup()), want) and np.array_equal(st.randomness, wrand)
+    _lib.check(sc.lib().sc_prover_set_polling(st._h, 1))
+    st.reset()
+    assert np.array_equal(st.prove(sc.Blake2b512Rng.setup()), want)
+    st.close()
+    dd, keep = poly._desc(True)
+    dd.flags |= _lib.SC_NO_DEVICE_POLLING
+    h = C.c_void_p()
+    _lib.check(sc.lib().sc_prover_init(C.byref(dd), C.byref(h)))
+    proof = np.empty((nv, 4, 4), dtype=np.uint64)
+    _lib.check(sc.lib().sc_ml_prove_handle(h, None, C.c_void_p(proof.ctypes.data)))
+    sc.lib().sc_prover_free(h)
+    assert np.array_equal(proof, want)
+
+
 @pytest.mark.parametrize("nv,nt,shapes", [(14, 10, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]), (9, 3, [[0, 1, 2], [2, 2]]), (13, 2, [[0, 1]])])
 def test_interactive_rounds_resident_kernel(nv, nt, shapes):
     """IPForMLSumcheck::prove_round round by round (prover.rs:74-77): the late rounds are served by ONE kernel that stays on the GPU

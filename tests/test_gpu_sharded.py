@@ -111,6 +111,23 @@ def test_sharded_proof_peer_to_peer_exchange_threads_on_one_gpu(G, nv, nt, shape
             assert np.array_equal(rand, wrand), f"rank {r}"
 
 
+def test_peer_to_peer_group_misuse_is_refused():
+    """a rank that joins a group twice, ranks that disagree on its size, a size beyond the inbox layout, a rank outside the group"""
+    _P2P_GROUP[0] += 1
+    gid = _P2P_GROUP[0]
+    _lib.check(sc.lib().sc_set_device(0))
+    a = sharded.P2PComm(gid, 0, 1, "cuda:0")  # a one-rank group forms at once
+    a.selftest()
+    h = C.c_void_p()
+    assert sc.lib().sc_comm_init_p2p(gid, 0, 1, C.byref(h)) == _lib.SC_ERR_BAD_ARG       # joined twice
+    assert sc.lib().sc_comm_init_p2p(gid, 1, 2, C.byref(h)) == _lib.SC_ERR_BAD_ARG       # disagrees on the size
+    assert sc.lib().sc_comm_init_p2p(gid + 100000, 0, 64, C.byref(h)) == _lib.SC_ERR_BAD_ARG
+    assert sc.lib().sc_comm_init_p2p(gid + 100000, 3, 2, C.byref(h)) == _lib.SC_ERR_BAD_ARG
+    a.close()
+    b = sharded.P2PComm(gid, 0, 1, "cuda:0")  # the id is free again once the last rank has left
+    b.close()
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_proof_peer_to_peer_one_thread_per_gpu(world):
     """the same on distinct GPUs (xGMI peer writes, pipelined late rounds): skipped below `world` visible GPUs"""
