@@ -146,6 +146,8 @@ def main():
                     help="config 3 at N>1: strong = the nv=24 instance split N ways (the metric as worded), weak = nv=24 per GPU")
     ap.add_argument("--nv", type=int, default=0, help="override the GLOBAL number of variables (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="HIP events around the dominant kernel's launches (the roofline's live duration) on every N-th timed step; 1 = every step")
     args = ap.parse_args()
 
     import torch
@@ -265,14 +267,33 @@ def main():
         C.CDLL(None).fflush(None)
     except Exception:
         pass
-    _lib.check(sc.lib().sc_prover_set_timing(handle, 1))  # per-kernel HIP events on the launch stream, timed region only
+    # The dominant kernel's duration is measured live, with HIP events on the launch stream inside the timed region -- on every
+    # --time-every-th step only: the events are instrumentation (four records and a collect per big round, ~1 % of a proof), and the
+    # other steps run as a caller's proofs do.  The sampled steps are part of the K timed steps like any other.
+    K = len(shapes)
+    ms_acc, ln_acc, rounds_ms_acc, timed_steps = [0.0] * K, [0] * K, 0.0, 0
+    ms = (C.c_double * K)()
+    ln = (C.c_uint64 * K)()
+    rounds_ms = C.c_double()
+    every = max(1, args.time_every)
     barrier()
     t0 = time.perf_counter()
     step_s = []  # a step returns when its last round's message is on the host, so per-step wall times cost nothing extra
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        sampled = i % every == 0
+        if sampled:
+            _lib.check(sc.lib().sc_prover_set_timing(handle, 1))
         ts = time.perf_counter()
         proof = step()
         step_s.append(time.perf_counter() - ts)
+        if sampled:
+            _lib.check(sc.lib().sc_prover_get_timing(handle, ms, ln, C.byref(rounds_ms)))
+            _lib.check(sc.lib().sc_prover_set_timing(handle, 0))
+            for q in range(K):
+                ms_acc[q] += ms[q]
+                ln_acc[q] += ln[q]
+            rounds_ms_acc += rounds_ms.value
+            timed_steps += 1
     barrier()
     elapsed = time.perf_counter() - t0
     # The line certifies its own parity: the last TIMED proof and one more proof after the timed region are compared, message by
@@ -296,11 +317,9 @@ def main():
     elif force_sharded and box["python"]:
         round_loop = "torch.distributed"
 
-    K = len(shapes)
-    ms = (C.c_double * K)()
-    ln = (C.c_uint64 * K)()
-    rounds_ms = C.c_double()
-    _lib.check(sc.lib().sc_prover_get_timing(handle, ms, ln, C.byref(rounds_ms)))
+    ms, ln = ms_acc, ln_acc
+    rounds_ms_total = rounds_ms_acc
+    ev_steps = max(timed_steps, 1)
 
     if rank == 0:
         ops = field_ops(nv_total, shapes, U)
@@ -316,7 +335,7 @@ def main():
         big_bytes = 32 * u_dom * ((1 << nv_local) + sum((1 << (nv_local - i + 2)) + (1 << (nv_local - i + 1)) for i in range(2, big_rounds + 1)))
         launches = int(ln[dom])
         avg_ms = ms[dom] / max(launches, 1)
-        bytes_per_launch = big_bytes * args.steps / max(launches, 1)
+        bytes_per_launch = big_bytes * ev_steps / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_source = None, None  # measured off-line with rocprofv3 PMC passes (tools/profile.sh), per launch of the same kernel
         try:
@@ -328,7 +347,7 @@ def main():
             pass
         # rounds_ms: event span of the rounds launched with events = the big rounds (late rounds are pipelined and record none)
         big_all_bytes = 32 * U * ((1 << nv_local) + sum((1 << (nv_local - i + 2)) + (1 << (nv_local - i + 1)) for i in range(2, big_rounds + 1)))
-        big_rounds_gbps = big_all_bytes * args.steps / (rounds_ms.value * 1e-3) / 1e9 if rounds_ms.value > 0 else 0.0
+        big_rounds_gbps = big_all_bytes * ev_steps / (rounds_ms_total * 1e-3) / 1e9 if rounds_ms_total > 0 else 0.0
         cfg_name = ("BASELINE config 4" if args.config == 4 else "BASELINE config 3") + (f", {scaling} scaling" if world > 1 else "")
         out = {
             "metric": "MLSumcheck prover field-ops/s (BLS12-381 Fr, nv=24)" if args.config == 3 else "MLSumcheck prover field-ops/s (BLS12-381 Fr, nv=28, config 4)",
@@ -345,9 +364,10 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": (f"k_round1_tree_split (round 1) + k_round_tree_split (rounds 2..{big_rounds}): all products, one launch per big round, one product per block row" if merged
                                     else f"{kname} (product {dom}, big rounds)"),
                          "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "big_rounds_GBps_incl_finalize": big_rounds_gbps, "big_rounds_ms_per_step": rounds_ms.value / args.steps,
+                         "big_rounds_GBps_incl_finalize": big_rounds_gbps, "big_rounds_ms_per_step": rounds_ms_total / ev_steps,
+                         "event_timed_steps": timed_steps, "event_timed_every": every,
                          "whole_proof_GBps": algorithmic_bytes(nv_local, U) * args.steps / elapsed / 1e9,
-                         "per_product_ms_per_step": [m / args.steps for m in ms],
+                         "per_product_ms_per_step": [m / ev_steps for m in ms],
                          # reference-algorithm multiplications per second over the measured Montgomery-product
                          # ceiling of the chip (137.6 G/s, saturated Comba product, profiles/r1_modmul_ceiling.txt).  It can
                          # exceed 1: the kernels execute fewer products than the reference algorithm (nodes, product tree).

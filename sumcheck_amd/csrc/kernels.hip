@@ -540,6 +540,49 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
             for (int l = 0; l < 9; ++l) my[(9 * t + l) * kBlock] = a.l[l];
         }
     }
+    // Block sums of the M + 1 nodes TOGETHER: the canonical conversions and the six shuffle steps of the nodes are independent chains
+    // that the scheduler interleaves, the wavefronts' sums cross through LDS behind ONE pair of barriers (the running sums' LDS is free
+    // by then), and threads 0..M each finish one node.  One node after the other, this epilogue was the last microseconds of every block of
+    // a four-multiplicand row -- invisible in the long rounds, visible in the short ones.
+#ifndef SC_SERIAL_EPILOGUE // (A/B build)
+    (void)sm;
+    Fr s[M + 1];
+#pragma unroll
+    for (int t = 0; t <= M; ++t) {
+        Fe a;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) a.l[l] = my[(9 * t + l) * kBlock];
+        s[t] = fe_to_fr(a);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int t = 0; t <= M; ++t) s[t] = fr_add(s[t], fr_shfl_down(s[t], off));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *x = reinterpret_cast<uint32_t *>(lacc); // [wave][node][8]
+    __syncthreads();                                   // every thread has read its running sums
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t <= M; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[(wave * (M + 1) + t) * 8 + i] = s[t].v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x <= (uint32_t)M) {
+        const int t = threadIdx.x;
+        Fr acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc.v[i] = x[t * 8 + i];
+        for (int w = 1; w < kBlock / 64; ++w) {
+            Fr o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] = x[(w * (M + 1) + t) * 8 + i];
+            acc = fr_add(acc, o);
+        }
+        fr_store(row + 2 * ((uint64_t)t * gridDim.x), acc);
+    }
+#else
 #pragma unroll
     for (int t = 0; t <= M; ++t) {
         Fe a;
@@ -548,6 +591,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
         const Fr s = block_sum(fe_to_fr(a), sm);
         if (threadIdx.x == 0) fr_store(row + 2 * ((uint64_t)t * gridDim.x), s);
     }
+#endif
 }
 
 template <int M>
