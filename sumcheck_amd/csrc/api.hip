@@ -1266,13 +1266,14 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
 
 static int await_round(sc_prover *p, uint64_t *out_evals, uint32_t want);
 
+constexpr int kResidentGone = -1; // internal: no resident kernel serves this round; take the ordinary path
 static int resident_start(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals);
 static int resident_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals);
 extern "C" int sc_prove_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals) {
     if (!p || !out_evals) return fail(SC_ERR_BAD_ARG, "null argument");
     // late rounds of the interactive protocol: a kernel that stays on the GPU between calls (see resident_start)
     int rc = p->res.active ? resident_round(p, r_or_null, out_evals) : resident_start(p, r_or_null, out_evals);
-    if (rc != -1 /* kResidentGone */) return rc;
+    if (rc != kResidentGone) return rc;
     rc = launch_round(p, r_or_null, nullptr, true);
     if (rc) return rc;
     return await_round(p, out_evals, p->seq);
@@ -1513,11 +1514,7 @@ static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, co
 // patience is short (resident_spins polls, ~0.5 ms): a verifier that does not answer in time finds the kernel gone -- it leaves cleanly
 // after the last round it completed, tables consistent -- and the call proceeds as if there had never been one (a launch sequence, or a
 // new resident kernel).  Every other entry point that touches the handle's stream or tables quiesces it first (a tagged stop word).
-constexpr int kResidentGone = -1; // internal: no resident kernel serves this round; take the ordinary path
-static bool resident_release_slot(sc_prover *p) {
-    g_tail_busy[(unsigned)p->device & 63u].store(0, std::memory_order_release);
-    return true;
-}
+static void resident_release_slot(sc_prover *p) { g_tail_busy[(unsigned)p->device & 63u].store(0, std::memory_order_release); }
 // the kernel has exited (all rounds done, patience expired, or stop word): fold what it did into the handle
 static int resident_finish(sc_prover *p) {
     if (!p->res.active) return SC_OK;

@@ -218,3 +218,21 @@ def test_argument_validation_matches_reference_asserts():
     for sh in ([2, 3, 0], [1, 4, 4], [3, 2, 1], [0, 0], [4]):
         p.add_product([ts[i] for i in sh], field.ONE)
     assert len(p.flattened_ml_extensions) == 5 and p.max_multiplicands == 3
+
+
+def test_header_is_a_c_header_and_the_library_links_from_plain_c(tmp_path):
+    """include/sumcheck_hip.h compiled as C99 (-pedantic -Werror) in tests/c/abi_smoke.c, linked against libsumcheck_hip.so and run:
+    ABI version, the transcript (BLAKE2b-512("abc")), the verifier's refusal of wrong lengths, and -- without a device -- the loud
+    SC_ERR_HIP of a compute entry point.  What a cgo / JNI binding does first; no Python, no torch in that process."""
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    so_dir = os.path.dirname(_lib.SO_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe,
+                           "-L" + so_dir, "-l:" + os.path.basename(_lib.SO_PATH), "-Wl,-rpath," + so_dir])
+    env = dict(os.environ)
+    # the pure-C process uses the system HIP runtime (or torch's, when that is the only one present)
+    import glob
+    extra = [p for p in ("/opt/rocm/lib",) + tuple(glob.glob("/usr/local/lib/python3*/dist-packages/torch/lib")) if os.path.isdir(p)]
+    env["LD_LIBRARY_PATH"] = ":".join(extra + [env.get("LD_LIBRARY_PATH", "")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "ABI-SMOKE-OK" in r.stdout, (r.returncode, r.stdout, r.stderr[-2000:])
