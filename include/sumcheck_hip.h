@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 3 /* 3: sc_prover_set_polling, sc_prover_set_resident, SC_NO_DEVICE_POLLING, sc_set_cache_limit, sc_comm_init_p2p (additions only) */
+#define SC_ABI_VERSION 3 /* 3: sc_prover_set_polling, sc_prover_set_resident, SC_NO_DEVICE_POLLING, sc_set_cache_limit, sc_comm_init_p2p, sc_gkr_prove_sharded (additions only) */
 #define SC_API __attribute__((visibility("default")))
 
 enum sc_status {
@@ -277,6 +277,15 @@ SC_API int sc_gkr_phase_one_sharded(sc_comm *comm_or_null, const uint64_t *f1_id
                                     uint64_t *f1g_idx, uint64_t *f1g_vals, uint64_t *f1g_nnz);
 SC_API int sc_gkr_phase_two_sharded(sc_comm *comm_or_null, const uint64_t *f1g_idx, const uint64_t *f1g_vals, uint64_t nnz_local, uint32_t dim,
                                     const uint64_t *u, uint32_t flags, uint64_t *f1_gu_or_null, uint64_t *lanes_or_null);
+/* GKRRoundSumcheck::prove (mod.rs:93-139) over several GPUs END TO END: the two initialisations as above (every rank passes its own
+ * subset of f1's non-zeros, and ALL of f2, f3, g) and BOTH sumcheck phases sharded like sc_ml_prove_sharded -- rank r proves over
+ * entries [r 2^dim / G, (r+1) 2^dim / G) of the phase's two tables, one all-reduce of the three evaluations per round, early gather,
+ * replicated tail; f2(u) is evaluated on every rank and scales the rank's own slice of f3.  `rng` continues the caller's transcript
+ * exactly as sc_gkr_prove does (no PolynomialInfo is fed: mod.rs:108-133).  out_proof: 2 x dim x 3 x 4, out_uv_or_null: 2 x dim x 4;
+ * identical on every rank.  nranks a power of two below 2^dim.  Worth it from dim ~ 24 (config 5, dim = 20, belongs on one GPU). */
+SC_API int sc_gkr_prove_sharded(sc_comm *comm, sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz_local, uint32_t dim,
+                                const uint64_t *f2, const uint64_t *f3, const uint64_t *g, uint32_t flags, uint64_t *out_proof,
+                                uint64_t *out_uv_or_null);
 /* n elements of 8 summed uint64 lanes -> canonical Montgomery limbs, on the GPU (sc_wide_reduce is the host twin for a handful
  * of elements).  flags: SC_TABLES_ON_DEVICE => lanes / out are device pointers. */
 SC_API int sc_wide_reduce_table(const uint64_t *lanes, uint64_t n, uint64_t *out, uint32_t flags);

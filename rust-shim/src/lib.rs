@@ -99,6 +99,8 @@ extern "C" {
     pub fn sc_gkr_phase_two(f1g_idx: *const u64, f1g_vals: *const u64, nnz: u64, dim: u32, u: *const u64, flags: u32, f1_gu: *mut u64) -> c_int;
     pub fn sc_gkr_prove(rng: *mut sc_rng, f1_idx: *const u64, f1_vals: *const u64, nnz: u64, dim: u32, f2: *const u64, f3: *const u64,
                         g: *const u64, flags: u32, out_proof: *mut u64, out_uv_or_null: *mut u64) -> c_int;
+    pub fn sc_gkr_prove_sharded(comm: *mut sc_comm, rng: *mut sc_rng, f1_idx: *const u64, f1_vals: *const u64, nnz_local: u64, dim: u32, f2: *const u64,
+                                f3: *const u64, g: *const u64, flags: u32, out_proof: *mut u64, out_uv_or_null: *mut u64) -> c_int;
     pub fn sc_comm_unique_id(out128: *mut u8) -> c_int;
     pub fn sc_comm_init(id128: *const u8, rank: c_int, nranks: c_int, out: *mut *mut sc_comm) -> c_int;
     pub fn sc_comm_init_host(rank: c_int, nranks: c_int, allreduce: sc_allreduce_u64_fn, allgather: sc_allgather_fn, ctx: *mut c_void,

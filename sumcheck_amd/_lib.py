@@ -98,6 +98,7 @@ SIGNATURES = {
     "sc_dense_scale": (C.c_int, [_V, C.c_uint64, _V, _V, C.c_uint32]),
     "sc_gkr_phase_one_sharded": (C.c_int, [_V, _V, _V, C.c_uint64, C.c_uint32, _V, _V, C.c_uint32, _V, _V, _V, _V, u64p]),
     "sc_gkr_phase_two_sharded": (C.c_int, [_V, _V, _V, C.c_uint64, C.c_uint32, _V, C.c_uint32, _V, _V]),
+    "sc_gkr_prove_sharded": (C.c_int, [_V, _V, _V, _V, C.c_uint64, C.c_uint32, _V, _V, _V, C.c_uint32, _V, _V]),
     "sc_wide_reduce_table": (C.c_int, [_V, C.c_uint64, _V, C.c_uint32]),
     "sc_synth_table_device": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _V]),
     "sc_prover_last_round_ms": (C.c_int, [_V, C.POINTER(C.c_float)]),

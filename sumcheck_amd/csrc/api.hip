@@ -3068,16 +3068,13 @@ static int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, co
     return SC_OK;
 }
 
-extern "C" int sc_ml_prove_sharded(sc_prover *p, sc_comm *comm, sc_rng *rng_or_null, uint32_t nv_total, uint64_t *out_proof, uint64_t *out_randomness) {
-    if (!p || !comm || !out_proof || !out_randomness) return fail(SC_ERR_BAD_ARG, "null argument");
+// everything of sc_ml_prove_sharded after the transcript has absorbed what precedes the rounds
+static int sharded_proof_body(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, uint32_t nv_total, uint64_t *out_proof, uint64_t *out_randomness) {
     const uint32_t G = (uint32_t)comm->nranks;
     if (G == 0 || (G & (G - 1)) != 0) return fail(SC_ERR_BAD_ARG, "the number of ranks must be a power of two");
     uint32_t k = 0;
     while ((1u << k) < G) ++k;
     if (p->round != 0 || p->nv + k != nv_total) return fail(SC_ERR_BAD_ARG, "handle must be at round 0 and hold a 1/%u shard of %u variables", G, nv_total);
-    sc_rng local;
-    sch::Blake2b512Rng &rng = rng_or_null ? rng_or_null->rng : local.rng;
-    rng.feed_poly_info(p->max_mult, nv_total); // mod.rs:54: the GLOBAL instance's info
     uint32_t m = sharded_tail_m(p->nv, k);
     // a streamed shard's tables only exist in HBM once round 2 has bound them: at least two local rounds before the gather (every rank
     // of a group uses the same kind of handle, so every rank computes the same m)
@@ -3089,6 +3086,20 @@ extern "C" int sc_ml_prove_sharded(sc_prover *p, sc_comm *comm, sc_rng *rng_or_n
     if (k == 0) return sc_prover_push_randomness(p, last); // mod.rs:65-67
     return sharded_tail(p, comm, rng, last, k, m, out_proof + (size_t)nl * p->D * 4, out_randomness + (size_t)nl * 4);
 }
+extern "C" int sc_ml_prove_sharded(sc_prover *p, sc_comm *comm, sc_rng *rng_or_null, uint32_t nv_total, uint64_t *out_proof, uint64_t *out_randomness) {
+    if (!p || !comm || !out_proof || !out_randomness) return fail(SC_ERR_BAD_ARG, "null argument");
+    sc_rng local;
+    sch::Blake2b512Rng &rng = rng_or_null ? rng_or_null->rng : local.rng;
+    rng.feed_poly_info(p->max_mult, nv_total); // mod.rs:54: the GLOBAL instance's info
+    return sharded_proof_body(p, comm, rng, nv_total, out_proof, out_randomness);
+}
+// gkr.hip: the rounds of one GKR sumcheck phase over a sharded pair of tables -- GKRRoundSumcheck::prove feeds no PolynomialInfo
+// (gkr_round_sumcheck/mod.rs:108-133) -- and the communicator's shape
+int sc_internal_sharded_phase(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, uint32_t nv_total, uint64_t *out_proof, uint64_t *out_randomness) {
+    if (!p || !comm || !out_proof || !out_randomness) return fail(SC_ERR_BAD_ARG, "null argument");
+    return sharded_proof_body(p, comm, rng, nv_total, out_proof, out_randomness);
+}
+int sc_internal_comm_rank(sc_comm *c) { return c ? c->rank : 0; }
 
 // ---------------------------------------------------------------------------------------------------
 // integer all-reduce lanes -> field

@@ -1181,6 +1181,101 @@ static int run_phase(sch::Blake2b512Rng &rng, sc_prover **handle, const Fr *dA, 
     return sc_internal_run_rounds(*handle, rng, dim, out_msgs, challenges); // prove_round / feed / sample x dim (late rounds pipelined)
 }
 
+// GKRRoundSumcheck::prove (mod.rs:93-139) with f1's non-zeros spread over the ranks of `comm` AND both sumcheck phases sharded: the two
+// initialisations as sc_gkr_phase_one/two_sharded (every rank ends with the complete dense table), then each phase's product of two
+// tables proved like any sharded MLSumcheck -- rank r takes entries [r 2^dim / G, (r + 1) 2^dim / G) of both tables (high-bit sharding:
+// pairs stay local under LSB-first binding), per-round all-reduce of the three evaluations, early gather, replicated tail.  f2(u) is
+// evaluated on every rank (2^dim products; the scalar is the same everywhere) and scales the rank's own slice of f3.  Worth it from
+// dim ~ 24; BASELINE config 5 (dim = 20) stays on one GPU.  Every rank returns the same proof and (u, v).
+int sc_internal_sharded_phase(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, uint32_t nv_total, uint64_t *out_proof, uint64_t *out_randomness); // api.hip
+int sc_internal_comm_rank(sc_comm *c);
+extern "C" int sc_gkr_prove_sharded(sc_comm *comm, sc_rng *rng, const uint64_t *f1_idx, const uint64_t *f1_vals, uint64_t nnz_local, uint32_t dim,
+                                    const uint64_t *f2, const uint64_t *f3, const uint64_t *g, uint32_t flags, uint64_t *out_proof, uint64_t *out_uv_or_null) {
+    if (!comm || !rng || (nnz_local && (!f1_idx || !f1_vals)) || !f2 || !f3 || !g || !out_proof) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    int rc = check_gkr_args(nnz_local, dim);
+    if (rc) return rc;
+    if ((rc = check_points(g, dim, "g"))) return rc;
+    const uint32_t G = (uint32_t)sc_internal_comm_ranks(comm), rank = (uint32_t)sc_internal_comm_rank(comm);
+    uint32_t k = 0;
+    while ((1u << k) < G) ++k;
+    if ((1u << k) != G || dim <= k) return sc_internal_fail(SC_ERR_BAD_ARG, "the number of ranks must be a power of two below 2^dim");
+    const bool dev = flags & SC_TABLES_ON_DEVICE;
+    const uint64_t N = 1ULL << dim, Nl = N >> k;
+    G_TRY(hipSetDevice(sc_internal_device()));
+    struct Bufs { // plain allocations: the calls below lease the process-wide GKR scratch themselves
+        std::vector<void *> v;
+        ~Bufs() {
+            for (void *q : v) (void)hipFree(q);
+        }
+        hipError_t get(void **out, size_t bytes) {
+            hipError_t e = hipMalloc(out, bytes ? bytes : 32);
+            if (e == hipSuccess) v.push_back(*out);
+            return e;
+        }
+    } bufs;
+    const uint64_t *d_idx = f1_idx, *d_vals = f1_vals, *d_f2 = f2, *d_f3 = f3;
+    auto stage = [&](const uint64_t *src, size_t bytes, const uint64_t **dst) -> int {
+        void *d = nullptr;
+        G_TRY(bufs.get(&d, bytes));
+        if (bytes) G_TRY(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        *dst = static_cast<const uint64_t *>(d);
+        return SC_OK;
+    };
+    if (!dev) {
+        if ((rc = stage(f1_idx, nnz_local * 8, &d_idx)) || (rc = stage(f1_vals, nnz_local * 32, &d_vals)) || (rc = stage(f2, N * 32, &d_f2)) ||
+            (rc = stage(f3, N * 32, &d_f3)))
+            return rc;
+    }
+    uint64_t *d_hg = nullptr, *d_gi = nullptr, *d_gv = nullptr, *d_f1gu = nullptr, *d_f3s = nullptr, *d_scalar = nullptr;
+    G_TRY(bufs.get(reinterpret_cast<void **>(&d_hg), N * 32));
+    G_TRY(bufs.get(reinterpret_cast<void **>(&d_gi), nnz_local * 8));
+    G_TRY(bufs.get(reinterpret_cast<void **>(&d_gv), nnz_local * 32));
+    G_TRY(bufs.get(reinterpret_cast<void **>(&d_f1gu), N * 32));
+    G_TRY(bufs.get(reinterpret_cast<void **>(&d_f3s), Nl * 32));
+    G_TRY(bufs.get(reinterpret_cast<void **>(&d_scalar), 32));
+    uint64_t n1 = 0;
+    if ((rc = sc_gkr_phase_one_sharded(comm, d_idx, d_vals, nnz_local, dim, d_f3, g, SC_TABLES_ON_DEVICE, d_hg, nullptr, d_gi, d_gv, &n1))) return rc; // mod.rs:106
+    // phase one: h_g * f2 (mod.rs:45-54, 107-119) on this rank's slices
+    struct Handle {
+        sc_prover *p = nullptr;
+        ~Handle() {
+            if (p) sc_prover_free(p);
+        }
+    } h;
+    const uint64_t *tabs[2] = {d_hg + 4 * (size_t)rank * Nl, d_f2 + 4 * (size_t)rank * Nl};
+    {
+        const uint32_t offs[2] = {0, 2}, idx[2] = {0, 1};
+        sc_poly_desc d;
+        std::memset(&d, 0, sizeof(d));
+        d.num_vars = dim - k;
+        d.max_multiplicands = 2;
+        d.n_products = 1;
+        d.coeffs = sch::kOne.l;
+        d.prod_offsets = offs;
+        d.prod_indices = idx;
+        d.n_tables = 2;
+        d.tables = tabs;
+        d.flags = SC_TABLES_ON_DEVICE | SC_TABLES_BORROW;
+        if ((rc = sc_prover_init(&d, &h.p))) return rc;
+    }
+    std::vector<uint64_t> u((size_t)dim * 4), v((size_t)dim * 4);
+    if ((rc = sc_internal_sharded_phase(h.p, comm, rng->rng, dim, out_proof, u.data()))) return rc;
+    // phase two: f1(g, u, .) * (f2(u) f3) (mod.rs:57-82, 121-133)
+    if ((rc = sc_gkr_phase_two_sharded(comm, d_gi, d_gv, n1, dim, u.data(), SC_TABLES_ON_DEVICE, d_f1gu, nullptr))) return rc;
+    if ((rc = sc_fix_variables(d_f2, dim, u.data(), dim, d_scalar, SC_TABLES_ON_DEVICE))) return rc; // f2.evaluate(&u), mod.rs:122
+    uint64_t scalar[4];
+    G_TRY(hipMemcpy(scalar, d_scalar, 32, hipMemcpyDeviceToHost));
+    if ((rc = sc_dense_scale(d_f3 + 4 * (size_t)rank * Nl, Nl, scalar, d_f3s, SC_TABLES_ON_DEVICE))) return rc; // mod.rs:71-75, this rank's slice
+    const uint64_t *tabs2[2] = {d_f1gu + 4 * (size_t)rank * Nl, d_f3s};
+    if ((rc = sc_prover_reset(h.p, tabs2, SC_TABLES_ON_DEVICE))) return rc;
+    if ((rc = sc_internal_sharded_phase(h.p, comm, rng->rng, dim, out_proof + (size_t)dim * 12, v.data()))) return rc;
+    if (out_uv_or_null) {
+        std::memcpy(out_uv_or_null, u.data(), (size_t)dim * 32);
+        std::memcpy(out_uv_or_null + (size_t)dim * 4, v.data(), (size_t)dim * 32);
+    }
+    return SC_OK;
+}
+
 namespace {
 struct ProverGuard { // declared AFTER the DevBuf it pairs with, so it is destroyed first, while the cache lease is still held
     sc_prover *p = nullptr;

@@ -65,6 +65,23 @@ def initialize_phase_two_sharded(comm, f1_g_local: SparseMultilinearExtension, u
     return DenseMultilinearExtension(dim, out)
 
 
+def prove_sharded(comm, rng, f1_local: SparseMultilinearExtension, f2: DenseMultilinearExtension, f3: DenseMultilinearExtension, g):
+    """GKRRoundSumcheck::prove over the ranks of `comm`, initialisations AND both sumcheck phases sharded (sc_gkr_prove_sharded): every rank
+    passes its own subset of f1's non-zeros and all of f2, f3, g (host arrays, or all of them device tensors); every rank gets the same
+    -> (phase-one messages (dim, 3, 4), phase-two messages (dim, 3, 4), u (dim, 4), v (dim, 4))."""
+    dim = f3.num_vars
+    assert f1_local.num_vars == 3 * dim and f2.num_vars == dim
+    on_dev = bool(f1_local.on_device and f2.on_device and f3.on_device)
+    assert on_dev or not (f1_local.on_device or f2.on_device or f3.on_device), "host arrays, or device tensors throughout"
+    g = _np64(g).reshape(-1, 4)
+    proof = np.empty((2, dim, 3, 4), dtype=np.uint64)
+    uv = np.empty((2, dim, 4), dtype=np.uint64)
+    i_ptr, v_ptr = f1_local._ptrs()
+    check(lib().sc_gkr_prove_sharded(comm._h, rng._h, i_ptr, v_ptr, f1_local.nnz, dim, _dense_ptr(f2), _dense_ptr(f3), _ptr(g),
+                                     SC_TABLES_ON_DEVICE if on_dev else 0, _ptr(proof), _ptr(uv)))
+    return proof[0], proof[1], uv[0], uv[1]
+
+
 class HipGkrEngine:
     """per-rank compute of the caller-driven protocol: the rank's contribution as lanes (sc_gkr_phase_*_sharded, lanes mode)"""
 
