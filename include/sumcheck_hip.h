@@ -29,7 +29,9 @@
  *
  * ERRORS.  Nothing aborts across the ABI.  The four misuse panics of the reference map to status codes
  * (the shim turns them back into the same panic! messages); sc_last_error() gives detail.
- * There is NO CPU fallback: without a usable HIP device every compute entry point returns SC_ERR_HIP.
+ * There is NO CPU fallback: without a usable HIP device every compute entry point returns SC_ERR_HIP.  A call that fails on a HIP error
+ * (SC_ERR_OOM: an allocation was refused; SC_ERR_HIP) takes that error out of the runtime's per-thread "last error" slot, so it does not
+ * resurface in the next call; the handle it failed on is freed (init) or must be reset (a proof in progress).
  */
 #ifndef SUMCHECK_HIP_H
 #define SUMCHECK_HIP_H

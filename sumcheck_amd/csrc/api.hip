@@ -103,12 +103,16 @@ int sc_internal_fail(int code, const char *fmt, ...) {
     g_last_error = buf;
     return code;
 }
+// (a failed HIP call also leaves its code as the thread's sticky "last error": it is taken out here, or the next kernel launch of this
+// thread -- whose wrapper returns hipGetLastError() -- would report it again: one refused hipMalloc must not fail the proofs after it)
 #define HIP_TRY(expr)                                                                                                   \
     do {                                                                                                                \
         hipError_t e_ = (expr);                                                                                         \
-        if (e_ != hipSuccess)                                                                                           \
+        if (e_ != hipSuccess) {                                                                                         \
+            (void)hipGetLastError();                                                                                    \
             return fail(e_ == hipErrorOutOfMemory ? SC_ERR_OOM : SC_ERR_HIP, "%s failed: %s (%s:%d)", #expr,            \
                         hipGetErrorString(e_), __FILE__, __LINE__);                                                     \
+        }                                                                                                               \
     } while (0)
 
 static inline FrHost to_dev(const sch::Fr &a) {

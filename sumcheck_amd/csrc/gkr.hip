@@ -431,9 +431,11 @@ __global__ __launch_bounds__(kBlock) void k_wide_fold(const uint64_t *__restrict
 #define G_TRY(expr)                                                                                                      \
     do {                                                                                                                 \
         hipError_t e_ = (expr);                                                                                          \
-        if (e_ != hipSuccess)                                                                                            \
+        if (e_ != hipSuccess) {                                                                                          \
+            (void)hipGetLastError(); /* (not left behind as the thread's sticky error: see api.hip, HIP_TRY) */          \
             return sc_internal_fail(e_ == hipErrorOutOfMemory ? SC_ERR_OOM : SC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
                                     hipGetErrorString(e_), __FILE__, __LINE__);                                          \
+        }                                                                                                                \
     } while (0)
 
 struct DevBuf { // device scratch for the lifetime of one API call: one arena (hipFree is synchronous and slow: ~20 separate

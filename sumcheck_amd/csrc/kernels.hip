@@ -582,6 +582,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
         }
         fr_store(row + 2 * ((uint64_t)t * gridDim.x), acc);
     }
+    __syncthreads(); // (a block that walks several products -- the experiments build's k_round_tree -- reuses the LDS at once)
 #else
 #pragma unroll
     for (int t = 0; t <= M; ++t) {

@@ -741,6 +741,50 @@ def test_interactive_rounds_resident_kernel(nv, nt, shapes):
     st2.close()
 
 
+def test_out_of_memory_is_a_status_code_and_a_resident_kernel_does_not_block_other_provers():
+    """(1) A handle whose bound-table buffers cannot be allocated (ten tables of 2^34 entries: 4.6 TB) is refused with SC_ERR_OOM, nothing
+    crashes, the next call works.  (2) While one handle's resident kernel (interactive protocol) holds the device's tail slot waiting for
+    its verifier, another handle proves whole proofs: its late rounds take the pipelined launches instead of waiting for the slot, and
+    both get the oracle's bits."""
+    import torch
+    nv_big, U = 34, 10
+    dummy = torch.zeros((16, 4), dtype=torch.int64, device="cuda:0")  # never dereferenced: a borrowing init only allocates
+    tabs = (C.c_void_p * U)(*[dummy.data_ptr()] * U)
+    coeffs = np.ascontiguousarray(cref.synth_table(1, 1000, 1))
+    offs, idx = np.asarray([0, 2], dtype=np.uint32), np.asarray([0, 1], dtype=np.uint32)
+    d = _lib.PolyDesc()
+    d.num_vars, d.max_multiplicands, d.n_products = nv_big, 2, 1
+    d.coeffs = coeffs.ctypes.data_as(C.POINTER(C.c_uint64))
+    d.prod_offsets = offs.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.prod_indices = idx.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.n_tables = U
+    d.tables = C.cast(tabs, C.POINTER(C.c_void_p))
+    d.flags = _lib.SC_TABLES_ON_DEVICE | _lib.SC_TABLES_BORROW
+    h = C.c_void_p()
+    assert sc.lib().sc_prover_init(C.byref(d), C.byref(h)) == _lib.SC_ERR_OOM and not h.value
+    nv, nt, shapes = 13, 4, [[0, 1, 2], [3, 3]]
+    tabs = [cref.synth_table(7400, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(7400, 1000, len(shapes))
+    dd = H.desc_from(nv, shapes, tabs, coefs)
+    want, _ = cref.ml_prove(dd, threads=4)
+    chal = cref.synth_table(7400, 2000, nv)
+    op = cref.Prover(dd, threads=4)
+    poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device="cuda:0")
+    a = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+    _lib.check(sc.lib().sc_prover_set_resident(a._h, 1 << 20))  # a patient resident kernel: it holds the slot throughout
+    b = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+    v = None
+    for i in range(nv):
+        got = sc.IPForMLSumcheck.prove_round(a, v).evaluations
+        assert np.array_equal(got, op.prove_round(None if v is None else v.randomness)), i
+        v = sc.VerifierMsg(chal[i])
+        if i >= 2:  # a's kernel is resident from its first late round on
+            b.reset()
+            assert np.array_equal(b.prove(sc.Blake2b512Rng.setup()), want), i
+    a.close()
+    b.close()
+
+
 def test_provers_on_several_threads_share_one_gpu():
     """Three host threads, one GPU: two whole-proof provers (pipelined late rounds + persistent tail kernel) and a GKR prover,
     each repeating its proof.  The library serialises its HIP calls per device (api.hip: DeviceGate) so that a kernel waiting
