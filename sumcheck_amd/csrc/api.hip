@@ -196,6 +196,10 @@ struct sc_prover {
     FinProd *d_finprods = nullptr;
     FrHost *d_W = nullptr; // node -> message matrices of every product (see FinProd::w_off)
     FrHost *d_scratch = nullptr;
+    // the multi-block finalize's node sums of the last two rounds (K * D each, round & 1 selects): a big binding round whose predecessor's
+    // sums are here leaves node 1 to the claim identity (kernels.h: ClaimArgs).  sums_round: the round whose complete sums are held, or -1
+    FrHost *d_sums[2] = {nullptr, nullptr};
+    int64_t sums_round = -1;
     FrHost *d_out = nullptr;
     FrHost *h_out = nullptr;      // pinned, host-mapped: k_finalize writes the message here directly
     uint32_t *h_flag = nullptr;   // pinned, host-mapped sequence flag raised by k_finalize
@@ -292,6 +296,7 @@ static void prover_destroy(sc_prover *p) {
     if (p->d_finprods) (void)hipFree(p->d_finprods);
     if (p->d_W) (void)hipFree(p->d_W);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
+    if (p->d_sums[0]) (void)hipFree(p->d_sums[0]);
     if (p->d_out) (void)hipFree(p->d_out);
     if (p->h_out) (void)hipHostFree(p->h_out);
     if (p->h_flag) (void)hipHostFree(p->h_flag);
@@ -385,6 +390,48 @@ static void build_node_matrix(uint32_t M, uint32_t D, const sch::Fr &scale, std:
         }
         if (inf_col >= 0) out[(size_t)t * (M + 1) + inf_col] = sch::mul(scale, inf_w);
     }
+}
+
+// The weights of a degree-M polynomial's values at the kernel nodes (0, 1, inf, -1, 2) in its value at an arbitrary point r:
+// lam[s] for s = 0..M, M <= 4.  The denominators' inverses are computed once; a call is ~20 field products (it runs on the host while
+// the round kernel runs on the device).
+static void claim_weights(uint32_t M, const sch::Fr &r, sch::Fr *lam) {
+    struct Den {
+        sch::Fr inv[5][5]; // inv[M][s]: 1 / prod_{j != s, finite}(x_s - x_j)
+        Den() {
+            for (uint32_t m = 1; m <= 4; ++m)
+                for (uint32_t s = 0; s <= m; ++s) {
+                    inv[m][s] = sch::zero();
+                    if (scd::node_value((int)s) == scd::kNodeInf) continue;
+                    sch::Fr den = sch::kOne;
+                    for (uint32_t j = 0; j <= m; ++j)
+                        if (j != s && scd::node_value((int)j) != scd::kNodeInf) den = sch::mul(den, fr_small((int64_t)scd::node_value((int)s) - scd::node_value((int)j)));
+                    inv[m][s] = sch::inverse(den);
+                }
+        }
+    };
+    static const Den den;
+    sch::Fr diff[5]; // r - x_j
+    for (uint32_t j = 0; j <= M; ++j)
+        if (scd::node_value((int)j) != scd::kNodeInf) diff[j] = sch::sub(r, fr_small(scd::node_value((int)j)));
+    sch::Fr inf_w = sch::kOne; // r^M - sum_s x_s^M l_s(r)
+    for (uint32_t e = 0; e < M; ++e) inf_w = sch::mul(inf_w, r);
+    int inf_col = -1;
+    for (uint32_t s = 0; s <= M; ++s) {
+        const int32_t xs = scd::node_value((int)s);
+        if (xs == scd::kNodeInf) {
+            inf_col = (int)s;
+            continue;
+        }
+        sch::Fr l = den.inv[M][s];
+        for (uint32_t j = 0; j <= M; ++j)
+            if (j != s && scd::node_value((int)j) != scd::kNodeInf) l = sch::mul(l, diff[j]);
+        lam[s] = l;
+        sch::Fr xm = sch::kOne;
+        for (uint32_t e = 0; e < M; ++e) xm = sch::mul(xm, fr_small(xs));
+        inf_w = sch::sub(inf_w, sch::mul(xm, l));
+    }
+    if (inf_col >= 0) lam[inf_col] = inf_w;
 }
 
 static int prover_build(const sc_poly_desc *d, sc_prover *p) {
@@ -549,6 +596,11 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
     HIP_TRY(hipMalloc(&p->d_W, std::max<size_t>(Wall.size(), 1) * 32));
     if (!Wall.empty()) HIP_TRY(hipMemcpyAsync(p->d_W, Wall.data(), Wall.size() * 32, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipMalloc(&p->d_scratch, (size_t)(2 + p->D) * std::max<uint32_t>(p->K, 1) * p->D * 32));
+    {
+        const size_t one = (size_t)std::max<uint32_t>(p->K, 1) * p->D * 32;
+        HIP_TRY(hipMalloc(&p->d_sums[0], 2 * one));
+        p->d_sums[1] = reinterpret_cast<FrHost *>(reinterpret_cast<char *>(p->d_sums[0]) + one);
+    }
     HIP_TRY(hipMalloc(&p->d_out, (size_t)p->D * 32));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_out), (size_t)p->D * 32, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_flag), 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -741,6 +793,17 @@ static bool ensure_mailbox(sc_prover *p) {
 }
 // Pipelined late rounds.  can_defer_next: the NEXT round is a latency-bound one and the mailbox machinery is available.
 // SC_FIN_MB=0 (experiments build): the single-block finalize
+// node 1 from the claim identity in the big binding rounds (kernels.h: ClaimArgs); -DSC_NO_SKIP1: A/B build without it
+static bool skip1_enabled() {
+#ifdef SC_NO_SKIP1
+    return false;
+#elif defined(SC_EXPERIMENTS)
+    static const bool on = !(std::getenv("SC_SKIP1") && std::atoi(std::getenv("SC_SKIP1")) == 0);
+    return on;
+#else
+    return true;
+#endif
+}
 static bool fin_mb_enabled() {
 #ifdef SC_EXPERIMENTS
     static const bool on = !(std::getenv("SC_FIN_MB") && std::atoi(std::getenv("SC_FIN_MB")) == 0);
@@ -1081,6 +1144,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     std::vector<uint8_t> bound(p->U, 0);
     bool ptrs_uploaded = false;
     bool finalized = false; // the merged big-round launch also produced the message
+    bool skip1 = false;     // the round kernel leaves node 1 out (ClaimArgs)
     const bool merged = !small && p->merge_rounds && !p->any_generic;
     if (merged) {
         grid = std::min(grid, scd::kRoundTreeGrid);
@@ -1096,6 +1160,9 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
 #endif
         if (p->K == 1) split_grid = std::min(split_grid, scd::kRoundTreeGrid); // (one product: one full wave of resident blocks, as before)
         if (split) grid = std::min(scd::grid_for_pairs(n_pairs), split_grid);
+        // the previous round's complete node sums are on the device and this round's will be: node 1 comes from the claim identity
+        skip1 = bind && split && p->sums_round == (int64_t)p->round - 1 && skip1_enabled() &&
+                scd::finalize_keeps_sums((int)p->K, (int)p->D, grid, !p->h_finprods.empty(), fin_mb_enabled());
         // One launch for the round.  The first factor touching a table binds and stores it (mode 1); every later factor on
         // that table -- in the same or in another product -- re-binds from the old buffer without storing (mode 3), so no
         // product reads what another one writes in this launch.
@@ -1153,7 +1220,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         ra.fin.h_flag = publish_to_host ? p->h_flag_dev : nullptr;
         ra.fin.seq = p->seq;
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[0], p->stream));
-        HIP_TRY(scd::launch_round_tree(ra, rc, n_pairs, p->d_partials, grid, p->stream, split));
+        HIP_TRY(scd::launch_round_tree(ra, rc, n_pairs, p->d_partials, grid, p->stream, split, skip1));
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[1], p->stream));
         scaled = 1;
         if (p->fused_finalize) finalized = true;
@@ -1253,10 +1320,30 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
     }
     if (!finalized) {
     p->seq += 1;
+    // the multi-block form leaves the round's node sums behind: kept per round parity for the next round's claims (tree rounds only:
+    // their sums all carry the same scaling)
+    const bool keeps = scd::finalize_keeps_sums((int)p->K, (int)p->D, grid, !p->h_finprods.empty(), fin_mb_enabled());
+    scd::ClaimArgs ca;
+    std::memset(&ca, 0, sizeof(ca));
+    if (skip1) {
+        ca.skip1 = 1;
+        ca.prev = reinterpret_cast<const uint4 *>(p->d_sums[(p->round - 1) & 1]);
+        bool done[5] = {false, false, false, false, false};
+        for (uint32_t k = 0; k < p->K; ++k) {
+            const uint32_t M = p->prods[k].M;
+            if (done[M]) continue;
+            done[M] = true;
+            sch::Fr lam[5];
+            claim_weights(M, r, lam);
+            for (uint32_t s2 = 0; s2 <= M; ++s2) ca.lam[scd::claim_off((int)M) + (int)s2] = to_dev(lam[s2]);
+        }
+    }
     SlowCallProbe pr_fin("launch k_finalize");
-    HIP_TRY(scd::launch_finalize(p->d_finprods, p->h_finprods.empty() ? nullptr : p->h_finprods.data(), p->d_W, (int)p->K, (int)p->D, grid, p->d_partials, p->d_scratch, p->d_out, d_wide,
+    HIP_TRY(scd::launch_finalize(p->d_finprods, p->h_finprods.empty() ? nullptr : p->h_finprods.data(), p->d_W, (int)p->K, (int)p->D, grid, p->d_partials,
+                                 keeps ? p->d_sums[p->round & 1] : p->d_scratch, p->d_out, d_wide,
                                  publish_to_host ? p->h_out_dev : nullptr, publish_to_host ? p->h_flag_dev : nullptr, p->seq, scaled,
-                                 fin_mb_enabled() ? p->d_fin_mb_counter : nullptr, p->stream));
+                                 fin_mb_enabled() ? p->d_fin_mb_counter : nullptr, p->stream, skip1 ? &ca : nullptr));
+    p->sums_round = keeps && merged ? (int64_t)p->round : -1;
     }
     if (timed) HIP_TRY(hipEventRecord(p->ev1, p->stream));
     if (!deferred) { // (a pipelined round leaves the previous round's pending event pairs to the next collect_timing)
@@ -1881,6 +1968,7 @@ extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_nu
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
     p->round = 0;
+    p->sums_round = -1;
     p->exhausted = false;
     p->randomness.clear();
     return SC_OK;

@@ -189,7 +189,9 @@ hipError_t launch_prod_tree(int M, const ProdArgs &args, const BindConst &rc, ui
 // all products of a round in one launch (see RoundArgs); d_partials is the base of the partial-sum array
 // one product per block row: grid x n_prod blocks, `grid` partial blocks per product.  (split = false, experiments build only: the
 // previous kernels, every block walking all products)
-hipError_t launch_round_tree(const RoundArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream, bool split = true);
+// skip1: node 1 of every product is left out (binding rounds only); the round's finalize launch must then carry ClaimArgs
+hipError_t launch_round_tree(const RoundArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream, bool split = true,
+                             bool skip1 = false);
 #ifdef SC_EXPERIMENTS // tiled variant (LDS-staged, one wavefront per node): grid from grid_for_tiles, same partial layout and scaling as _fe
 int grid_for_tiles(uint64_t n_pairs);
 hipError_t launch_round_tile(int M, const ProdArgs &args, const FrHost &r32, uint64_t n_pairs, FrHost *d_partials, int grid,
@@ -214,10 +216,24 @@ hipError_t launch_sum_combos(const TablePtrs &tp, const Combo *d_combos, int n_c
 hipError_t launch_sum_combos_meta(const TablePtrs &tp, const ComboMeta &meta, int n_combos, uint64_t n_pairs, FrHost *d_partials, int grid,
                                   hipStream_t stream);
 // combine per-block partials of all products into the round polynomial (D evaluations)
+// Node 1 from the previous round.  For every product, S(0) + S(1) of a binding round equals the previous round's polynomial of that
+// product at the challenge just bound (the verifier's check, product by product), so a big round that follows one whose complete node
+// sums are still on the device computes the nodes {0, inf, -1, 2} only: one final Montgomery product less per product and pair.
+// The finalize launch gets the previous sums and the weights lam_s(r) of the node basis at the challenge (host, once per round, while
+// the round kernel runs) and restores S(1) = sum_s lam_s S_prev(s) - S(0) before the message is formed.  Sums of both rounds carry the
+// same 2^(-5(M-1)), so the identity holds between them as stored.
+struct ClaimArgs {
+    uint32_t skip1;    // 1: the round kernel left node 1 out
+    uint32_t pad;
+    const uint4 *prev; // the previous round's K * D node sums (the multi-block finalize's `d_scratch` of that round)
+    FrHost lam[14];    // lam[claim_off(M) + s], s = 0..M, for M = 1..4
+};
+__host__ __device__ constexpr int claim_off(int M) { return (M - 1) * (M + 2) / 2; }
+bool finalize_keeps_sums(int K, int D, int nblocks, bool have_host_prods, bool have_counter);
 // h_prods_or_null: host copy of the records; with at most kMetaProds products they travel as a kernel argument
 hipError_t launch_finalize(const FinProd *d_prods, const FinProd *h_prods_or_null, const FrHost *d_W, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
                            FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
-                           int scaled, uint32_t *d_counter_or_null, hipStream_t stream);
+                           int scaled, uint32_t *d_counter_or_null, hipStream_t stream, const ClaimArgs *claim_or_null = nullptr);
 // (d_counter_or_null: one zeroed device word owned by the caller selects the multi-block form, which needs d_scratch for K * D sums
 // and leaves the word at zero)
 hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);

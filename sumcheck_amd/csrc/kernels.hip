@@ -320,11 +320,14 @@ struct LoadFactor {
 };
 
 // one product's pass of a block over its share of the pairs: row = this block's M+1 partial sums of that product
-template <int M, bool kR1 = false, bool kChain = kChainDefault>
+// kSkip1: node 1's sum is not computed -- the finalize step derives it from the previous round (S(0) + S(1) = that round's
+// polynomial at the challenge, product by product: ClaimArgs in kernels.h); binding rounds only
+template <int M, bool kR1 = false, bool kChain = kChainDefault, bool kSkip1 = false>
 __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBindLds], const uint64_t n_pairs, uint4 *__restrict__ row, uint32_t (*sm)[8],
                                           int32_t *lacc) {
     // The M+1 running sums live in LDS (limb-planar, one column per thread: lacc[(9 t + limb) * kBlock + tid], conflict-free and
     // private to the thread, so no barrier): 45 VGPRs less for M = 4, one more resident block per CU.
+    static_assert(!(kSkip1 && kR1), "round 1 has no previous round to take node 1 from");
     int32_t *my = lacc + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 9 * (M + 1); ++i) my[i * kBlock] = 0;
@@ -397,7 +400,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
                 // q(2) = 2 q(1) + 2 q(inf) - q(0), re-tightened for the shared reduction -- so that those products see eight live
                 // elements instead of twelve coefficients plus four temporaries (the 136 bytes of scratch per lane this path used to need).
                 accumulate(0, fe_mul2_sum<kChain>(a0, b0, c0, d0));
-                accumulate(1, fe_mul2_sum<kChain>(a1, b1, c1, d1));
+                if constexpr (!kSkip1) accumulate(1, fe_mul2_sum<kChain>(a1, b1, c1, d1));
                 accumulate(2, fe_mul2_sum<kChain>(ai, bi, ci, di));
                 auto extend = [](Fe &q0, Fe &q1, const Fe &qi) { // (q0, q1) <- (q(-1), q(2))
                     const Fe t = fe_add(qi, qi);
@@ -422,7 +425,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
                 LoadFactor<0, kR1, kChain>::run(S, b2, r, m0, k0);
                 LoadFactor<1, kR1, kChain>::run(S, b2, r, m1, k1);
                 P[0] = fe_mul2_sum<kChain>(l0, l1, m0, m1);
-                P[1] = fe_mul2_sum<kChain>(h0, h1, k0, k1);
+                if constexpr (!kSkip1) P[1] = fe_mul2_sum<kChain>(h0, h1, k0, k1);
                 P[2] = fe_mul2_sum<kChain>(fe_sub(h0, l0), fe_sub(h1, l1), fe_sub(k0, m0), fe_sub(k1, m1));
             } else {
                 Fe q0, q1, qi, l2, h2;
@@ -448,7 +451,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
                 fe_pin3(s0, s1, si);
                 LoadFactor<2, kR1, kChain>::run(S, b2, r, m2, k2);
                 P[0] = fe_mul2_sum<kChain>(l2, q0, m2, s0);
-                P[1] = fe_mul2_sum<kChain>(h2, q1, k2, s1);
+                if constexpr (!kSkip1) P[1] = fe_mul2_sum<kChain>(h2, q1, k2, s1);
                 P[2] = fe_mul2_sum<kChain>(fe_sub(h2, l2), qi, fe_sub(k2, m2), si);
                 // node -1: f2(-1) = 2 lo - hi (re-tightened: the shared reduction needs both operands within 2^29), q(-1) = 2 q(0) + 2 q(inf) - q(1)
                 const Fe qm1 = fe_carry_pass(fe_sub(fe_add(fe_add(qi, qi), fe_add(q0, q0)), q1));
@@ -457,6 +460,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
             }
 #pragma unroll
             for (int t = 0; t <= M; ++t) {
+                if (kSkip1 && t == 1) continue;
                 Fe a;
 #pragma unroll
                 for (int l = 0; l < 9; ++l) a.l[l] = my[(9 * t + l) * kBlock];
@@ -479,7 +483,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
             LoadFactor<0, kR1, kChain>::run(S, b, r, l0, h0);
             LoadFactor<1, kR1, kChain>::run(S, b, r, l1, h1);
             P[0] = fe_mul<kChain>(l0, l1);
-            P[1] = fe_mul<kChain>(h0, h1);
+            if constexpr (!kSkip1) P[1] = fe_mul<kChain>(h0, h1);
             P[2] = fe_mul<kChain>(fe_sub(h0, l0), fe_sub(h1, l1));
         } else if constexpr (M == 3) {
             Fe q0, q1, qi;
@@ -496,7 +500,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
             Fe l2, h2;
             LoadFactor<2, kR1, kChain>::run(S, b, r, l2, h2);
             P[0] = fe_mul<kChain>(l2, q0);
-            P[1] = fe_mul<kChain>(h2, q1);
+            if constexpr (!kSkip1) P[1] = fe_mul<kChain>(h2, q1);
             P[2] = fe_mul<kChain>(fe_sub(h2, l2), qi);
             P[3] = fe_mul<kChain>(fe_sub(fe_add(l2, l2), h2), qm1); // f2(-1) = 2 lo - hi
         } else {
@@ -522,13 +526,14 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
             // a quadratic from its values at 0, 1 and its leading coefficient: q(-1) = 2 q(0) + 2 q(inf) - q(1), q(2) = 2 q(1) + 2 q(inf) - q(0)
             const Fe a2i = fe_add(ai, ai), b2i = fe_add(bi, bi);
             P[0] = fe_mul<kChain>(a0, b0);
-            P[1] = fe_mul<kChain>(a1, b1);
+            if constexpr (!kSkip1) P[1] = fe_mul<kChain>(a1, b1);
             P[2] = fe_mul<kChain>(ai, bi);
             P[3] = fe_mul<kChain>(fe_carry_pass(fe_sub(fe_add(a2i, fe_add(a0, a0)), a1)), fe_carry_pass(fe_sub(fe_add(b2i, fe_add(b0, b0)), b1)));
             P[4] = fe_mul<kChain>(fe_carry_pass(fe_sub(fe_add(a2i, fe_add(a1, a1)), a0)), fe_carry_pass(fe_sub(fe_add(b2i, fe_add(b1, b1)), b0)));
         }
 #pragma unroll
         for (int t = 0; t <= M; ++t) {
+            if (kSkip1 && t == 1) continue;
             Fe a;
 #pragma unroll
             for (int l = 0; l < 9; ++l) a.l[l] = my[(9 * t + l) * kBlock];
@@ -549,6 +554,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
     Fr s[M + 1];
 #pragma unroll
     for (int t = 0; t <= M; ++t) {
+        if (kSkip1 && t == 1) { s[t] = fr_zero(); continue; }
         Fe a;
 #pragma unroll
         for (int l = 0; l < 9; ++l) a.l[l] = my[(9 * t + l) * kBlock];
@@ -557,7 +563,8 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
-        for (int t = 0; t <= M; ++t) s[t] = fr_add(s[t], fr_shfl_down(s[t], off));
+        for (int t = 0; t <= M; ++t)
+            if (!(kSkip1 && t == 1)) s[t] = fr_add(s[t], fr_shfl_down(s[t], off));
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *x = reinterpret_cast<uint32_t *>(lacc); // [wave][node][8]
@@ -569,7 +576,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
             for (int i = 0; i < 8; ++i) x[(wave * (M + 1) + t) * 8 + i] = s[t].v[i];
     }
     __syncthreads();
-    if (threadIdx.x <= (uint32_t)M) {
+    if (threadIdx.x <= (uint32_t)M && !(kSkip1 && threadIdx.x == 1)) { // (node 1's row of the partials is left alone: nothing reads it)
         const int t = threadIdx.x;
         Fr acc;
 #pragma unroll
@@ -586,6 +593,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
 #else
 #pragma unroll
     for (int t = 0; t <= M; ++t) {
+        if (kSkip1 && t == 1) continue;
         Fe a;
 #pragma unroll
         for (int l = 0; l < 9; ++l) a.l[l] = my[(9 * t + l) * kBlock];
@@ -1236,7 +1244,7 @@ constexpr int kFinMbBlock = 256;
 __global__ __launch_bounds__(kFinMbBlock) void k_finalize_mb(const FinMeta meta, const uint4 *__restrict__ Wm, const int K, const int D, const int nblocks,
                                                              const uint4 *__restrict__ partials, uint4 *__restrict__ sums, uint32_t *__restrict__ counter,
                                                              uint4 *__restrict__ out, uint64_t *__restrict__ out_wide, uint4 *__restrict__ h_out,
-                                                             uint32_t *__restrict__ h_flag, const uint32_t seq, const int scaled) {
+                                                             uint32_t *__restrict__ h_flag, const uint32_t seq, const int scaled, const ClaimArgs C) {
     extern __shared__ uint4 fin_lds[];
     auto prod_of = [&](int k) -> FinProd { return meta.prod[k]; };
     if (gridDim.x == 1) {
@@ -1258,7 +1266,15 @@ __global__ __launch_bounds__(kFinMbBlock) void k_finalize_mb(const FinMeta meta,
     const uint4 *base = partials + 2 * (meta.prod[k].partial_off + (uint64_t)t * nblocks);
     Fr acc = fr_zero();
     constexpr int kLoads = 3; // 768 partials = one batch
-    for (int b0 = threadIdx.x; b0 < nblocks; b0 += kFinMbBlock * kLoads) {
+    // C.skip1: the round kernel left node 1 out.  This block's "sum" is then the product's CLAIM, the previous round's polynomial at
+    // the challenge = sum_s lam_s(r) S_prev[s] (host-computed weights, one product per lane; the shuffles below add them up), and the
+    // block that finishes the message turns it into S[1] = claim - S[0].
+    const bool claim_block = C.skip1 && t == 1;
+    if (claim_block) {
+        const int M = (int)meta.prod[k].M;
+        if ((int)threadIdx.x <= M) acc = fr_mul(fr_from_host(C.lam[claim_off(M) + (int)threadIdx.x]), fr_load(C.prev + 2 * (k * D + (int)threadIdx.x)));
+    }
+    for (int b0 = threadIdx.x; b0 < (claim_block ? 0 : nblocks); b0 += kFinMbBlock * kLoads) {
         Fr x[kLoads];
 #pragma unroll
         for (int j = 0; j < kLoads; ++j) {
@@ -1284,8 +1300,12 @@ __global__ __launch_bounds__(kFinMbBlock) void k_finalize_mb(const FinMeta meta,
     if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int c = threadIdx.x; c < K * D; c += kFinMbBlock) {
         if (c % D <= (int)meta.prod[c / D].M) {
-            fin_lds[2 * c] = sums[2 * c];
-            fin_lds[2 * c + 1] = sums[2 * c + 1];
+            Fr v = fr_load(sums + 2 * c);
+            if (C.skip1 && c % D == 1) { // claim -> node 1's sum; `sums` keeps the complete set for the next round's claims
+                v = fr_sub(v, fr_load(sums + 2 * (c - 1)));
+                fr_store(sums + 2 * c, v);
+            }
+            fr_store(fin_lds + 2 * c, v);
         }
     }
     __syncthreads();
@@ -1405,7 +1425,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_round1_tree_split(const RoundArgs
     }
 }
 // kChain: single-chain multiply-adds (fe_device.hpp) -- the instantiation for a proof's first binding round, whose sources are canonical
-template <bool kChain>
+template <bool kChain, bool kSkip1>
 __global__ __launch_bounds__(kBlock, 3) void k_round_tree_split(const RoundArgs R, const BindConst r, const uint64_t n_pairs, uint4 *__restrict__ partials) {
     __shared__ uint32_t sm[kBlock / 64][8];
     __shared__ int32_t rt[kBindLds];
@@ -1414,10 +1434,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_round_tree_split(const RoundArgs 
     const TreeProd &T = R.prod[blockIdx.y];
     uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x);
     switch (T.M) {
-    case 1: tree_pass<1, false, kChain>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    case 2: tree_pass<2, false, kChain>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    case 3: tree_pass<3, false, kChain>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    default: tree_pass<4, false, kChain>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 1: tree_pass<1, false, kChain, kSkip1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 2: tree_pass<2, false, kChain, kSkip1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 3: tree_pass<3, false, kChain, kSkip1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    default: tree_pass<4, false, kChain, kSkip1>(T.slot, rt, n_pairs, row, sm, lacc); break;
     }
 }
 
@@ -1934,7 +1954,8 @@ hipError_t launch_prod_tree(int M, const ProdArgs &args, const BindConst &r32, u
     }
 }
 
-hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream, bool split) {
+hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream, bool split,
+                             bool skip1) {
     size_t extra_lds = 0;
 #ifdef SC_EXPERIMENTS // SC_EXTRA_LDS: unused dynamic LDS per block, to lower the number of resident blocks per CU (occupancy experiments)
     static const size_t env_lds = [] {
@@ -1948,6 +1969,7 @@ hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64
         for (uint32_t f = 0; f < args.prod[q].M; ++f) round1 = round1 && args.prod[q].slot[f].mode == 0 && args.prod[q].slot[f].src_top == nullptr;
 #ifdef SC_EXPERIMENTS
     if (!split) {
+        if (skip1) return hipErrorInvalidValue;
         if (round1 && extra_lds == 0) hipLaunchKernelGGL(k_round1_tree, dim3(grid), dim3(kBlock), 0, stream, args, n_pairs, (uint4 *)d_partials);
         else hipLaunchKernelGGL(k_round_tree, dim3(grid), dim3(kBlock), extra_lds, stream, args, r32, n_pairs, (uint4 *)d_partials);
         return hipGetLastError();
@@ -1964,9 +1986,18 @@ hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64
 #endif
     for (int q = 0; q < args.n_prod && canonical_sources; ++q)
         for (uint32_t f = 0; f < args.prod[q].M; ++f) canonical_sources = canonical_sources && args.prod[q].slot[f].src_top == nullptr;
-    if (round1) hipLaunchKernelGGL(k_round1_tree_split, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, n_pairs, (uint4 *)d_partials);
-    else if (canonical_sources) hipLaunchKernelGGL(k_round_tree_split<true>, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
-    else hipLaunchKernelGGL(k_round_tree_split<kChainDefault>, dim3(grid, args.n_prod), dim3(kBlock), 0, stream, args, r32, n_pairs, (uint4 *)d_partials);
+    const dim3 g(grid, args.n_prod), b(kBlock);
+    uint4 *const part = (uint4 *)d_partials;
+    if (round1) {
+        if (skip1) return hipErrorInvalidValue; // (round 1 has no previous round)
+        hipLaunchKernelGGL(k_round1_tree_split, g, b, 0, stream, args, n_pairs, part);
+    } else if (canonical_sources) {
+        if (skip1) hipLaunchKernelGGL((k_round_tree_split<true, true>), g, b, 0, stream, args, r32, n_pairs, part);
+        else hipLaunchKernelGGL((k_round_tree_split<true, false>), g, b, 0, stream, args, r32, n_pairs, part);
+    } else {
+        if (skip1) hipLaunchKernelGGL((k_round_tree_split<kChainDefault, true>), g, b, 0, stream, args, r32, n_pairs, part);
+        else hipLaunchKernelGGL((k_round_tree_split<kChainDefault, false>), g, b, 0, stream, args, r32, n_pairs, part);
+    }
     return hipGetLastError();
 }
 
@@ -2034,10 +2065,19 @@ hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t 
     return hipGetLastError();
 }
 
+// the multi-block form with more than one block: every (product, node) sum of the round is left in d_scratch
+bool finalize_keeps_sums(int K, int D, int nblocks, bool have_host_prods, bool have_counter) {
+    return (size_t)K * D * (D + 2) * 32 <= kFinLdsMax && have_host_prods && K <= kMetaProds && have_counter && nblocks > 8;
+}
+
 hipError_t launch_finalize(const FinProd *d_prods, const FinProd *h_prods_or_null, const FrHost *d_W, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
                            FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
-                           int scaled, uint32_t *d_counter_or_null, hipStream_t stream) {
+                           int scaled, uint32_t *d_counter_or_null, hipStream_t stream, const ClaimArgs *claim_or_null) {
     const size_t lds = (size_t)K * D * (D + 2) * 32;
+    ClaimArgs claim;
+    std::memset(&claim, 0, sizeof(claim));
+    if (claim_or_null) claim = *claim_or_null;
+    if (claim.skip1 && !finalize_keeps_sums(K, D, nblocks, h_prods_or_null != nullptr, d_counter_or_null != nullptr)) return hipErrorInvalidValue;
     FinMeta meta;
     std::memset(&meta, 0, sizeof(meta));
     const bool use_meta = h_prods_or_null && K <= kMetaProds;
@@ -2047,7 +2087,7 @@ hipError_t launch_finalize(const FinProd *d_prods, const FinProd *h_prods_or_nul
         for (int k = 0; k < K; ++k) n_valid += std::min<int>((int)meta.prod[k].M, D - 1) + 1;
         hipLaunchKernelGGL(k_finalize_mb, dim3(nblocks <= 8 ? 1 : n_valid), dim3(kFinMbBlock), lds, stream, meta, (const uint4 *)d_W, K, D, nblocks,
                            (const uint4 *)d_partials, (uint4 *)d_scratch, d_counter_or_null, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped,
-                           h_flag_mapped, seq, scaled);
+                           h_flag_mapped, seq, scaled, claim);
     } else if (lds <= kFinLdsMax && use_meta)
         hipLaunchKernelGGL((k_finalize<true, true>), dim3(1), dim3(kFinBlock), lds, stream, d_prods, meta, (const uint4 *)d_W, K, D, nblocks,
                            (const uint4 *)d_partials, (uint4 *)d_scratch, (uint4 *)d_out, d_out_wide, (uint4 *)h_out_mapped, h_flag_mapped, seq,

@@ -138,6 +138,11 @@ SHAPES = [
     (17, 3, [[0, 1, 2]]),                                                        # several grid-stride iterations
     (3, 2, [[0], [1], [0, 1]]),
     (9, 36, [[3 * i, 3 * i + 1, 3 * i + 2] for i in range(11)] + [[33, 34], [35]]),  # > 32 tables: no small-round kernels
+    # several big binding rounds in a row with every product length 1..4 and repeated tables: node 1 of those rounds comes from the
+    # previous round's sums (claim identity), compared with the oracle message by message
+    (16, 7, [[0, 1, 2, 3], [4, 5, 6], [1, 1], [2], [3, 3, 3], [5, 6, 6, 0]]),
+    (15, 2, [[0], [1]]),
+    (18, 4, [[0, 1], [2, 3], [0, 3]]),
 ]
 
 
