@@ -337,6 +337,10 @@ SC_API int sc_prover_get_timing(sc_prover *p, double *ms_per_product, uint64_t *
  * tables_or_null = new device pointers, or NULL for the same tables.  Copying handle: tables are required and
  * copied in again (device pointers iff flags has SC_TABLES_ON_DEVICE). */
 SC_API int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_null, uint32_t flags);
+/* Host logic of the claim identity, exposed for tests: out[s], s = 0..M, are the weights of a degree-M polynomial's
+ * values at the kernel nodes 0, 1, inf (= leading coefficient), -1, 2 in its value at the point r, i.e.
+ * f(r) = sum_s out[s] * f(node_s).  1 <= M <= 4; r canonical Montgomery limbs; no device needed. */
+SC_API int sc_claim_weights(uint32_t M, const uint64_t *r, uint64_t *out);
 /* Elementwise field arithmetic on host arrays of n elements, computed on the GPU (arithmetic parity tests):
  * op 0 mul (production path) | 1 add | 2 sub | 3 mul, plain-C++ CIOS | 4 mul, Comba asm | 5 a[i] * b[0] with b[0] uniform. */
 SC_API int sc_fr_elementwise(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n);

@@ -105,6 +105,7 @@ SIGNATURES = {
     "sc_prover_set_timing": (C.c_int, [_V, C.c_int]),
     "sc_prover_get_timing": (C.c_int, [_V, C.POINTER(C.c_double), u64p, C.POINTER(C.c_double)]),
     "sc_prover_reset": (C.c_int, [_V, _V, C.c_uint32]),
+    "sc_claim_weights": (C.c_int, [C.c_uint32, _V, _V]),
     "sc_fr_elementwise": (C.c_int, [C.c_int, _V, _V, _V, C.c_uint64]),
     "sc_bench_modmul": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), u64p]),
 }

@@ -3237,6 +3237,17 @@ extern "C" int sc_synth_table_device(uint64_t seed, uint64_t stream, uint64_t fi
     return SC_OK;
 }
 
+extern "C" int sc_claim_weights(uint32_t M, const uint64_t *r, uint64_t *out) {
+    if (!r || !out) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (M < 1 || M > 4) return fail(SC_ERR_BAD_ARG, "claim weights exist for 1..4 multiplicands, not %u", M);
+    sch::Fr rr, lam[5];
+    std::memcpy(&rr, r, 32);
+    if (sch::geq_p(rr)) return fail(SC_ERR_BAD_ARG, "the point is not a canonical field element");
+    claim_weights(M, rr, lam);
+    std::memcpy(out, lam, (size_t)(M + 1) * 32);
+    return SC_OK;
+}
+
 extern "C" int sc_fr_elementwise(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n) {
     if (!a || !b || !out) return fail(SC_ERR_BAD_ARG, "null argument");
     if (op < 0 || op > 5) return fail(SC_ERR_BAD_ARG, "unknown op %d", op);

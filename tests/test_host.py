@@ -168,6 +168,27 @@ def test_interpolate_uni_poly():
         assert field.to_int(sc.interpolate_uni_poly(field.from_ints(ys), field.from_int(n - 1))) == ys[n - 1]
 
 
+def test_claim_weights_evaluate_a_polynomial_from_its_kernel_nodes():
+    """The host half of the claim identity: f(r) = sum_s lam_s(r) f(node_s) over the kernels' nodes 0, 1, inf, -1, 2 -- what
+    turns the previous round's node sums into this round's S(0) + S(1).  Checked against big-integer evaluation of random polynomials."""
+    rng = np.random.default_rng(11)
+    nodes = [0, 1, None, -1, 2]  # None: the leading coefficient
+    for M in (1, 2, 3, 4):
+        for _ in range(5):
+            coef = [int.from_bytes(rng.bytes(32), "little") % po.P for _ in range(M + 1)]
+            f = lambda x: sum(c * pow(x, i, po.P) for i, c in enumerate(coef)) % po.P
+            vals = [coef[M] if x is None else f(x % po.P) for x in nodes[: M + 1]]
+            for r in (0, 1, po.P - 1, int.from_bytes(rng.bytes(32), "little") % po.P):
+                rr, out = field.from_int(r), np.empty((M + 1, 4), np.uint64)
+                _lib.check(sc.lib().sc_claim_weights(M, C.c_void_p(rr.ctypes.data), C.c_void_p(out.ctypes.data)))
+                lam = field.to_ints(out)
+                assert sum(l * v for l, v in zip(lam, vals)) % po.P == f(r), (M, r)
+    bad = np.full(4, np.uint64(0xFFFFFFFFFFFFFFFF))
+    out = np.empty((5, 4), np.uint64)
+    assert sc.lib().sc_claim_weights(2, C.c_void_p(bad.ctypes.data), C.c_void_p(out.ctypes.data)) == _lib.SC_ERR_BAD_ARG
+    assert sc.lib().sc_claim_weights(5, C.c_void_p(field.from_int(3).ctypes.data), C.c_void_p(out.ctypes.data)) == _lib.SC_ERR_BAD_ARG
+
+
 def test_wide_reduce_folds_integer_allreduce_lanes():
     rng = np.random.default_rng(6)
     for ranks in (1, 2, 8, 1000):
