@@ -170,6 +170,54 @@ def test_random_shapes_vs_oracle(nv, nt, shapes):
     assert np.array_equal(np.stack([m.evaluations for m in proof]), want)
 
 
+def test_claim_identity_rounds_survive_state_export_timing_stream_switch_and_reset():
+    """Node 1 of a big binding round comes from the previous round's sums kept on the device.  Everything a caller may do between
+    two rounds -- read the state, switch timing on, move the handle to another stream, rewind it mid-proof -- must leave every message equal to the
+    oracle's."""
+    import torch
+    nv, shapes, nt = 16, [[0, 1, 2, 3], [4, 5, 6], [1, 1], [2]], 7
+    poly, mles, coefs = _device_poly(nv, shapes, nt, 4242)
+    tabs = [m.evaluations.cpu().numpy().view(np.uint64) for m in mles]
+    d = H.desc_from(nv, shapes, tabs, coefs)
+    chal = cref.synth_table(4242, 2000, nv)
+    op = cref.Prover(d, threads=cref.max_threads())
+    want = []
+    v = None
+    for i in range(nv):
+        want.append(op.prove_round(None if v is None else v))
+        v = chal[i]
+    st = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+    side = torch.cuda.Stream()
+
+    def run(upto, meddle):
+        v = None
+        for i in range(upto):
+            got = sc.IPForMLSumcheck.prove_round(st, v).evaluations
+            assert np.array_equal(got, want[i]), f"round {i + 1}"
+            v = sc.VerifierMsg(chal[i])
+            if meddle and i == 0:
+                assert st.round == 1 and len(st.randomness) == 0
+            if meddle and i == 1:
+                st.set_timing(True)
+                t = st.flattened_ml_extensions  # exports (and converts) the bound tables
+                assert t[0].evaluations.shape[0] == 1 << (nv - 1)
+            if meddle and i == 2:
+                _lib.check(sc.lib().sc_prover_set_stream(st._h, C.c_void_p(side.cuda_stream), 0))
+            if meddle and i == 4:
+                _lib.check(sc.lib().sc_prover_set_stream(st._h, None, 1))
+                st.set_timing(False)
+
+    run(nv, meddle=True)
+    st.reset()
+    run(4, meddle=False)  # abandoned mid-proof, in the middle of the big binding rounds ...
+    st.reset()
+    run(nv, meddle=False)  # ... and the next proof starts from nothing
+    st.reset()
+    proof = st.prove(sc.Blake2b512Rng.setup())
+    wantp, _ = cref.ml_prove(d, threads=cref.max_threads())
+    assert np.array_equal(proof, wantp)
+
+
 def test_state_machine_errors():
     case = H.load("ml_nv3_c1shape.json")
     poly, _ = H.hip_poly(case)
