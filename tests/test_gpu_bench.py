@@ -61,6 +61,11 @@ def test_bench_line_two_ranks_one_gpu():
     d = _two_ranks(["--nv", "16"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["cpu_baseline"] is None
     assert d["config"]["nv"] == 16 and d["config"]["nv_per_gpu"] == 15 and d["config"]["round_loop"].startswith("library")
-    assert "selftest passed" in d["config"]["round_loop_reason"] and d["parity"]["ok"] is None
+    assert "selftest passed" in d["config"]["round_loop_reason"]
+    # no CPU proof at N > 1: the line certifies itself through the verifier and its final oracle query over the sharded tables
+    assert d["parity"]["ok"] is True and d["parity"]["verifier_accepts"] and d["parity"]["oracle_query_matches"], d["parity"]
     d = _two_ranks(["--config", "4", "--nv", "17"])
     assert d["config"]["tables"] == 3 and d["config"]["nv_per_gpu"] == 16 and "config 4" in d["config"]["workload"]
+    assert d["parity"]["ok"] is True, d["parity"]
+    d = _two_ranks(["--nv", "17", "--scaling", "weak"])
+    assert d["parity"]["ok"] is True, d["parity"]
