@@ -1485,7 +1485,7 @@ static int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null
     std::memset(&fm, 0, sizeof(fm));
     std::memcpy(fm.prod, p->h_finprods.data(), (size_t)p->K * sizeof(FinProd));
     grid = 1; // (the kernel's tail_active_blocks for the first round)
-    if (A.first_pairs > (uint64_t)scd::kTailFlatPairs) {
+    if (A.first_pairs > scd::tail_flat_pairs(p->n_combos)) {
         const uint64_t bind_blocks = (2 * A.first_pairs * p->U + scd::kBlock - 1) / scd::kBlock;
         const uint64_t sum_blocks = ((A.first_pairs + scd::kBlock - 1) / scd::kBlock) * (uint64_t)p->n_combos;
         grid = (int)std::min<uint64_t>((uint64_t)p->tail_max_blocks, std::max(bind_blocks, sum_blocks));

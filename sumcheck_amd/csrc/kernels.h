@@ -138,6 +138,13 @@ constexpr uint64_t kTailMaxPairs = 2048; // rounds above this many pairs are thr
 static_assert(kTailMaxPairs / kBlock <= 8, "k_tail_rounds' block 0 adds up a combination's partial blocks itself: at most 8 of them");
 constexpr int kTailMaxGrid = 1024; // at most 4 resident blocks per CU (120 VGPRs), all co-resident on a 256-CU device
 constexpr int kTailFlatPairs = 16; // rounds with at most this many pairs run in block 0 alone, one lane per (combination, pair)
+// ... and with few combinations (one product of two or three multiplicands: the GKR phases, configs 1 and 2) up to 64 pairs do: as long as
+// every (combination, pair) has its own lane of the block and a combination's pairs share a wavefront
+__host__ __device__ constexpr uint64_t tail_flat_pairs(int n_combos) {
+    uint64_t p = kTailFlatPairs;
+    while (p < 64 && 2 * p * (uint64_t)n_combos <= (uint64_t)kBlock) p *= 2;
+    return p;
+}
 struct TailTables {
     const uint4 *cur0[kMaxSmallTables];       // where each table's evaluations are when the tail starts ...
     const int32_t *cur0_top[kMaxSmallTables]; // ... non-null: in the internal F29 format (straight from the big rounds)

@@ -1535,7 +1535,7 @@ __device__ __forceinline__ bool grid_barrier(uint32_t *sync, uint32_t &gen, cons
 
 // blocks a round of `n_pairs` pairs can use: one per 256 bind outputs, and at least one per (combination, 256 pairs) tile
 __device__ __forceinline__ uint32_t tail_active_blocks(const uint64_t n_pairs, const int n_tables, const int n_combos, const uint32_t G) {
-    if (n_pairs <= (uint64_t)kTailFlatPairs) return 1; // one block does the whole round (flat mode below)
+    if (n_pairs <= tail_flat_pairs(n_combos)) return 1; // one block does the whole round (flat mode below)
     const uint64_t bind_blocks = (2 * n_pairs * (uint64_t)n_tables + kBlock - 1) / kBlock;
     const uint64_t sum_blocks = ((n_pairs + kBlock - 1) / kBlock) * (uint64_t)n_combos;
     return (uint32_t)min((uint64_t)G, max(bind_blocks, sum_blocks));
