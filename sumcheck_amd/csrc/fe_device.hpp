@@ -145,13 +145,32 @@ __device__ __forceinline__ Fe fe_carry_pass(const Fe &a) {
 // profiles/r1_mem_bench.txt).  The next round's lane b reads pairs 2b and 2b+1, i.e. for each of them 32 consecutive columns
 // per half-wavefront: every load instruction is two contiguous 512-byte runs.
 // Tables in this format always hold a multiple of 128 entries (big rounds only).
+// Both directions are STREAMED (nontemporal): a big round reads every element of its source tables once and writes every element of its
+// destination tables once, fully coalesced in this layout.  Measured together (profiles/r3y_nontemporal_ab.txt): -2.4 % per proof, rounds 3-6
+// -3...-10 %; the stores alone -1.1 %, the loads alone nothing.  (The caller's canonical tables are NOT read this way: their 16-byte-per-lane
+// loads at a 64 / 128-byte stride live off the L1 hits that the hint gives up -- rounds 1 and 2 were 19 % and 69 % slower.)
+#ifndef SC_NO_NT // (A/B build without the hints)
+typedef uint32_t sc_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 f29_ld(const uint4 *p) {
+    const sc_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const sc_u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void f29_st(uint4 *p, const uint32_t a, const uint32_t b, const uint32_t c, const uint32_t d) {
+    sc_u32x4 w;
+    w.x = a; w.y = b; w.z = c; w.w = d;
+    __builtin_nontemporal_store(w, reinterpret_cast<sc_u32x4 *>(p));
+}
+#else
+__device__ __forceinline__ uint4 f29_ld(const uint4 *p) { return *p; }
+__device__ __forceinline__ void f29_st(uint4 *p, const uint32_t a, const uint32_t b, const uint32_t c, const uint32_t d) { *p = make_uint4(a, b, c, d); }
+#endif
 __device__ __forceinline__ uint64_t f29_chunk(uint64_t entry, int half) { // index in uint4 units
     const uint64_t q = entry >> 1; // pair
     const uint64_t col = ((q & 63) >> 1) | ((q & 1) << 5); // even pairs in columns 0..31, odd pairs in 32..63
     return (entry >> 7) * 256 + (uint64_t)(2 * (int)(entry & 1) + half) * 64 + col;
 }
 __device__ __forceinline__ Fe fe_load_f29(const uint4 *main, uint64_t entry, int32_t top) {
-    const uint4 a = main[f29_chunk(entry, 0)], b = main[f29_chunk(entry, 1)];
+    const uint4 a = f29_ld(main + f29_chunk(entry, 0)), b = f29_ld(main + f29_chunk(entry, 1));
     Fe r;
     r.l[0] = (int32_t)a.x; r.l[1] = (int32_t)a.y; r.l[2] = (int32_t)a.z; r.l[3] = (int32_t)a.w;
     r.l[4] = (int32_t)b.x; r.l[5] = (int32_t)b.y; r.l[6] = (int32_t)b.z; r.l[7] = (int32_t)b.w;
@@ -159,8 +178,8 @@ __device__ __forceinline__ Fe fe_load_f29(const uint4 *main, uint64_t entry, int
     return r;
 }
 __device__ __forceinline__ void fe_store_f29(uint4 *main, uint64_t entry, const Fe &v) {
-    main[f29_chunk(entry, 0)] = make_uint4((uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
-    main[f29_chunk(entry, 1)] = make_uint4((uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
+    f29_st(main + f29_chunk(entry, 0), (uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
+    f29_st(main + f29_chunk(entry, 1), (uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
 }
 // One multiply-add of a column.  kChain: the instruction is written out, so that every multiply-add of a product accumulates into ONE
 // register pair in program order -- the compiler otherwise starts each column's chain from zero and joins it to the carry with a 64-bit
