@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 3 /* 3: sc_prover_set_polling, sc_prover_set_resident, SC_NO_DEVICE_POLLING, sc_set_cache_limit, sc_comm_init_p2p, sc_gkr_prove_sharded (additions only) */
+#define SC_ABI_VERSION 4 /* 4: sc_comm_info, sc_comm_exchange_bench, sc_set_publish_timeout_ms, sc_prover_get_round_timing (additions only); 3: sc_prover_set_polling, sc_prover_set_resident, SC_NO_DEVICE_POLLING, sc_set_cache_limit, sc_comm_init_p2p, sc_gkr_prove_sharded (additions only) */
 #define SC_API __attribute__((visibility("default")))
 
 enum sc_status {
@@ -179,6 +179,8 @@ SC_API int sc_comm_init_host(int rank, int nranks, sc_allreduce_u64_fn allreduce
  *     inbox as self-validating words (posted writes over xGMI), polls its own inbox, adds, and publishes the total to the host --
  *     instead of ncclAllReduce + a publishing kernel; the tail's gather is peer copies.  Ranks may share a GPU (functional tests on
  *     a one-GPU box; rounds are then not pipelined and the exchange kernel is re-launched until its peers' kernels have run).
+ *     LIMITS: at most 16 ranks; round messages of at most 8 evaluations (max_multiplicands <= 7) -- sc_ml_prove_sharded returns
+ *     SC_ERR_BAD_ARG for longer ones before it touches the handle.
  *     THREADS AND RCCL: an RCCL communicator driven by one thread per GPU inside one process must follow RCCL's own rule for that
  *     mode -- one communicator per thread, every thread issuing the same collectives in the same order, no thread holding a lock
  *     another needs while inside a collective.  The library's per-device gate is never held across devices, so distinct-device
@@ -187,6 +189,21 @@ SC_API int sc_comm_init_p2p(uint64_t group_id, int rank, int nranks, sc_comm **o
 /* diagnostic, collective: one all-reduce and one all-gather of known patterns over the communicator, checked on every rank */
 SC_API int sc_comm_selftest(sc_comm *comm);
 SC_API void sc_comm_free(sc_comm *comm);
+/* what the communicator itself knows: this rank, the number of ranks, and its kind (bench.py reports `ranks_seen` from here, not from
+ * its command line) */
+#define SC_COMM_RCCL 1
+#define SC_COMM_HOST 2
+#define SC_COMM_P2P 3
+SC_API int sc_comm_info(sc_comm *comm, int *rank_out, int *nranks_out, int *kind_out);
+/* measurement, collective (every rank calls it): `iters` back-to-back exchanges of n_words (<= 64) uint64 lanes in exactly the form a
+ * sharded round uses on this communicator (RCCL: ncclAllReduce + publishing kernel + the host's poll; peer-to-peer: the one exchange
+ * kernel + poll; host transport: publishing kernel + poll + the caller's all-reduce), each waited for before the next is issued; the
+ * sums are checked.  *us_mean_out / *us_min_out_or_null: this rank's wall time per exchange.  The per-round cost a sharded proof pays
+ * on top of its kernels (the reference's counterpart, the rayon reduce of prover.rs:139-148, is in-process). */
+SC_API int sc_comm_exchange_bench(sc_comm *comm, uint32_t n_words, uint32_t iters, double *us_mean_out, double *us_min_out_or_null);
+/* how long a host loop waits for a round's message or a peer's lanes before it gives the proof up (default 20 000 ms; also
+ * SC_PUBLISH_TIMEOUT_MS in the environment; 0 restores the default).  Process-wide. */
+SC_API int sc_set_publish_timeout_ms(uint32_t ms);
 SC_API int sc_ml_prove_sharded(sc_prover *p, sc_comm *comm, sc_rng *rng_or_null, uint32_t nv_total, uint64_t *out_proof,
                                uint64_t *out_randomness);
 SC_API int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *rng, uint32_t nv_total, uint32_t n_rounds, uint64_t *out_proof,
@@ -333,6 +350,9 @@ SC_API int sc_prover_last_round_ms(sc_prover *p, float *ms);
  * that launch is reported under product 0 and the other products report no launches. */
 SC_API int sc_prover_set_timing(sc_prover *p, int on);
 SC_API int sc_prover_get_timing(sc_prover *p, double *ms_per_product, uint64_t *launches_per_product, double *rounds_ms);
+/* the same per ROUND (num_vars entries, index = round - 1): device time of that round's big-round kernel launch(es) and how many timed
+ * proofs contributed; zero for the latency-bound rounds, which record no events.  bench.py's roofline.per_round. */
+SC_API int sc_prover_get_round_timing(sc_prover *p, double *ms_per_round, uint64_t *launches_per_round);
 /* Rewind a handle to round 0 without reallocating (repeated proofs over resident tables).  Borrowing handle:
  * tables_or_null = new device pointers, or NULL for the same tables.  Copying handle: tables are required and
  * copied in again (device pointers iff flags has SC_TABLES_ON_DEVICE). */

@@ -1,4 +1,4 @@
-//! `extern "C"` binding of `libsumcheck_hip.so` (C ABI: `include/sumcheck_hip.h`, SC_ABI_VERSION 3) exposed with the
+//! `extern "C"` binding of `libsumcheck_hip.so` (C ABI: `include/sumcheck_hip.h`, SC_ABI_VERSION 4) exposed with the
 //! signatures of the reference's public API:
 //!
 //! | here | reference |
@@ -60,7 +60,7 @@ pub struct sc_comm {
     _private: [u8; 0],
 }
 
-pub const SC_ABI_VERSION: c_int = 3;
+pub const SC_ABI_VERSION: c_int = 4;
 pub const SC_OK: c_int = 0;
 pub const SC_ERR_CONSTANT_POLY: c_int = 1;
 pub const SC_ERR_FIRST_ROUND_HAS_MSG: c_int = 2;
@@ -107,6 +107,9 @@ extern "C" {
                              out: *mut *mut sc_comm) -> c_int;
     pub fn sc_comm_init_p2p(group_id: u64, rank: c_int, nranks: c_int, out: *mut *mut sc_comm) -> c_int;
     pub fn sc_comm_free(comm: *mut sc_comm);
+    pub fn sc_comm_info(comm: *mut sc_comm, rank_out: *mut c_int, nranks_out: *mut c_int, kind_out: *mut c_int) -> c_int;
+    pub fn sc_comm_exchange_bench(comm: *mut sc_comm, n_words: u32, iters: u32, us_mean_out: *mut f64, us_min_out_or_null: *mut f64) -> c_int;
+    pub fn sc_set_publish_timeout_ms(ms: u32) -> c_int;
     pub fn sc_ml_prove_sharded(p: *mut sc_prover, comm: *mut sc_comm, rng_or_null: *mut sc_rng, nv_total: u32, out_proof: *mut u64,
                                out_randomness: *mut u64) -> c_int;
     pub fn sc_rng_setup() -> *mut sc_rng;

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # SC_LIB_VARIANT=exp (tests/test_gpu_variants.py only): the -DSC_EXPERIMENTS build with the cross-check kernels and their knobs
 SO_PATH = os.path.join(HERE, "libsumcheck_hip_exp.so" if os.environ.get("SC_LIB_VARIANT") == "exp" else "libsumcheck_hip.so")
-if os.environ.get("SC_LIB_PATH"):  # A/B runs of two builds on one box (tools/): an explicit library file
+if os.environ.get("SC_LIB_PATH"):  # an explicit library file (A/B runs of two builds on one box: tools/ab.sh)
     SO_PATH = os.environ["SC_LIB_PATH"]
 
 u64p = C.POINTER(C.c_uint64)
@@ -74,6 +74,9 @@ SIGNATURES = {
     "sc_comm_init_p2p": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.POINTER(_V)]),
     "sc_comm_selftest": (C.c_int, [_V]),
     "sc_comm_free": (None, [_V]),
+    "sc_comm_info": (C.c_int, [_V, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sc_comm_exchange_bench": (C.c_int, [_V, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sc_set_publish_timeout_ms": (C.c_int, [C.c_uint32]),
     "sc_ml_prove_sharded": (C.c_int, [_V, _V, _V, C.c_uint32, _V, _V]),
     "sc_ml_prove_sharded_rounds": (C.c_int, [_V, _V, _V, C.c_uint32, C.c_uint32, _V, _V]),
     "sc_fix_variables": (C.c_int, [_V, C.c_uint32, _V, C.c_uint32, _V, C.c_uint32]),
@@ -104,13 +107,21 @@ SIGNATURES = {
     "sc_prover_last_round_ms": (C.c_int, [_V, C.POINTER(C.c_float)]),
     "sc_prover_set_timing": (C.c_int, [_V, C.c_int]),
     "sc_prover_get_timing": (C.c_int, [_V, C.POINTER(C.c_double), u64p, C.POINTER(C.c_double)]),
+    "sc_prover_get_round_timing": (C.c_int, [_V, C.POINTER(C.c_double), u64p]),
     "sc_prover_reset": (C.c_int, [_V, _V, C.c_uint32]),
     "sc_claim_weights": (C.c_int, [C.c_uint32, _V, _V]),
     "sc_fr_elementwise": (C.c_int, [C.c_int, _V, _V, _V, C.c_uint64]),
     "sc_bench_modmul": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), u64p]),
 }
 
+ABI_VERSION = 4  # SC_ABI_VERSION of include/sumcheck_hip.h as declared above
 _lib = None
+
+
+def _missing_symbol(name):
+    def stub(*_a, **_k):
+        raise SumcheckError(SC_ERR_BAD_ARG, f"{SO_PATH} does not export {name} (an older build loaded with SC_AB_ALLOW_MISSING=1)")
+    return stub
 
 
 class SumcheckError(RuntimeError):
@@ -137,15 +148,26 @@ def lib():
         except Exception:
             pass
         L = C.CDLL(SO_PATH)
+        # An A/B run against an OLDER build (tools/ab.sh) sets SC_AB_ALLOW_MISSING=1 next to SC_LIB_PATH: entry points that build lacks
+        # become stubs that raise when called.  Without it every declared symbol must resolve, whatever file SC_LIB_PATH names.
+        allow_missing = os.environ.get("SC_AB_ALLOW_MISSING") == "1"
         for name, (res, args) in SIGNATURES.items():
             try:
                 fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
             except AttributeError:
-                if os.environ.get("SC_LIB_PATH"):  # an A/B run against an older build (tools/run_ab.sh): it simply lacks the newer entry points
-                    continue
-                raise
+                if not allow_missing:
+                    raise
+                setattr(L, name, _missing_symbol(name))
+                continue
             fn.restype = res
             fn.argtypes = args
+        got = L.sc_abi_version()
+        if got != ABI_VERSION:
+            msg = f"{SO_PATH} reports ABI version {got}, this loader declares {ABI_VERSION}: signatures may not match"
+            if not allow_missing:
+                raise ImportError(msg + " (rebuild: python -c 'import __graft_entry__ as g; g.build()')")
+            import warnings
+            warnings.warn(msg)
         _lib = L
     return _lib
 

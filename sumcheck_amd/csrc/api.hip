@@ -37,6 +37,23 @@ using scd::TablePtrs;
 // ---------------------------------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------------------------------
+// How long a host loop waits for a round's message (or a peer's lanes) before it declares the proof dead: sc_set_publish_timeout_ms,
+// SC_PUBLISH_TIMEOUT_MS in the environment, 20 s by default (a device-side wait's own bound -- SC_WAIT_SPINS -- expires long before).
+static std::atomic<uint32_t> g_publish_timeout_ms{0}; // 0: not set yet
+static std::chrono::milliseconds publish_timeout() {
+    uint32_t ms = g_publish_timeout_ms.load(std::memory_order_relaxed);
+    if (ms == 0) {
+        const char *e = std::getenv("SC_PUBLISH_TIMEOUT_MS");
+        const long v = e ? std::atol(e) : 0;
+        ms = v > 0 ? (uint32_t)std::min<long>(v, 3600 * 1000L) : 20000u;
+        g_publish_timeout_ms.store(ms, std::memory_order_relaxed);
+    }
+    return std::chrono::milliseconds(ms);
+}
+extern "C" int sc_set_publish_timeout_ms(uint32_t ms) {
+    g_publish_timeout_ms.store(ms ? ms : 20000u, std::memory_order_relaxed);
+    return SC_OK;
+}
 static thread_local std::string g_last_error;
 static thread_local int g_device = 0;
 
@@ -179,6 +196,7 @@ struct Table {
     int next = 0;                     // buffer the next bind writes to
 };
 
+constexpr uint32_t kResidentSpinsDefault = 256; // ~0.5 ms of polls
 struct sc_prover {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -246,7 +264,7 @@ struct sc_prover {
         bool first_has_bind = false;
         uint32_t seq0 = 0, sig0 = 0, n_rounds = 0, done = 0; // done: rounds whose message the host has taken
     } res;
-    uint32_t resident_spins = 256;  // its patience for the next call, in polls of the host-mapped mailbox (~2 us each); 0: not used
+    uint32_t resident_spins = kResidentSpinsDefault; // its patience for the next call, in polls of the host-mapped mailbox (~2 us each); 0: not used
     bool deferred_pending = false;  // a round is enqueued behind the wait and still needs its challenge
     bool fused_finalize = false;    // experiments, SC_FUSED_FIN=1: the merged big-round launch finalizes in-kernel (measured: slower than the k_finalize launch)
     bool use_tail = true;           // sc_ml_prove* / GKR: the latency-bound rounds run in the persistent tail kernel (SC_TAIL=0: pipelined launches)
@@ -276,6 +294,9 @@ struct sc_prover {
     std::vector<double> prod_ms;       // accumulated device time of each product's kernel
     std::vector<uint64_t> prod_launches;
     double rounds_ms = 0.0;            // accumulated ev0..ev1 (all kernels of a round incl. finalize)
+    std::vector<double> round_kernel_ms;   // per round (index = round - 1): accumulated device time of the merged big-round launch ...
+    std::vector<uint64_t> round_kernel_launches; // ... and how many launches that is (sc_prover_get_round_timing)
+    uint32_t timed_round = 0;          // the round the pending event pairs belong to
 };
 
 static int resident_quiesce(sc_prover *p); // the interactive protocol's resident kernel leaves before anything else touches the handle
@@ -633,6 +654,16 @@ static int prover_build(const sc_poly_desc *d, sc_prover *p) {
 
 static std::vector<uint8_t> pool_key_of(const sc_poly_desc *d, int device);
 static sc_prover *handle_pool_take(const std::vector<uint8_t> &key);
+// Per-owner policy of a handle, as prover_build leaves it: whether kernels may wait for the host (SC_NO_DEVICE_POLLING /
+// sc_prover_set_polling), the resident kernel's patience (sc_prover_set_resident), per-launch timing (sc_prover_set_timing).  A handle
+// that comes back from the pool starts from these, whatever its previous owner had set.
+static void reset_owner_policy(sc_prover *p, uint32_t desc_flags) {
+    p->polling_off_by_caller = (desc_flags & SC_NO_DEVICE_POLLING) != 0;
+    p->pipeline_ok = !p->polling_off_by_caller;
+    p->resident_spins = kResidentSpinsDefault;
+    if (p->timing) (void)sc_prover_set_timing(p, 0);
+    p->n_retries = 0;
+}
 extern "C" int sc_prover_init(const sc_poly_desc *desc, sc_prover **out) {
     if (!out) return fail(SC_ERR_BAD_ARG, "null out");
     *out = nullptr;
@@ -642,8 +673,7 @@ extern "C" int sc_prover_init(const sc_poly_desc *desc, sc_prover **out) {
     std::vector<uint8_t> key = pool_key_of(desc, g_device);
     if (sc_prover *kept = handle_pool_take(key)) {
         if (sc_prover_reset(kept, desc->tables, desc->flags & SC_TABLES_ON_DEVICE) == SC_OK) {
-            kept->polling_off_by_caller = (desc->flags & SC_NO_DEVICE_POLLING) != 0; // (what a previous owner set with sc_prover_set_polling does not carry over)
-            kept->pipeline_ok = !kept->polling_off_by_caller;
+            reset_owner_policy(kept, desc->flags); // (nothing a previous owner set -- polling, the resident kernel's patience -- carries over)
             *out = kept;
             return SC_OK;
         }
@@ -704,6 +734,10 @@ static int collect_timing(sc_prover *p) {
         HIP_TRY(hipEventElapsedTime(&ms, p->prod_ev[2 * k], p->prod_ev[2 * k + 1]));
         p->prod_ms[k] += ms;
         p->prod_launches[k] += 1;
+        if (p->timed_round >= 1 && p->timed_round <= p->round_kernel_ms.size()) { // (per-product launches of one round add up)
+            p->round_kernel_ms[p->timed_round - 1] += ms;
+            if (k == 0) p->round_kernel_launches[p->timed_round - 1] += 1;
+        }
     }
     p->timing_pending = false;
     return SC_OK;
@@ -1351,6 +1385,7 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         p->timing_pending = timed;
         p->prod_timed = timed && !small;
         p->prod_merged = merged;
+        p->timed_round = p->round;
     }
     return SC_OK;
 }
@@ -1415,16 +1450,43 @@ constexpr size_t kTailSyncBytes = 4 * (16 + (size_t)scd::kTailMaxGrid);
 // idle GPU (tail_max_resident_blocks); two of them from two proving threads could each end up partially resident and wait for
 // blocks that are never scheduled.  A prover that finds the slot taken does not wait for it: its late rounds run as pipelined
 // launches (the path every proof took before the tail kernel existed).  (The kernel's waits are bounded as well: kernels.hip, grid_barrier.)
-static std::atomic<int> g_tail_busy[64];
-struct TailSlot {
-    const int device;
-    bool held;
-    explicit TailSlot(int d) : device(d), held(false) {
-        int expect = 0;
-        held = g_tail_busy[(unsigned)device & 63u].compare_exchange_strong(expect, 1, std::memory_order_acquire);
+// The slot has an OWNER (a handle), taken and given back under a per-device mutex.  A resident kernel of the interactive protocol holds
+// it for as long as the kernel may be on the GPU -- but its patience is ~0.5 ms, while the handle may sit idle mid-protocol for as long as
+// its verifier likes and only notices that its kernel left on its next call.  So a slot whose holder is a resident kernel that has
+// raised its exit marker (sig[1], host-mapped: the kernel's last store before every block returns) counts as free: the next prover
+// takes it over, and the former holder's release becomes a no-op.
+struct TailOwner {
+    std::mutex mu;
+    sc_prover *owner = nullptr;
+    bool resident = false;           // held by resident_start (reclaimable once the kernel has left)
+    const uint32_t *marker = nullptr; // the holder's sig + 1
+};
+static TailOwner g_tail_owner[64];
+static bool tail_slot_acquire(sc_prover *p, bool resident) {
+    TailOwner &t = g_tail_owner[(unsigned)p->device & 63u];
+    std::lock_guard<std::mutex> lk(t.mu);
+    if (t.owner && t.owner != p) {
+        if (!(t.resident && t.marker && __atomic_load_n(t.marker, __ATOMIC_ACQUIRE) != 0)) return false;
     }
+    t.owner = p;
+    t.resident = resident;
+    t.marker = p->sig ? p->sig + 1 : nullptr;
+    return true;
+}
+static void tail_slot_release(sc_prover *p) { // (a holder that lost the slot to a reclaim releases nothing)
+    TailOwner &t = g_tail_owner[(unsigned)p->device & 63u];
+    std::lock_guard<std::mutex> lk(t.mu);
+    if (t.owner == p) {
+        t.owner = nullptr;
+        t.marker = nullptr;
+    }
+}
+struct TailSlot {
+    sc_prover *const p;
+    bool held;
+    explicit TailSlot(sc_prover *p_) : p(p_), held(tail_slot_acquire(p_, false)) {}
     ~TailSlot() {
-        if (held) g_tail_busy[(unsigned)device & 63u].store(0, std::memory_order_release);
+        if (held) tail_slot_release(p);
     }
     TailSlot(const TailSlot &) = delete;
     TailSlot &operator=(const TailSlot &) = delete;
@@ -1552,7 +1614,7 @@ static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, co
             while (!(seen = (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) == A.seq0 + j))) {
                 if ((++spins & 0xfff) == 0) {
                     if (wait_gave_up(p)) break;
-                    if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) break;
+                    if (std::chrono::steady_clock::now() - t_start > publish_timeout()) break;
                 }
             }
             if (!seen || wait_gave_up(p)) {
@@ -1605,7 +1667,7 @@ static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, co
 // patience is short (resident_spins polls, ~0.5 ms): a verifier that does not answer in time finds the kernel gone -- it leaves cleanly
 // after the last round it completed, tables consistent -- and the call proceeds as if there had never been one (a launch sequence, or a
 // new resident kernel).  Every other entry point that touches the handle's stream or tables quiesces it first (a tagged stop word).
-static void resident_release_slot(sc_prover *p) { g_tail_busy[(unsigned)p->device & 63u].store(0, std::memory_order_release); }
+static void resident_release_slot(sc_prover *p) { tail_slot_release(p); }
 // the kernel has exited (all rounds done, patience expired, or stop word): fold what it did into the handle
 static int resident_finish(sc_prover *p) {
     if (!p->res.active) return SC_OK;
@@ -1653,7 +1715,7 @@ static int resident_wait(sc_prover *p, uint32_t j, uint64_t *out_evals) {
                 int rc = resident_finish(p);
                 return rc ? rc : kResidentGone;
             }
-            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) {
+            if (std::chrono::steady_clock::now() - t_start > publish_timeout()) {
                 (void)resident_quiesce(p);
                 p->exhausted = true;
                 return fail(SC_ERR_HIP, "the resident round kernel did not publish its message within 20 s");
@@ -1680,8 +1742,7 @@ static int resident_start(sc_prover *p, const uint64_t *r_or_null, uint64_t *out
         if (sch::geq_p(r)) return kResidentGone;
     }
     if (!resident_enabled(p) || !tail_possible(p)) return kResidentGone;
-    int expect = 0;
-    if (!g_tail_busy[(unsigned)p->device & 63u].compare_exchange_strong(expect, 1, std::memory_order_acquire)) return kResidentGone;
+    if (!tail_slot_acquire(p, true)) return kResidentGone;
     const uint32_t n_rounds = p->nv - p->round;
     scd::TailArgs A;
     int grid = 1;
@@ -1737,7 +1798,7 @@ static int run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, 
         const auto t0 = clk::now();
         int rc;
         if (!enqueued && tail_possible(p)) { // from here on every round is latency-bound: one persistent kernel runs them all
-            TailSlot slot(p->device);        // (unless another prover's tail kernel has the device: then pipelined launches, below)
+            TailSlot slot(p);                // (unless another prover's tail kernel has the device: then pipelined launches, below)
             if (slot.held) return run_tail(p, rng, n_rounds - i, have ? &vm : nullptr, pm, out_challenges_or_null ? out_challenges_or_null + i : nullptr);
         }
         if (!enqueued) {
@@ -1894,6 +1955,24 @@ extern "C" int sc_prover_set_timing(sc_prover *p, int on) {
     p->prod_ms.assign(p->K, 0.0);
     p->prod_launches.assign(p->K, 0);
     p->rounds_ms = 0.0;
+    p->round_kernel_ms.assign(p->nv, 0.0);
+    p->round_kernel_launches.assign(p->nv, 0);
+    return SC_OK;
+}
+
+// per round (index = round - 1, p->nv entries): accumulated device time of the big-round kernel launch(es) of that round since
+// sc_prover_set_timing(p, 1), and the number of timed proofs that contributed (0 for the latency-bound rounds, which record no events)
+extern "C" int sc_prover_get_round_timing(sc_prover *p, double *ms_per_round, uint64_t *launches_per_round) {
+    if (!p) return fail(SC_ERR_BAD_ARG, "null prover");
+    DeviceGate gate_(p->device);
+    if (!p->timing) return fail(SC_ERR_BAD_ARG, "timing is not enabled on this handle");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = collect_timing(p);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < p->nv; ++i) {
+        if (ms_per_round) ms_per_round[i] = i < p->round_kernel_ms.size() ? p->round_kernel_ms[i] : 0.0;
+        if (launches_per_round) launches_per_round[i] = i < p->round_kernel_launches.size() ? p->round_kernel_launches[i] : 0;
+    }
     return SC_OK;
 }
 
@@ -2892,6 +2971,105 @@ int sc_internal_allreduce_lanes(sc_comm *c, uint64_t *d_lanes, size_t n_words, h
 }
 int sc_internal_comm_ranks(sc_comm *c) { return c ? c->nranks : 1; }
 
+extern "C" int sc_comm_info(sc_comm *c, int *rank, int *nranks, int *kind) {
+    if (!c) return fail(SC_ERR_BAD_ARG, "null argument");
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = c->nranks;
+    if (kind) *kind = c->comm ? SC_COMM_RCCL : c->p2p ? SC_COMM_P2P : SC_COMM_HOST;
+    return SC_OK;
+}
+// Measurement, collective: `iters` back-to-back exchanges of n_words uint64 lanes in exactly the form a sharded round uses on this
+// communicator -- RCCL: ncclAllReduce on a stream, the publishing kernel, the host's poll of the flag; peer-to-peer: the one exchange
+// kernel and the poll; host transport: the publishing kernel, the poll, the caller's all-reduce function -- each waited for before
+// the next is issued, as the rounds of a proof are.  The sums are checked.  *us_mean_out = wall time per exchange on this rank.
+extern "C" int sc_comm_exchange_bench(sc_comm *c, uint32_t n_words, uint32_t iters, double *us_mean_out, double *us_min_out) {
+    if (!c || !us_mean_out || n_words == 0 || n_words > (uint32_t)scd::kP2PWords || iters == 0) return fail(SC_ERR_BAD_ARG, "bad argument");
+    if (sc_device_count() <= 0) return fail(SC_ERR_HIP, "no HIP device visible: libsumcheck_hip has no CPU fallback");
+    const int device = c->p2p ? c->device : g_device;
+    HIP_TRY(hipSetDevice(device));
+    struct Res {
+        hipStream_t s = nullptr;
+        uint64_t *d = nullptr, *h = nullptr, *h_dev = nullptr;
+        uint32_t *flag = nullptr, *flag_dev = nullptr;
+        ~Res() {
+            if (s) (void)hipStreamSynchronize(s);
+            if (d) (void)hipFree(d);
+            if (h) (void)hipHostFree(h);
+            if (flag) (void)hipHostFree(flag);
+            if (s) (void)hipStreamDestroy(s);
+        }
+    } R;
+    {
+        DeviceGate gate_(device);
+        HIP_TRY(hipStreamCreateWithFlags(&R.s, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&R.d), (size_t)n_words * 8));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&R.h), (size_t)n_words * 8, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&R.h_dev), R.h, 0));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&R.flag), 64, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&R.flag_dev), R.flag, 0));
+        *R.flag = 0;
+    }
+    const bool p2p = c->p2p != nullptr && c->nranks > 1;
+    std::vector<uint64_t> mine(n_words), lanes(n_words);
+    double total_us = 0.0, min_us = 1e30;
+    const uint64_t tri = (uint64_t)c->nranks * (uint64_t)(c->nranks + 1) / 2;
+    for (uint32_t it = 0; it <= iters; ++it) { // (iteration 0 warms up and is not counted)
+        for (uint32_t w = 0; w < n_words; ++w) mine[w] = (uint64_t)(c->rank + 1) * (uint64_t)(w + 1 + it);
+        {
+            DeviceGate gate_(device);
+            HIP_TRY(hipMemcpyAsync(R.d, mine.data(), (size_t)n_words * 8, hipMemcpyHostToDevice, R.s));
+            HIP_TRY(hipStreamSynchronize(R.s));
+        }
+        const uint32_t want = it + 1;
+        scd::P2PArgs xa;
+        const auto t0 = std::chrono::steady_clock::now();
+        {
+            DeviceGate gate_(device);
+            if (c->comm) NCCL_TRY(g_nccl.AllReduce(R.d, R.d, (size_t)n_words, ncclUint64, ncclSum, c->comm, R.s));
+            if (p2p) {
+                std::memset(&xa, 0, sizeof(xa));
+                for (int q = 0; q < c->nranks; ++q) xa.inbox[q] = c->p2p->inbox[q];
+                xa.nranks = c->nranks;
+                xa.rank = c->rank;
+                xa.n_words = (int)n_words;
+                xa.gen = ++c->p2p_gen;
+                xa.max_spins = c->p2p_shared_device ? 2048u : scd::wait_spins_default();
+                HIP_TRY(scd::launch_p2p_allreduce(xa, R.d, R.h_dev, R.flag_dev, want, R.s));
+            } else {
+                HIP_TRY(scd::launch_publish_words(R.d, R.h_dev, (int)n_words, R.flag_dev, want, R.s));
+            }
+        }
+        uint64_t spins = 0;
+        for (;;) {
+            const uint32_t f = __atomic_load_n(R.flag, __ATOMIC_ACQUIRE);
+            if (f == want) break;
+            if (p2p && f == (want | scd::kP2PRetryBit)) { // (ranks sharing a GPU: a peer's kernel was queued behind this one)
+                if (!c->p2p_shared_device) return fail(SC_ERR_HIP, "p2p all-reduce: a peer's lanes did not arrive");
+                __atomic_store_n(R.flag, 0u, __ATOMIC_RELEASE);
+                std::this_thread::yield();
+                DeviceGate gate_(device);
+                HIP_TRY(scd::launch_p2p_allreduce(xa, R.d, R.h_dev, R.flag_dev, want, R.s));
+                continue;
+            }
+            if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > publish_timeout()) return fail(SC_ERR_HIP, "exchange %u did not publish", it);
+        }
+        std::copy(R.h, R.h + n_words, lanes.begin());
+        if (!c->comm && !p2p && c->nranks > 1) {
+            if (c->h_allreduce(c->ctx, lanes.data(), (size_t)n_words) != 0) return fail(SC_ERR_HIP, "the host transport's all-reduce failed");
+        }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        for (uint32_t w = 0; w < n_words; ++w)
+            if (lanes[w] != tri * (uint64_t)(w + 1 + it)) return fail(SC_ERR_HIP, "exchange %u returned a wrong sum in word %u", it, w);
+        if (it > 0) {
+            total_us += us;
+            min_us = std::min(min_us, us);
+        }
+    }
+    *us_mean_out = total_us / iters;
+    if (us_min_out) *us_min_out = min_us;
+    return SC_OK;
+}
+
 extern "C" void sc_comm_free(sc_comm *c) {
     if (!c) return;
     if (c->comm && g_nccl.CommDestroy) (void)g_nccl.CommDestroy(c->comm);
@@ -2925,6 +3103,10 @@ extern "C" void sc_comm_free(sc_comm *c) {
 static int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_t *out_proof, uint64_t *out_randomness) {
     HIP_TRY(hipSetDevice(p->device));
     const int n_words = (int)p->D * 8;
+    // (before anything changes the handle: the peer-to-peer inbox holds kP2PWords lanes per source, i.e. messages of at most 8 evaluations)
+    if (comm->p2p && comm->nranks > 1 && n_words > scd::kP2PWords)
+        return fail(SC_ERR_BAD_ARG, "a peer-to-peer communicator carries round messages of at most %d evaluations (max_multiplicands <= %d); this polynomial has %u",
+                    scd::kP2PWords / 8, scd::kP2PWords / 8 - 1, p->D);
     if (!p->d_wide) {
         HIP_TRY(hipMalloc(&p->d_wide, (size_t)n_words * 8));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_wide), (size_t)n_words * 8, hipHostMallocMapped | hipHostMallocCoherent));
@@ -2998,14 +3180,14 @@ static int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, 
             if (p2p && __atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) == (want | scd::kP2PRetryBit)) {
                 // the exchange kernel left without its peers' words.  Ranks that share a GPU: a peer's kernels may have been queued behind
                 // it -- launch it again (pushes are idempotent, what has arrived stays).  Distinct GPUs: its bound is seconds; a peer is gone.
-                if (!comm->p2p_shared_device || next_enqueued || std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) break;
+                if (!comm->p2p_shared_device || next_enqueued || std::chrono::steady_clock::now() - t_start > publish_timeout()) break;
                 __atomic_store_n(p->h_flag, 0u, __ATOMIC_RELEASE);
                 std::this_thread::yield();
                 DeviceGate gate_(p->device);
                 HIP_TRY(scd::launch_p2p_allreduce(xargs[want & 1u], p->d_wide, p->h_wide_dev, p->h_flag_dev, want, p->stream));
                 continue;
             }
-            if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) break;
+            if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t_start > publish_timeout()) break;
         }
         if (!seen && p2p && (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) & scd::kP2PRetryBit)) {
             abandon_deferred(p);

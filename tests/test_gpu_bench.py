@@ -1,5 +1,7 @@
 """bench.py's output contract on a GPU box: one JSON line (the last line of stdout) with the fields the driver reads, at N=1
-and -- through the one-GPU test mode (two ranks on GPU 0, gloo) -- on the multi-rank path that `torch.distributed.run` takes."""
+and -- through the one-GPU test mode (two ranks on GPU 0) -- on the multi-rank paths: `python bench.py --gpus 2` exactly as the driver
+types it (bench.py starts its own ranks: processes over torch.distributed.run, or thread ranks over the peer-to-peer communicator) and
+under an external `torch.distributed.run`."""
 import json
 import os
 import socket
@@ -40,32 +42,77 @@ def test_bench_line_single_gpu():
     assert par["ok"] is True and par["rounds"] == 19 and par["rounds_equal"] == 19 and par["rounds_equal_after_timed_region"] == 19
     assert "phases_s" in cb and cb["phases_s"]["sums"] > 0 and cb["whole_prove"]["value"] > 0
     assert "traffic_source" in rf
+    # measurement hygiene: per-round roofline from the live events, the multiplier figures, the sampling floor
+    assert d["roofline"]["event_timed_steps"] == 2 and rf["event_timed_every"] == 1  # at least 8 sampled steps, or all of them
+    pr = rf["per_round"]
+    assert [x["round"] for x in pr] == [1, 2] and all(x["ms"] > 0 and 0 < x["frac"] < 1 for x in pr)  # nv=19: two big rounds
+    assert abs(sum(x["ms"] * x["samples"] for x in pr) / rf["launches"] - rf["avg_launch_ms"]) < 1e-6
+    mu = rf["multiplier"]
+    assert 0 < mu["frac_executed"] < 1 and mu["executed_products_per_s"] < mu["reference_muls_per_s"] and "modmul_fraction" not in rf
+    assert d["config"]["gpu_leg"]["proofs_after_the_clock"] >= 1 and d["config"]["launcher"] == "single process"
 
 
-def _two_ranks(extra):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+def _two_ranks(extra, launcher=None, timeout=900):
+    """launcher None: `python bench.py --gpus 2 ...` with NO launcher around it (the driver's command line); "external": under
+    `python -m torch.distributed.run`; "threads" / "processes": the self-launch forced to one form"""
     env = dict(os.environ, SC_BENCH_ONE_GPU="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra,
-                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    return _last_json(r.stdout)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
+    if launcher == "external":
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail + (["--launcher", launcher] if launcher else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # ONE line on stdout: the record
+    return json.loads(lines[-1])
 
 
-def test_bench_line_two_ranks_one_gpu():
-    """the driver's N>1 launch line on a one-GPU box: the whole sharded proof inside the library (sc_ml_prove_sharded) over its
-    host transport; strong scaling = the same global instance split over the ranks"""
+def test_bench_two_gpus_as_the_driver_types_it():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts its own ranks; the N > 1 line carries a CPU
+    baseline and is bit-exact against the CPU proof of the same (strong-scaling) instance, on every rank"""
     d = _two_ranks(["--nv", "16"])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["cpu_baseline"] is None
-    assert d["config"]["nv"] == 16 and d["config"]["nv_per_gpu"] == 15 and d["config"]["round_loop"].startswith("library")
-    assert "selftest passed" in d["config"]["round_loop_reason"]
-    # no CPU proof at N > 1: the line certifies itself through the verifier and its final oracle query over the sharded tables
-    assert d["parity"]["ok"] is True and d["parity"]["verifier_accepts"] and d["parity"]["oracle_query_matches"], d["parity"]
-    d = _two_ranks(["--config", "4", "--nv", "17"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    par = d["parity"]
+    assert par["ok"] is True and par["rounds_equal"] == 16 and par["rounds_equal_after_timed_region"] == 16 and par["ranks_compared"] == 2, par
+    c = d["config"]
+    assert c["nv"] == 16 and c["nv_per_gpu"] == 15 and c["round_loop"].startswith("library") and "self-launched" in c["launcher"]
+    assert c["ranks_seen"] == 2 and c["communicator"] == "host-transport" and c["exchange"]["exchange_us"] > 0 and c["exchange"]["bytes"] == 320
+    assert "selftest passed" in c["round_loop_reason"]
+
+
+def test_bench_two_thread_ranks_over_p2p():
+    """the other self-launch: two thread ranks of one process over sc_comm_init_p2p (no torch.distributed, no RCCL)"""
+    d = _two_ranks(["--nv", "16"], launcher="threads")
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["communicator"] == "p2p" and c["launcher"].startswith("threads") and c["round_loop"] == "library+p2p"
+    assert d["cpu_baseline"]["value"] > 0 and d["parity"]["ok"] is True and d["parity"]["rounds_equal"] == 16 and d["parity"]["ranks_compared"] == 2
+    assert c["exchange"]["exchange_us"] > 0
+
+
+def test_bench_line_two_ranks_external_launcher():
+    """under `torch.distributed.run` (the documented launch line): config 4 and weak scaling have no CPU proof of the instance -- the line
+    certifies itself through the verifier and its final oracle query over the sharded tables"""
+    d = _two_ranks(["--config", "4", "--nv", "17"], launcher="external")
     assert d["config"]["tables"] == 3 and d["config"]["nv_per_gpu"] == 16 and "config 4" in d["config"]["workload"]
-    assert d["parity"]["ok"] is True, d["parity"]
-    d = _two_ranks(["--nv", "17", "--scaling", "weak"])
-    assert d["parity"]["ok"] is True, d["parity"]
+    assert d["config"]["launcher"] == "processes (external launcher)" and d["cpu_baseline"]["value"] > 0
+    assert d["parity"]["ok"] is True and d["parity"]["rounds_equal"] == 17, d["parity"]  # (config 4 at nv <= 24: the CPU leg proves the instance itself)
+    d = _two_ranks(["--nv", "17", "--scaling", "weak", "--no-cpu-baseline"], launcher="external")
+    assert d["parity"]["ok"] is True and d["parity"]["verifier_accepts"] and d["parity"]["oracle_query_matches"], d["parity"]
+    assert d["cpu_baseline"] is None
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    env = dict(os.environ)
+    env.pop("SC_BENCH_ONE_GPU", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 2 and "visible GPUs" in r.stderr and r.stdout.strip() == ""

@@ -81,6 +81,45 @@ def test_two_adic_root_of_unity_through_the_device_multipliers(op):
     assert cref.mont_to_ints(dmul(acc, acc)) == [1] * 3
 
 
+@pytest.mark.parametrize("op", [0, 3, 4])
+def test_r3_published_constant_through_the_device_multipliers(op):
+    """Published known answer: R^3 = 2^768 mod p = 0x6e2a...73af.  mont(R) squared is mont(R^2), whose raw limbs ARE R^3 -- for the
+    production multiplier (op 0) this goes through the 9 x 29-bit representation and its 2^261 radix, so the literal pins the 2^5
+    compensation; two more dependent squarings against Python's pow."""
+    from oracle import pyoracle as po
+    from tests.test_oracle import R3_PUBLISHED
+    x = np.ascontiguousarray(cref.ints_to_mont([po.R] * 5))
+    e = 1
+    for step in range(3):
+        out = np.empty_like(x)
+        _lib.check(sc.lib().sc_fr_elementwise(op, C.c_void_p(x.ctypes.data), C.c_void_p(x.ctypes.data), C.c_void_p(out.ctypes.data), x.shape[0]))
+        x, e = out, 2 * e
+        raws = [sum(int(v) << (64 * i) for i, v in enumerate(row)) for row in x]
+        assert raws == [pow(2, 256 * (e + 1), po.P)] * 5
+        if step == 0:
+            assert raws[0] == R3_PUBLISHED
+
+
+def test_add_sub_mul_edge_identities_on_the_device():
+    """literal identities around (p - 1) / 2 and -1 through every device add / sub / mul: the places where a lazy or carry-free
+    representation has to wrap exactly"""
+    from oracle import pyoracle as po
+    h, m1 = (po.P - 1) // 2, po.P - 1
+    cases = [  # (op name, a, b, expected)
+        ("add", h, h, m1), ("add", h, h + 1, 0), ("add", m1, 1, 0), ("add", m1, m1, po.P - 2), ("add", h + 1, h + 1, 1),
+        ("sub", 0, 1, m1), ("sub", h, h + 1, m1), ("sub", 0, m1, 1), ("sub", m1, m1, 0), ("sub", 1, m1, 2), ("sub", h, m1, h + 1),
+        ("mul", m1, m1, 1), ("mul", 2, h + 1, 1), ("mul", m1, h, h + 1), ("mul", m1, 1, m1), ("mul", h + 1, h + 1, pow(4, -1, po.P)),
+    ]
+    for ops, name in (((1,), "add"), ((2,), "sub"), ((0, 3, 4), "mul")):
+        sel = [c for c in cases if c[0] == name]
+        a = np.ascontiguousarray(cref.ints_to_mont([c[1] for c in sel]))
+        b = np.ascontiguousarray(cref.ints_to_mont([c[2] for c in sel]))
+        for op in ops:
+            out = np.empty_like(a)
+            _lib.check(sc.lib().sc_fr_elementwise(op, C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(out.ctypes.data), a.shape[0]))
+            assert cref.mont_to_ints(out) == [c[3] for c in sel], (name, op)
+
+
 def _interactive(poly, challenges, borrow=False):
     st = sc.IPForMLSumcheck.prover_init(poly, borrow=borrow)
     msgs, v = [], None

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/sumcheck_hip.h but not exported"
     assert set(declared) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert sc.lib().sc_abi_version() == 3
+    assert sc.lib().sc_abi_version() == 4
 
 
 def test_transcript_matches_golden():
@@ -166,6 +166,14 @@ def test_interpolate_uni_poly():
         x = int.from_bytes(rng.bytes(32), "little") % po.P
         assert field.to_int(sc.interpolate_uni_poly(field.from_ints(ys), field.from_int(x))) == f(x)
         assert field.to_int(sc.interpolate_uni_poly(field.from_ints(ys), field.from_int(n - 1))) == ys[n - 1]
+
+
+def test_interpolate_uni_poly_known_answers_over_the_rationals():
+    """known answers computed with Python fractions over Q (tests/test_oracle.py: no modular arithmetic in the expectation), lengths on
+    both sides of the reference's tier switches (verifier.rs:256-322)"""
+    from tests.test_oracle import interpolation_known_answers
+    for ys, x, want in interpolation_known_answers():
+        assert field.to_int(sc.interpolate_uni_poly(field.from_ints(ys), field.from_int(x))) == want
 
 
 def test_claim_weights_evaluate_a_polynomial_from_its_kernel_nodes():

@@ -2,6 +2,8 @@
 other, against published known answers, and against the algebraic relations the reference's tests assert."""
 import hashlib
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -21,6 +23,64 @@ def test_field_constants():
     assert po.P % (1 << 32) == 1
     one = cref.ints_to_mont([1])[0]
     assert [int(x) for x in one] == [0x00000001FFFFFFFE, 0x5884B7FA00034802, 0x998C4FEFECBC4FF5, 0x1824B159ACC5056F]
+
+
+R3_PUBLISHED = int("6e2a5bb9c8db33e973d13c71c7b5f4181b3e0d188cf06990c62c1807439b73af", 16)  # 2^768 mod p: the R3 constant of the published BLS12-381 scalar-field implementations
+
+
+def lagrange_over_Q(ys, x):
+    """sum_i y_i prod_{j != i} (x - j) / (i - j), exactly, with Python fractions -- independent of every modular implementation here"""
+    from fractions import Fraction
+    tot = Fraction(0)
+    for i, y in enumerate(ys):
+        t = Fraction(y)
+        for j in range(len(ys)):
+            if j != i:
+                t *= Fraction(x - j, i - j)
+        tot += t
+    assert tot.denominator == 1
+    return int(tot)
+
+
+def interpolation_known_answers():
+    """integer polynomials with SMALL integer coefficients, so that the answer is an integer computed over Q and only then reduced mod p
+    (no modular inverse is involved in producing the expectation): lengths on both sides of the reference's tier switches (20, 33
+    points: verifier.rs:256-322)"""
+    rng = np.random.default_rng(20241008)
+    out = []
+    for n in (2, 3, 4, 7, 20, 21, 33, 34):
+        coef = [int(c) for c in rng.integers(-50, 50, size=n)]
+        f = lambda v, coef=coef: sum(c * v ** i for i, c in enumerate(coef))
+        ys = [f(i) for i in range(n)]
+        for x in (n, n + 5, -3, 1000003):
+            want = lagrange_over_Q(ys, x)
+            assert want == f(x)
+            out.append(([y % po.P for y in ys], x % po.P, want % po.P))
+    return out
+
+
+def test_r3_published_constant_through_the_c_field_multiplier():
+    """R^3 mod p by DEPENDENT Montgomery squarings: mont(R)^2 = mont(R^2) whose raw limbs are R^3 (the published literal); two more
+    squarings against Python's pow"""
+    assert pow(2, 768, po.P) == R3_PUBLISHED
+    x = cref.ints_to_mont([po.R])  # Montgomery form of the integer R: raw limbs R^2
+    L = cref.lib()
+    u64p = C.POINTER(C.c_uint64)
+    e = 1
+    for step in range(3):
+        out = np.empty_like(x)
+        L.orc_fr_mul(x[0].ctypes.data_as(u64p), x[0].ctypes.data_as(u64p), out[0].ctypes.data_as(u64p))
+        x, e = out, 2 * e
+        raw = sum(int(v) << (64 * i) for i, v in enumerate(x[0]))
+        assert raw == pow(2, 256 * (e + 1), po.P)
+        if step == 0:
+            assert raw == R3_PUBLISHED
+
+
+def test_interpolate_known_answers_over_the_rationals():
+    for ys, x, want in interpolation_known_answers():
+        assert po.interpolate_uni_poly(ys, x) == want
+        assert cref.mont_to_ints(cref.interpolate_uni_poly(cref.ints_to_mont(ys), cref.ints_to_mont([x])[0])) == [want]
 
 
 def test_field_ops_c_vs_bigint():

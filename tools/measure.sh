@@ -1,0 +1,16 @@
+#!/bin/bash
+# The end-of-round measurement set on HEAD, one gpurun call:  tools/measure.sh TAG   (writes gpurun_out/TAG_*; copy what is to be
+# judged into profiles/).  GPU suite, smoke, rocprofv3 stats + HBM counter passes (tools/profile.sh), bench line, round times, the
+# other BASELINE configs, the interactive protocol.
+TAG=${1:?tag}
+cd "$(dirname "$0")/.."
+timeout 1800 python -m pytest tests -q -m gpu --durations=10 > gpurun_out/${TAG}_gpu_suite.log 2>&1; grep -E "passed|failed" gpurun_out/${TAG}_gpu_suite.log | tail -1
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+bash tools/profile.sh $TAG 2>&1 | tail -2
+python tools/collect_profiles.py $TAG 2>&1 | tail -1
+timeout 600 python bench.py 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench_line.json; cut -c1-260 gpurun_out/${TAG}_bench_line.json
+timeout 120 python tools/round_times.py 24 2>&1 | tail -27 > gpurun_out/${TAG}_round_times.txt
+timeout 900 python tools/bench_configs.py --config4 > gpurun_out/${TAG}_bench_configs.json 2>/dev/null; grep -c gpu_ms gpurun_out/${TAG}_bench_configs.json
+SC_GKR_TRACE=1 timeout 200 python tools/bench_configs.py --only-gkr 2>&1 | grep "^\[gkr\]" | tail -7 > gpurun_out/${TAG}_gkr_stage_trace.txt
+timeout 300 python tools/interactive_time.py 8 12 16 20 2>&1 | grep nv= > gpurun_out/${TAG}_interactive.txt
+timeout 200 python tools/oneshot_time.py 2>&1 | grep "nv=" > gpurun_out/${TAG}_oneshot_times.txt
