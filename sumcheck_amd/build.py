@@ -16,8 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsumcheck_hip.so")
 OUT_EXP = os.path.join(HERE, "libsumcheck_hip_exp.so")
-SOURCES = ["kernels.hip", "gkr.hip", "api.hip"]
-HEADERS = ["fr_device.hpp", "fe_device.hpp", "fr_mac.inc", "fr_mul_gen.inc", "kernels.h", "host_fr.hpp", "transcript.hpp", os.path.join("..", "..", "include", "sumcheck_hip.h")]
+SOURCES = ["kernels_big.hip", "kernels.hip", "gkr.hip", "api.hip"]
+HEADERS = ["fr_device.hpp", "fe_device.hpp", "kernel_common.hpp", "finalize_device.hpp", "fr_mac.inc", "fr_mul_gen.inc", "kernels.h", "host_fr.hpp", "transcript.hpp", os.path.join("..", "..", "include", "sumcheck_hip.h")]
+EXTRA = os.environ.get("SC_BUILD_EXTRA", "").split()  # e.g. SC_BUILD_EXTRA="-DSC_TAIL_CLOCKS" for a one-off local build
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
@@ -55,16 +56,21 @@ def _start(experiments: bool, verbose: bool, force: bool = False):
         src = os.path.join(CSRC, s)
         if not force and not _obj_stale(o, src):
             continue
-        cmd = [hipcc] + FLAGS + (["-DSC_EXPERIMENTS"] if experiments else []) + ["-MD", "-MF", o + ".d", "-c", src, "-o", o]
+        # -Rpass-analysis: registers / scratch / LDS / occupancy of every kernel, for free with every build (tools/kernel_resources.py prints them)
+        cmd = [hipcc] + FLAGS + (["-DSC_EXPERIMENTS"] if experiments else []) + EXTRA + ["-Rpass-analysis=kernel-resource-usage", "-MD", "-MF", o + ".d", "-c", src, "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((cmd, o, subprocess.Popen(cmd)))
+        procs.append((cmd, o, subprocess.Popen(cmd, stderr=open(o + ".log", "w"))))
     return hipcc, procs, objs
 
 
 def _finish(hipcc, procs, objs, out):
     for cmd, o, p in procs:
         if p.wait() != 0:
+            try:
+                sys.stderr.write("".join(l for l in open(o + ".log") if "remark:" not in l and "-Rpass" not in l)[-8000:])
+            except OSError:
+                pass
             for f in (o, o + ".d"):  # never leave a half-written object behind
                 if os.path.exists(f):
                     os.remove(f)

@@ -8,7 +8,7 @@
 #   -k     run this slice of the GPU parity suite on every LIB first (a variant that is not bit-exact is not a candidate)
 #   -w     what to time, comma separated (default bench,rounds):
 #            bench        python bench.py --no-cpu-baseline: ms per proof (mean, min), average big-round launch     [config 3, nv=24]
-#            rounds       tools/round_times.py 24: device and wall time per round
+#            rounds       tools/round_times.py 24: device and wall time per round   (-R "25 c4": other arguments, e.g. config 4's shard)
 #            small        tools/small_proofs.py: whole proofs at nv 8..16 (latency-bound rounds)                     [SC_SHAPE=c3|c2|gkr]
 #            configs      tools/bench_configs.py: BASELINE configs 2, README shape, 5                                (+ config 4 with configs4)
 #            gkr          tools/bench_configs.py --only-gkr
@@ -17,8 +17,8 @@
 #   -r     repetitions of the bench / small / configs legs (default 3), interleaved across the LIBs
 # Older builds that lack newer entry points load with SC_AB_ALLOW_MISSING=1 (set here).
 cd "$(dirname "$0")/.."
-K=""; REPS=3; WHAT="bench,rounds"; EXTRA_ENV=""
-while getopts "k:r:w:e:" o; do case $o in k) K=$OPTARG;; r) REPS=$OPTARG;; w) WHAT=$OPTARG;; e) EXTRA_ENV=$OPTARG;; *) exit 2;; esac; done
+K=""; REPS=3; WHAT="bench,rounds"; EXTRA_ENV=""; RARGS="24"
+while getopts "k:r:w:e:R:" o; do case $o in k) K=$OPTARG;; r) REPS=$OPTARG;; w) WHAT=$OPTARG;; e) EXTRA_ENV=$OPTARG;; R) RARGS=$OPTARG;; *) exit 2;; esac; done
 shift $((OPTIND - 1))
 [ $# -ge 1 ] || { sed -n '2,22p' "$0"; exit 2; }
 export SC_AB_ALLOW_MISSING=1
@@ -39,7 +39,7 @@ for rep in $(seq 1 $REPS); do
   done
 done
 for L in "$@"; do
-  if has rounds; then echo "== rounds $L"; env $(libenv $L) timeout 120 python tools/round_times.py 24 2>&1 | sed -n '3,27p'; fi
+  if has rounds; then echo "== rounds $L"; env $(libenv $L) timeout 300 python tools/round_times.py $RARGS 2>&1 | sed -n '3,32p'; fi
   if has interactive; then echo "== interactive $L"; env $(libenv $L) timeout 300 python tools/interactive_time.py 8 12 16 20 2>&1 | grep nv=; fi
   if has tailclocks; then for sh in c3 gkr; do echo "== tail clocks $sh $L"; env $(libenv $L) SC_SHAPE=$sh timeout 200 python tools/tail_clocks.py 12 2>&1 | grep -v amdgpu; done; fi
 done
