@@ -1185,8 +1185,6 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         // One product per block row (k_round_tree_split / k_round1_tree_split): `grid` blocks per product.  Measured per round size on
         // config 3 (profiles/r2e_split_rounds.txt): many small blocks for the rounds that stream tables, fewer for the short ones.
         bool split = !p->fused_finalize;
-        uint32_t max_m = 0;
-        for (uint32_t k = 0; k < p->K; ++k) max_m = std::max(max_m, p->prods[k].M);
         int split_grid = n_pairs >= (1ULL << 21) ? 1024 : n_pairs >= (1ULL << 20) ? 768 : n_pairs >= (1ULL << 18) ? 384 : n_pairs >= (1ULL << 17) ? 256 : 192;
 #ifdef SC_EXPERIMENTS // SC_SPLIT=0: every product in every block (k_round_tree); SC_SPLIT_GRID=n: blocks per product
         static const bool split_off = std::getenv("SC_SPLIT") && std::atoi(std::getenv("SC_SPLIT")) == 0;
@@ -1199,9 +1197,8 @@ static int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wid
         // the streaming rounds of a single row keep one full wave of resident blocks (a second, partial wave would run alone at the end).
 #ifndef SC_NO_KGRID // (A/B build: the per-row counts whatever the number of rows)
         if (p->K < 4 && n_pairs < (1ULL << 21)) split_grid = std::min(scd::kMaxGrid, split_grid * 4 / (int)p->K);
-        else if (p->K == 1) split_grid = std::min(split_grid, max_m <= 3 ? scd::kMaxGrid : scd::kRoundTreeGrid); // (M <= 3: four resident blocks per CU = 1024)
+        else if (p->K == 1) split_grid = std::min(split_grid, scd::kRoundTreeGrid); // (one product: one full wave of resident blocks)
 #else
-        (void)max_m;
         if (p->K == 1) split_grid = std::min(split_grid, scd::kRoundTreeGrid);
 #endif
         if (split) grid = std::min(scd::grid_for_pairs(n_pairs), split_grid);
@@ -1557,22 +1554,8 @@ static int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null
     scd::FinMeta fm;
     std::memset(&fm, 0, sizeof(fm));
     std::memcpy(fm.prod, p->h_finprods.data(), (size_t)p->K * sizeof(FinProd));
-    // rounds as tiles (kernels.h): every shape whose products all fit the carry-free path
-#if defined(SC_TAIL_TILES) && SC_TAIL_TILES == 0 // A/B build: the two-phase form of round 3 (bind, grid barrier, sums)
-    A.tile_log2 = -1;
-#else
-    A.tile_log2 = p->any_generic ? -1 : scd::tail_tile_log2(p->n_combos, (int)p->U);
-#endif
-#ifdef SC_TAIL_SOLO_TILES
-    A.solo_tiles = SC_TAIL_SOLO_TILES;
-#else
-    A.solo_tiles = 2;
-#endif
-    grid = 1; // (the kernel's count of active blocks for the first round)
-    if (A.tile_log2 >= 0) {
-        const uint64_t n_tiles = std::max<uint64_t>(A.first_pairs >> A.tile_log2, 1);
-        if (n_tiles > (uint64_t)A.solo_tiles) grid = (int)std::min<uint64_t>((uint64_t)p->tail_max_blocks, n_tiles);
-    } else if (A.first_pairs > scd::tail_flat_pairs(p->n_combos)) {
+    grid = 1; // (the kernel's tail_active_blocks for the first round)
+    if (A.first_pairs > scd::tail_flat_pairs(p->n_combos)) {
         const uint64_t bind_blocks = (2 * A.first_pairs * p->U + scd::kBlock - 1) / scd::kBlock;
         const uint64_t sum_blocks = ((A.first_pairs + scd::kBlock - 1) / scd::kBlock) * (uint64_t)p->n_combos;
         grid = (int)std::min<uint64_t>((uint64_t)p->tail_max_blocks, std::max(bind_blocks, sum_blocks));

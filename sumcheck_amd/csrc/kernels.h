@@ -137,8 +137,8 @@ struct ComboMeta {
 #define SC_TAIL_MAX_PAIRS 2048
 #endif
 constexpr uint64_t kTailMaxPairs = SC_TAIL_MAX_PAIRS; // rounds above this many pairs are throughput- rather than latency-bound: separate (pipelined) launches
-                                                      // with full-chip grids beat a resident grid that pays a barrier per round
-static_assert(kTailMaxPairs >= 64 && (kTailMaxPairs & (kTailMaxPairs - 1)) == 0 && kTailMaxPairs <= kSmallRoundPairs, "a power of two within the small rounds");
+                                                      // with full-chip grids beat a resident grid that pays a barrier per phase (measured: 32 vs 54 us at 4096 pairs)
+static_assert(kTailMaxPairs / kBlock <= 8 || SC_TAIL_MAX_PAIRS != 2048, "k_tail_rounds' block 0 adds up a combination's partial blocks itself: at most 8 of them");
 constexpr int kTailMaxGrid = 1024; // at most 4 resident blocks per CU (120 VGPRs), all co-resident on a 256-CU device
 constexpr int kTailFlatPairs = 16; // rounds with at most this many pairs run in block 0 alone, one lane per (combination, pair)
 // ... and with few combinations (one product of two or three multiplicands: the GKR phases, configs 1 and 2) up to 64 pairs do: as long as
@@ -175,22 +175,7 @@ struct TailArgs {
                                // word i of slot (sig0 + j) & 1 -- the tag makes every word self-validating, one poll fetches the challenge
     uint32_t sig0;
     uint32_t max_spins;
-    // Rounds as TILES (tile_log2 >= 0; every product within kMaxFusedM multiplicands): a block binds the entries of a tile of 2^tile_log2
-    // pairs of EVERY table into LDS and sums every combination over the same tile from there -- what a block's sums read is what that block
-    // bound, so bind and sums need no grid barrier between them.  Rounds of at most solo_tiles tiles run in block 0 alone.  -1: the
-    // two-phase form (bind, grid barrier, sums; shapes with a product of more than kMaxFusedM multiplicands).
-    int tile_log2;
-    int solo_tiles;
 };
-// LDS of a tile: two planes (even / odd entry of a pair) x 9 limbs x (tables x pairs) ints
-constexpr int kTailTileInts = 6144; // 24 KB
-// pairs per tile for a shape: every (combination, pair) of a tile has its own lane (one pass of sums), the tile's 2 T U binds take at most
-// two passes, the bound tile fits kTailTileInts; at most a wavefront of pairs (the pair sums are shuffles)
-__host__ __device__ constexpr int tail_tile_log2(int n_combos, int n_tables) {
-    int l = 6;
-    while (l > 0 && (((1 << l) * n_combos > kBlock) || (2 * (1 << l) * n_tables > 2 * kBlock) || (18 * (1 << l) * n_tables > kTailTileInts))) --l;
-    return ((1 << l) * n_combos <= kBlock && 2 * (1 << l) * n_tables <= 2 * kBlock && 18 * (1 << l) * n_tables <= kTailTileInts) ? l : -1;
-}
 int tail_max_resident_blocks(int device); // co-resident blocks of the tail kernel (0: unknown -> the tail kernel is not used)
 uint32_t wait_spins_default(); // bound of the device-side polls for a challenge (SC_WAIT_SPINS overrides it: tests)
 hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream); // (a plain kernel: hipMemsetAsync may take runtime paths that wait on other streams)

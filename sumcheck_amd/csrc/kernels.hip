@@ -539,9 +539,6 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
     __shared__ Combo combo_sh[kMetaCombos];
     __shared__ uint32_t slot_table_sh[kMetaSlots], slot_exp_sh[kMetaSlots];
     __shared__ const uint4 *tab_sh[kMaxSmallTables];
-    __shared__ const int32_t *top_sh[kMaxSmallTables]; // tile rounds: the F29 limb-8 array of a table that comes straight from the big rounds
-    __shared__ uint4 *dst_sh[kMaxSmallTables];         // tile rounds: where the round's bound entries go
-    __shared__ int32_t tile_sh[kTailTileInts];         // tile rounds: the bound tile, [plane (entry & 1)][limb][table * T + pair]
     __shared__ int prod_index_sh[kMetaCombos]; // the position (in fin.prod) of each combination's product
     for (int i = threadIdx.x; i < kMetaCombos; i += kBlock) {
         combo_sh[i] = meta.combo[i];
@@ -555,9 +552,6 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
         slot_exp_sh[i] = meta.slot_exp[i];
     }
     auto tab_lds = [&](uint32_t u) -> const uint4 * { return tab_sh[u]; };
-    FeU r32;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r32.l[i] = 0;
     if (threadIdx.x == 0) stop_sh = 0;
     // (keeping block 0's Lagrange weights in registers for the whole launch was measured: eight more live registers, the first spills
     // of this kernel, no change in the round time -- the weights are L2 hits after the first round)
@@ -565,16 +559,11 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
     for (int j = 0; j < A.n_rounds; ++j, n_pairs >>= 1) {
         // The rounds shrink: blocks beyond what this round can use retire for good (the count never grows again), so the barriers of
         // the later rounds synchronise a handful of blocks instead of one per CU, and the last rounds run in block 0 alone.
-        const bool has_bind = j > 0 || A.first_has_bind;
-        // A round as tiles (TailArgs::tile_log2): T pairs per tile, n_tiles tiles dealt to the active blocks round-robin
-        const bool tiled = A.tile_log2 >= 0;
-        const int tlj = tiled ? (int)min((uint64_t)A.tile_log2, (uint64_t)(63 - __builtin_clzll(n_pairs))) : 0; // (a round with fewer pairs than a tile: one smaller tile)
-        const uint32_t T = 1u << tlj, n_tiles = (uint32_t)(n_pairs >> tlj);
-        const uint32_t Gj = tiled ? (n_tiles <= (uint32_t)A.solo_tiles ? 1u : min(G, n_tiles)) : tail_active_blocks(n_pairs, A.n_tables, A.n_combos, G);
+        const uint32_t Gj = tail_active_blocks(n_pairs, A.n_tables, A.n_combos, G);
         if (blockIdx.x >= Gj) return;
         TAIL_STAMP(j, 0); // round start (block 0 has this round's challenge)
         const bool solo = Gj == 1; // no other block left: block barriers are enough
-        if (has_bind) {
+        if (j > 0 || A.first_has_bind) {
             // ---- this round's challenge: round 0's came with the launch; block 0 fetched the later ones from the host itself (below)
             // and the other blocks read them from device memory once block 0 has released them
             if (j == 0) {
@@ -605,9 +594,7 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
             FrHost rh;
 #pragma unroll
             for (int i = 0; i < 4; ++i) rh.l[i] = r_sh[i];
-            r32 = feu_shl5(fru_from_host(rh).v); // the carry-free bind's multiplier: r * 2^5 as 29-bit limbs
-        }
-        if (has_bind && !tiled) {
+            const FeU r32 = feu_shl5(fru_from_host(rh).v); // the carry-free bind's multiplier: r * 2^5 as 29-bit limbs
             // ---- bind: out[b] = in[2b] + r (in[2b+1] - in[2b]), 2 n_pairs outputs per table ------------------------------------
             const uint64_t n_out = 2 * n_pairs; // a power of two
             const int sh = 63 - __builtin_clzll(n_out);
@@ -636,111 +623,10 @@ __global__ __launch_bounds__(kBlock) void k_tail_rounds(const TailArgs A, const 
                 return;
             }
         }
-        if (threadIdx.x < (uint32_t)A.n_tables) { // where this round's tables are (tile rounds: as they are BEFORE the bind, and where the bound entries go)
-            tab_sh[threadIdx.x] = tab(threadIdx.x);
-            top_sh[threadIdx.x] = binds == 0 ? A.t.cur0_top[threadIdx.x] : nullptr;
-            dst_sh[threadIdx.x] = (binds & 1) ? A.t.b1[threadIdx.x] : A.t.b0[threadIdx.x];
-        }
+        if (threadIdx.x < (uint32_t)A.n_tables) tab_sh[threadIdx.x] = tab(threadIdx.x); // where this round's tables are
         __syncthreads();
         TAIL_STAMP(j, 1); // bound (and barrier passed)
-        if (tiled) {
-            // ---- the round as tiles.  Per tile: (1) lane i binds entry (table i / 2T, entry i % 2T) of the tile -- the round's table entry
-            // ge = 2 T tile + e from entries 2 ge, 2 ge + 1 of the table before the bind (a round that binds nothing just loads entry ge) --
-            // and parks it in LDS as nine 29-bit limbs, even and odd entries in separate planes; (2) lane (combination c, pair p) multiplies
-            // its slots' (lo, hi) from LDS and adds the product to its running sum; (3) the bound entries go to memory, canonical, for the
-            // next round -- after the sums, off their critical path.  What a block's sums read is what that block bound: no grid barrier
-            // between bind and sums, no trip through memory.  After its tiles a block adds up each combination's T pair lanes (shuffles)
-            // and leaves ONE partial per combination (the layout finalize reads, with the active blocks as the partial blocks).
-            const uint32_t n_bind = 2u * T * (uint32_t)A.n_tables, UT = T * (uint32_t)A.n_tables;
-            const bool sum_lane = threadIdx.x < ((uint32_t)A.n_combos << tlj);
-            const uint32_t ci = sum_lane ? (threadIdx.x >> tlj) : 0u, pp = threadIdx.x & (T - 1u);
-            const Combo c = combo_sh[ci];
-            const int32_t nv = node_value((int)c.t);
-            Fe acc = fe_zero();
-            uint32_t iter = 0;
-            for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += Gj, ++iter) {
-                Fe keep[2];
-#pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-                    const uint32_t i = (uint32_t)pass * kBlock + threadIdx.x;
-                    if (i < n_bind) {
-                        const uint32_t u = i >> (tlj + 1), e = i & (2u * T - 1u);
-                        const uint64_t ge = ((uint64_t)tile << (tlj + 1)) + e;
-                        const uint4 *src = tab_sh[u];
-                        const int32_t *stop = top_sh[u];
-                        Fe v;
-                        if (has_bind) {
-                            Fe lo, hi;
-                            if (stop) { // the table arrives from the big rounds in F29, leaves canonical
-                                const int2 t = *reinterpret_cast<const int2 *>(stop + 2 * ge);
-                                lo = fe_load_f29(src, 2 * ge, t.x);
-                                hi = fe_load_f29(src, 2 * ge + 1, t.y);
-                            } else {
-                                lo = fe_from_fr(fr_load(src + 4 * ge));
-                                hi = fe_from_fr(fr_load(src + 4 * ge + 2));
-                            }
-                            v = fe_carry_pass(fe_add(lo, fe_mul_u<true>(fe_sub(hi, lo), r32)));
-                        } else {
-                            v = stop ? fe_load_f29(src, ge, stop[ge]) : fe_from_fr(fr_load(src + 2 * ge));
-                        }
-                        int32_t *q = tile_sh + (e & 1u) * 9u * UT + u * T + (e >> 1);
-#pragma unroll
-                        for (int l = 0; l < 9; ++l) q[l * UT] = v.l[l];
-                        keep[pass] = v;
-                    }
-                }
-                __syncthreads();
-                if (sum_lane) {
-                    Fe prod = fe_zero();
-                    bool first = true;
-                    for (uint32_t sI = 0; sI < c.n_slots; ++sI) {
-                        const int32_t *q = tile_sh + slot_table_sh[c.slot_off + sI] * T + pp;
-                        Fe lo, hi;
-#pragma unroll
-                        for (int l = 0; l < 9; ++l) {
-                            if (nv != 1) lo.l[l] = q[l * UT];
-                            if (nv != 0) hi.l[l] = q[(9 + l) * UT];
-                        }
-                        const Fe val = nv == 0 ? lo : (nv == 1 ? hi : fe_line(lo, hi, nv));
-                        uint32_t k = 0;
-                        if (first) { prod = val; k = 1; first = false; }
-                        for (const uint32_t ex = slot_exp_sh[c.slot_off + sI]; k < ex; ++k) prod = fe_mul<true>(val, prod);
-                    }
-                    acc = fe_carry_pass(fe_add(acc, prod));
-                    if ((iter & 31u) == 31u) acc = fe_from_fr(fe_to_fr(acc)); // keep the top limb far from 2^31 over many tiles
-                }
-                if (has_bind) {
-#pragma unroll
-                    for (int pass = 0; pass < 2; ++pass) {
-                        const uint32_t i = (uint32_t)pass * kBlock + threadIdx.x;
-                        if (i < n_bind) {
-                            const uint32_t u = i >> (tlj + 1), e = i & (2u * T - 1u);
-                            fr_store(dst_sh[u] + 2 * (((uint64_t)tile << (tlj + 1)) + e), fe_to_fr(keep[pass]));
-                        }
-                    }
-                }
-                __syncthreads(); // the next tile overwrites the LDS
-            }
-            Fr ssum = sum_lane ? fe_to_fr(acc) : fr_zero();
-            for (uint32_t off = T >> 1; off >= 1; off >>= 1) ssum = fr_add(ssum, fr_shfl_down(ssum, (int)off));
-            if (sum_lane && pp == 0) {
-                if (solo) fr_store(fin_lds + 2 * (prod_index_sh[ci] * A.D + (int)c.t), ssum); // scratch[k * D + t]
-                else fr_store(A.partials + 2 * (c.partial_off + (uint64_t)c.t * Gj + blockIdx.x), ssum);
-            }
-            if (has_bind) binds += 1;
-            if (solo) {
-                __syncthreads();
-                TAIL_STAMP(j, 2); // node sums ready
-                finalize_message<kBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 1, w_pre);
-            } else {
-                if (!grid_barrier(A.sync, gen, Gj, bar_spins, A.sig + 1, A.sig0 + (uint32_t)j + 1u, stop_sh)) return;
-                TAIL_STAMP(j, 2); // partial sums ready (barrier passed)
-                if (blockIdx.x == 0) {
-                    finalize_body<kBlock>(prod_of, A.Wm, A.K, A.D, (int)Gj, A.partials, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag,
-                                          A.seq0 + (uint32_t)j, 1, w_pre);
-                }
-            }
-        } else if (solo) {
+        if (solo) {
             // ---- flat mode: lane i of the block = (combination i / n_pairs, pair i % n_pairs); the pairs of a combination are
             // n_pairs adjacent lanes of one wavefront, summed by log2(n_pairs) shuffles; the sums go straight to finalize's scratch
             const int shp = 63 - __builtin_clzll(n_pairs);

@@ -236,7 +236,7 @@ struct LoadFactor {
 // one product's pass of a block over its share of the pairs: row = this block's M+1 partial sums of that product
 // kSkip1: node 1's sum is not computed -- the finalize step derives it from the previous round (S(0) + S(1) = that round's
 // polynomial at the challenge, product by product: ClaimArgs in kernels.h); binding rounds only
-template <int M, bool kR1 = false, bool kChain = kChainDefault, bool kSkip1 = false, bool kTwoPairs = true>
+template <int M, bool kR1 = false, bool kChain = kChainDefault, bool kSkip1 = false>
 __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBindLds], const uint64_t n_pairs, uint4 *__restrict__ row, uint32_t (*sm)[8],
                                           int32_t *lacc) {
     // The M+1 running sums live in LDS (limb-planar, one column per thread: lacc[(9 t + limb) * kBlock + tid], conflict-free and
@@ -258,7 +258,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
 #else
     constexpr bool kM4Pairs = kR1;
 #endif
-    if constexpr (kTwoPairs && (M == 2 || M == 3 || (M == 4 && kM4Pairs))) {
+    if constexpr (M == 2 || M == 3 || (M == 4 && kM4Pairs)) {
         for (; b + stride < n_pairs; b += 2 * stride, ++iter) {
             Fe P[M + 1];
             const uint64_t b2 = b + stride;
@@ -744,31 +744,22 @@ __global__ __launch_bounds__(kBlock, 3) void k_round1_tree_split(const RoundArgs
     }
 }
 // kChain: single-chain multiply-adds (fe_device.hpp) -- the instantiation for a proof's first binding round, whose sources are canonical.
-// kMaxM: the longest product of the launch.  With at most THREE multiplicands per product (BASELINE configs 2 and 4, the GKR phases)
-// the running sums need four nodes instead of five (36.9 KB of LDS), and with ONE pair per iteration (no shared reductions: these
-// rounds wait for memory, not for the multiplier) the pass fits 128 registers: FOUR resident blocks per CU instead of three -- a third
-// more wavefronts in flight for rounds that stream tables at 7 products per pair.
-#ifdef SC_M3_TWO_PAIRS // A/B build: the three-multiplicand instantiations keep two pairs per iteration (they spill at 128 registers)
-constexpr bool kM3TwoPairs = true;
-#else
-constexpr bool kM3TwoPairs = false;
-#endif
-template <bool kChain, bool kSkip1, int kMaxM>
-__global__ __launch_bounds__(kBlock, kMaxM <= 3 ? 4 : 3) void k_round_tree_split(const RoundArgs R, const BindConst r, const uint64_t n_pairs, uint4 *__restrict__ partials) {
+// (Round 4 measured instantiations for launches whose products all have at most three multiplicands -- four nodes of running sums, one
+// pair per iteration, 113-116 registers, FOUR resident blocks per CU -- on config 4's shapes: no change beyond box noise,
+// profiles/r4c_config4_m3_occupancy_ab.txt; those rounds already move their real bytes at 5.2-5.3 TB/s.  Not kept.)
+template <bool kChain, bool kSkip1>
+__global__ __launch_bounds__(kBlock, 3) void k_round_tree_split(const RoundArgs R, const BindConst r, const uint64_t n_pairs, uint4 *__restrict__ partials) {
     __shared__ uint32_t sm[kBlock / 64][8];
     __shared__ int32_t rt[kBindLds];
-    __shared__ int32_t lacc[9 * (kMaxM + 1) * kBlock];
+    __shared__ int32_t lacc[9 * 5 * kBlock];
     bind_consts_to_lds(r, rt);
     const TreeProd &T = R.prod[blockIdx.y];
     uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x);
-    constexpr bool kTwo = kMaxM >= 4 || kM3TwoPairs;
     switch (T.M) {
-    case 1: tree_pass<1, false, kChain, kSkip1, kTwo>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    case 2: tree_pass<2, false, kChain, kSkip1, kTwo>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    case 3: tree_pass<3, false, kChain, kSkip1, kTwo>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    default:
-        if constexpr (kMaxM >= 4) tree_pass<4, false, kChain, kSkip1, kTwo>(T.slot, rt, n_pairs, row, sm, lacc);
-        break;
+    case 1: tree_pass<1, false, kChain, kSkip1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 2: tree_pass<2, false, kChain, kSkip1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 3: tree_pass<3, false, kChain, kSkip1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    default: tree_pass<4, false, kChain, kSkip1>(T.slot, rt, n_pairs, row, sm, lacc); break;
     }
 }
 
@@ -882,32 +873,15 @@ hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64
         for (uint32_t f = 0; f < args.prod[q].M; ++f) canonical_sources = canonical_sources && args.prod[q].slot[f].src_top == nullptr;
     const dim3 g(grid, args.n_prod), b(kBlock);
     uint4 *const part = (uint4 *)d_partials;
-    uint32_t max_m = 0;
-    for (int q = 0; q < args.n_prod; ++q) max_m = std::max(max_m, args.prod[q].M);
-#ifdef SC_NO_M3_KERNELS // A/B build: every shape through the five-node, three-blocks-per-CU instantiations
-    const bool m3 = false;
-#else
-    const bool m3 = max_m <= 3;
-#endif
     if (round1) {
         if (skip1) return hipErrorInvalidValue; // (round 1 has no previous round)
         hipLaunchKernelGGL(k_round1_tree_split, g, b, 0, stream, args, n_pairs, part);
     } else if (canonical_sources) {
-        if (m3) {
-            if (skip1) hipLaunchKernelGGL((k_round_tree_split<true, true, 3>), g, b, 0, stream, args, r32, n_pairs, part);
-            else hipLaunchKernelGGL((k_round_tree_split<true, false, 3>), g, b, 0, stream, args, r32, n_pairs, part);
-        } else {
-            if (skip1) hipLaunchKernelGGL((k_round_tree_split<true, true, 4>), g, b, 0, stream, args, r32, n_pairs, part);
-            else hipLaunchKernelGGL((k_round_tree_split<true, false, 4>), g, b, 0, stream, args, r32, n_pairs, part);
-        }
+        if (skip1) hipLaunchKernelGGL((k_round_tree_split<true, true>), g, b, 0, stream, args, r32, n_pairs, part);
+        else hipLaunchKernelGGL((k_round_tree_split<true, false>), g, b, 0, stream, args, r32, n_pairs, part);
     } else {
-        if (m3) {
-            if (skip1) hipLaunchKernelGGL((k_round_tree_split<kChainDefault, true, 3>), g, b, 0, stream, args, r32, n_pairs, part);
-            else hipLaunchKernelGGL((k_round_tree_split<kChainDefault, false, 3>), g, b, 0, stream, args, r32, n_pairs, part);
-        } else {
-            if (skip1) hipLaunchKernelGGL((k_round_tree_split<kChainDefault, true, 4>), g, b, 0, stream, args, r32, n_pairs, part);
-            else hipLaunchKernelGGL((k_round_tree_split<kChainDefault, false, 4>), g, b, 0, stream, args, r32, n_pairs, part);
-        }
+        if (skip1) hipLaunchKernelGGL((k_round_tree_split<kChainDefault, true>), g, b, 0, stream, args, r32, n_pairs, part);
+        else hipLaunchKernelGGL((k_round_tree_split<kChainDefault, false>), g, b, 0, stream, args, r32, n_pairs, part);
     }
     return hipGetLastError();
 }
