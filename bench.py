@@ -140,6 +140,12 @@ def cpu_baseline(shapes, n_tables, nv_full=24, budget_s=12.0):
     enters `whole_prove`.  The all-cores proof of the full-size instance is kept: bench.py compares the GPU proofs with it."""
     from oracle import cref
     threads = cref.max_threads()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("OMP_NUM_THREADS") == "1":
+        # torch.distributed.run exports OMP_NUM_THREADS=1 to every rank it starts unless the caller set it.  The CPU leg is rank 0's
+        # alone (the other ranks wait) and is meant to use the host's cores: the hardware threads, capped by the container's quota.
+        q = cref.cpu_quota_cores()
+        hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = max(1, min(hw, q) if q else hw)
     coefs = cref.synth_table(SEED, 1000, len(shapes))
 
     def run(nv, nthreads, improved=False):
@@ -711,6 +717,8 @@ def self_launch(args):
                os.path.abspath(__file__)] + sys.argv[1:]
         log(f"[bench] --gpus {N} without a launcher: starting {N} ranks: {' '.join(cmd[1:9])} bench.py ...")
         env = dict(os.environ, SC_BENCH_SELF_LAUNCHED="1")
+        if "OMP_NUM_THREADS" not in env:  # (torch.distributed.run would set it to 1 for every rank: rank 0's CPU leg wants the cores)
+            env["OMP_NUM_THREADS"] = str(os.cpu_count() or 1)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
         line, _ = last_json_line(r.stdout)

@@ -2640,8 +2640,13 @@ struct NcclApi {
 static NcclApi g_nccl;
 static int nccl_load() {
     if (g_nccl.lib) return SC_OK;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // A copy the process has already mapped (PyTorch-ROCm ships its own librccl) is the one to use: two RCCLs in one process is one too
+    // many.  Nothing is promoted to the global namespace (RTLD_LOCAL): the entry points are taken with dlsym from this handle, and the
+    // host process's own symbol resolution is left alone.
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) return fail(SC_ERR_HIP, "cannot load librccl: %s", dlerror());
     g_nccl.GetUniqueId = reinterpret_cast<decltype(&ncclGetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     g_nccl.CommInitRank = reinterpret_cast<decltype(&ncclCommInitRank)>(dlsym(h, "ncclCommInitRank"));

@@ -29,6 +29,7 @@
 // sub), the other <= 2^29 (normalised, or a difference of two normalised values).  Then every column is below
 // 9*2^59 + 8*2^58 + carry < 2^63 in magnitude.  Values (not limbs) stay below 2^259 in magnitude, results below 2^257 + p.
 #pragma once
+#include <utility>
 #include "fr_device.hpp"
 #include "kernels.h"
 
@@ -199,20 +200,101 @@ __device__ __forceinline__ void fe_mad_k(int64_t &acc, const int32_t a, const in
     if constexpr (kChain) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(k) : "vcc");
     else acc += (int64_t)a * (int64_t)k;
 }
+#include "fe_mad_chain.inc" // mad_chain_vv / mad_chain_vs: a column's multiply-adds as ONE asm statement (tools/gen_mad_chain.py)
+#ifdef SC_CHAIN_PER_MAD // A/B build: one asm statement per multiply-add (each followed by the hazard recogniser's s_nop)
+constexpr bool kChainColumns = false;
+#else
+constexpr bool kChainColumns = true;
+#endif
 #ifdef SC_MAD_CHAIN // A/B build: the written-out chain everywhere
 constexpr bool kChainDefault = true;
 #else
 constexpr bool kChainDefault = false;
 #endif
 
+// Column k of a 9 x 9 limb product: its operand products a_i b_{k-i} and its reduction products m_j (-p_{k-j}), as compile-time
+// counts -- the written-out chains (kChain) issue a column as ONE asm statement selected by these (MadMix, fe_mad_chain.inc).
+__host__ __device__ constexpr int fe_col_n(int k) { return (k < 8 ? k : 8) - (k > 8 ? k - 8 : 0) + 1; }
+__host__ __device__ constexpr int fe_col_nr(int k) { // j < k, 1 <= k - j <= 8, j <= 8
+    int c = 0;
+    for (int j = 0; j < 9; ++j) c += (j < k && k - j >= 1 && k - j < 9) ? 1 : 0;
+    return c;
+}
+template <int K, typename B>
+__device__ __forceinline__ void fe_col_chain(int64_t &acc, const Fe &a, const B &b, const int32_t (&m)[9]) {
+    constexpr int n = fe_col_n(K), nr = fe_col_nr(K);
+    int32_t xa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, xb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, xm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, xk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int q = 0, qr = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int j = K - i;
+        if (j >= 0 && j < 9) { xa[q] = a.l[i]; xb[q] = b.l[j]; ++q; }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int l = K - j;
+        if (j < K && l >= 1 && l < 9) { xm[qr] = m[j]; xk[qr] = -fe_p_limb(l); ++qr; }
+    }
+    if constexpr (nr == 0) mad_chain_vv(acc, xa, xb, n);
+    else MadMix<n, nr>::run(acc, xa, xb, xm, xk);
+}
+// the same for (a b + c d): the a b products as one statement, the c d products with the reduction products as another
+template <int K>
+__device__ __forceinline__ void fe_col2_chain(int64_t &acc, const Fe &a, const Fe &b, const Fe &c, const Fe &d, const int32_t (&m)[9]) {
+    constexpr int n = fe_col_n(K), nr = fe_col_nr(K);
+    int32_t xa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, xb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, xc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, xd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t xm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, xk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int q = 0, qr = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int j = K - i;
+        if (j >= 0 && j < 9) { xa[q] = a.l[i]; xb[q] = b.l[j]; xc[q] = c.l[i]; xd[q] = d.l[j]; ++q; }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int l = K - j;
+        if (j < K && l >= 1 && l < 9) { xm[qr] = m[j]; xk[qr] = -fe_p_limb(l); ++qr; }
+    }
+    mad_chain_vv(acc, xa, xb, n);
+    if constexpr (nr == 0) mad_chain_vv(acc, xc, xd, n);
+    else MadMix<n, nr>::run(acc, xc, xd, xm, xk);
+}
+// the Montgomery bookkeeping between columns (subtractive steps: the low 29 bits are the next multiplier, or a limb of the result)
+template <int K>
+__device__ __forceinline__ void fe_col_finish(int64_t &acc, int32_t (&m)[9], Fe &r) {
+    if constexpr (K < 9) m[K] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask);
+    else r.l[K - 9] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask);
+    acc >>= 29;
+}
+template <typename B, int... K>
+__device__ __forceinline__ Fe fe_mul_chain_cols(const Fe &a, const B &b, std::integer_sequence<int, K...>) {
+    int64_t acc = 0;
+    int32_t m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Fe r;
+    ((fe_col_chain<K, B>(acc, a, b, m), fe_col_finish<K>(acc, m, r)), ...);
+    r.l[8] = (int32_t)acc;
+    return r;
+}
+template <int... K>
+__device__ __forceinline__ Fe fe_mul2_chain_cols(const Fe &a, const Fe &b, const Fe &c, const Fe &d, std::integer_sequence<int, K...>) {
+    int64_t acc = 0;
+    int32_t m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Fe r;
+    ((fe_col2_chain<K>(acc, a, b, c, d, m), fe_col_finish<K>(acc, m, r)), ...);
+    r.l[8] = (int32_t)acc;
+    return r;
+}
+
 // a * b / 2^261 (mod p), result value in (a b / 2^261 - p, a b / 2^261], i.e. |.| < 2^257 + p; result limbs 0..7 in [0, 2^29), limb 8 signed and small.
 template <typename B, bool kChain = kChainDefault>
 __device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {
+    if constexpr (kChain && kChainColumns) return fe_mul_chain_cols<B>(a, b, std::make_integer_sequence<int, 17>{});
     int64_t acc = 0;
     int32_t m[9];
     Fe r;
 #pragma unroll
     for (int k = 0; k <= 16; ++k) {
+        {
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int j = k - i;
@@ -222,6 +304,7 @@ __device__ __forceinline__ Fe fe_mul_t(const Fe &a, const B &b) {
         for (int j = 0; j < 9; ++j) {
             const int l = k - j;
             if (j < k && l >= 1 && l < 9) fe_mad_k<kChain>(acc, m[j], -fe_p_limb(l));
+        }
         }
         if (k < 9) {
             m[k] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask); // subtracting m p_0 = m clears the low 29 bits: that IS the shift below
@@ -240,11 +323,13 @@ __device__ __forceinline__ Fe fe_mul(const Fe &a, const Fe &b) { return fe_mul_t
 // column is within 18 * 2^58.01 + 8 * 2^58 + carry < 2^63 in magnitude.
 template <bool kChain = kChainDefault>
 __device__ __forceinline__ Fe fe_mul2_sum(const Fe &a, const Fe &b, const Fe &c, const Fe &d) {
+    if constexpr (kChain && kChainColumns) return fe_mul2_chain_cols(a, b, c, d, std::make_integer_sequence<int, 17>{});
     int64_t acc = 0;
     int32_t m[9];
     Fe r;
 #pragma unroll
     for (int k = 0; k <= 16; ++k) {
+        {
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int j = k - i;
@@ -257,6 +342,7 @@ __device__ __forceinline__ Fe fe_mul2_sum(const Fe &a, const Fe &b, const Fe &c,
         for (int j = 0; j < 9; ++j) {
             const int l = k - j;
             if (j < k && l >= 1 && l < 9) fe_mad_k<kChain>(acc, m[j], -fe_p_limb(l));
+        }
         }
         if (k < 9) {
             m[k] = (int32_t)((uint32_t)acc & (uint32_t)kFeMask);
@@ -309,11 +395,26 @@ __device__ __forceinline__ Fe fe_mul_bind(const Fe &d, const int32_t (&RT)[kBind
                 n1 = *reinterpret_cast<const int4 *>(q + 12 * (k + 1) + 4);
                 n2 = q[12 * (k + 1) + 8];
             }
+            if constexpr (kChain && kChainColumns) { // the column's nine products and its one or two reduction products as one statement
+                const int32_t xd[9] = {d.l[0], d.l[1], d.l[2], d.l[3], d.l[4], d.l[5], d.l[6], d.l[7], d.l[8]};
+                int32_t xm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, xk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                int nr = 0;
+                if (k >= 1) { xm[nr] = m0; xk[nr] = -fe_p_limb(k); ++nr; }
+                if (k >= 2) { xm[nr] = m1; xk[nr] = -fe_p_limb(k - 1); ++nr; }
+                if (nr == 0) mad_chain_vv(acc, xd, c, 9);
+                else if (nr == 1) MadMix<9, 1>::run(acc, xd, c, xm, xk);
+                else MadMix<9, 2>::run(acc, xd, c, xm, xk);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) fe_mad<kChain>(acc, d.l[i], c[i]);
+                for (int i = 0; i < 9; ++i) fe_mad<kChain>(acc, d.l[i], c[i]);
+            }
         }
-        if (k >= 1 && k < 9) fe_mad_k<kChain>(acc, m0, -fe_p_limb(k));
-        if (k >= 2) fe_mad_k<kChain>(acc, m1, -fe_p_limb(k - 1));
+        if constexpr (!(kChain && kChainColumns)) {
+            if (k >= 1 && k < 9) fe_mad_k<kChain>(acc, m0, -fe_p_limb(k));
+        }
+        if (!(kChain && kChainColumns) || k == 9) {
+            if (k >= 2) fe_mad_k<kChain>(acc, m1, -fe_p_limb(k - 1));
+        }
         if (k == 0) {
             m0 = (int32_t)((uint32_t)acc & (uint32_t)kFeMask); // subtractive steps, as in fe_mul_t
         } else if (k == 1) {

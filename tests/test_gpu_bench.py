@@ -81,6 +81,7 @@ def test_bench_two_gpus_as_the_driver_types_it():
     d = _two_ranks(["--nv", "16"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    assert d["cpu_baseline"]["cores"] >= min(2, os.cpu_count() or 1)  # (not the OMP_NUM_THREADS=1 a launcher hands its ranks)
     par = d["parity"]
     assert par["ok"] is True and par["rounds_equal"] == 16 and par["rounds_equal_after_timed_region"] == 16 and par["ranks_compared"] == 2, par
     c = d["config"]

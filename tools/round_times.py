@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Per-round device time (HIP events around each round's kernels, no profiler) and wall time: tools/round_times.py [nv] [c3|c4]
-(c3: config 3's four products over ten tables, default; c4: config 4's one product of three)."""
+(c3: config 3's four products over ten tables, default; c4: config 4's one product of three; gkr: one product of two, a GKR phase)."""
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sumcheck_amd as sc
 from sumcheck_amd import _lib
 nv = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-shapes = [[0, 1, 2]] if (len(sys.argv) > 2 and sys.argv[2] == "c4") else [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]
+shapes = {"c4": [[0, 1, 2]], "gkr": [[0, 1]]}.get(sys.argv[2] if len(sys.argv) > 2 else "c3", [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]])
 NT = 1 + max(max(s) for s in shapes)
 dev = torch.device("cuda:0")
 tabs = []
