@@ -52,7 +52,7 @@ C3_SHAPES = [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]
 C4_SHAPES = [[0, 1, 2]]
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FE_MUL_CEILING_PER_S = 160e9  # the carry-free product's in-kernel rate, chip-wide (profiles/r1_modmul_ceiling.txt, tools/modmul_bench.py)
-BIG_ROUND_MIN_PAIRS_LOG2 = 17  # rounds with at least 2^17 pairs (more than kernels.h's kSmallRoundPairs = 2^16) run the merged big-round kernel
+BIG_ROUND_MIN_PAIRS_LOG2 = 15  # rounds with at least 2^15 pairs (more than kernels.h's kSmallRoundPairs = 2^14) run the merged big-round kernel
 
 
 def field_ops(nv, shapes, n_tables):
@@ -559,14 +559,16 @@ def run_rank(args, W, result):
         ops = field_ops(nv_total, shapes, U)
         value = ops * args.steps / elapsed
         # dominant kernel: the merged big-round launch (every product of the round, one product per block row), launched once per BIG
-        # round (more than 2^16 pairs on this GPU; later rounds are latency-bound and run through the small-round kernels).
+        # round (more than 2^14 pairs on this GPU; later rounds are latency-bound and run through the small-round kernels).
         # Algorithmic bytes of those launches: round 1 reads the tables once; round i >= 2 reads T_{i-1} and writes T_i.
         dom = int(np.argmax(list(ms)))
         merged = ln[0] > 0 and all(ln[q] == 0 for q in range(1, K))
         u_dom = U if merged else len(set(shapes[dom]))
         kname = "k_round_tree" if merged else f"k_prod_tree<{len(shapes[dom])}>"  # (round 1 runs its own instantiation, k_round1_tree)
-        big_rounds = max(nv_local - 17, 1) if nv_local > 17 else 0
-        big_bytes = 32 * u_dom * ((1 << nv_local) + sum((1 << (nv_local - i + 2)) + (1 << (nv_local - i + 1)) for i in range(2, big_rounds + 1)))
+        # (which rounds those are is taken from the events themselves: the rounds whose launch recorded one)
+        big_idx = [i for i in range(1, nv_local + 1) if rln_acc[i - 1] > 0] or list(range(1, max(nv_local - BIG_ROUND_MIN_PAIRS_LOG2, 0) + 1))
+        big_rounds = len(big_idx)
+        big_bytes = sum(round_bytes(nv_local, u_dom, i) for i in big_idx)
         launches = int(ln[dom])
         avg_ms = ms[dom] / max(launches, 1)
         bytes_per_launch = big_bytes * ev_steps / max(launches, 1)
@@ -599,7 +601,7 @@ def run_rank(args, W, result):
         except Exception as e:
             traffic_source = f"not reported: {type(e).__name__}: {e}"
         # rounds_ms: event span of the rounds launched with events = the big rounds (late rounds are pipelined and record none)
-        big_all_bytes = 32 * U * ((1 << nv_local) + sum((1 << (nv_local - i + 2)) + (1 << (nv_local - i + 1)) for i in range(2, big_rounds + 1)))
+        big_all_bytes = sum(round_bytes(nv_local, U, i) for i in big_idx)
         big_rounds_gbps = big_all_bytes * ev_steps / (rounds_ms_total * 1e-3) / 1e9 if rounds_ms_total > 0 else 0.0
         cfg_name = ("BASELINE config 4" if args.config == 4 else "BASELINE config 3") + (f", {scaling} scaling" if world > 1 else "")
         ref_muls = reference_muls(nv_total, shapes, U)

@@ -1345,6 +1345,10 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     if ((rc = stage_in(mem, f1_idx, nnz, dev, &d_idx, s)) || (rc = stage_in(mem, f1_vals, nnz, dev, &d_vals, s)) ||
         (rc = stage_in(mem, f2, N, dev, &d_f2, s)) || (rc = stage_in(mem, f3, N, dev, &d_f3, s)))
         return rc;
+    // Host inputs: the copies above are asynchronous on `s`, and the second stream (non-blocking: no implicit ordering with `s`) reads the
+    // staged indices below while phase one runs -- it must not start before they have landed.  (Found in round 4 as a one-in-fifteen
+    // mismatch of phase two's messages at dim = 1 in the GPU suite; device-resident inputs were never affected.)
+    if (!dev) G_TRY(hipStreamSynchronize(s));
     lap("h2d");
     // Bucketed initialisation (k_bucket_accumulate) whenever the list is dense enough for 2^dim cells to be worth a pass; the list form (sort, merge, scatter:
     // what sc_gkr_phase_one returns to a caller) otherwise, and when a bucket is too crowded.  SC_GKR_DIRECT=0 forces the list form.

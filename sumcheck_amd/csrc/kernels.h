@@ -9,7 +9,11 @@ constexpr int kBlock = 256;    // 4 wavefronts of 64
 constexpr int kMaxFusedM = 8;  // products up to this many multiplicands run register-resident and fused with the bind
 constexpr int kMaxGrid = 1024; // 256 CUs x 4 resident 256-thread blocks; longer ranges are grid-strided
 constexpr int kMaxSmallTables = 32;         // table-pointer block that fits a kernel argument
-constexpr uint64_t kSmallRoundPairs = 1u << 16; // rounds at or below this many pairs are latency-bound: split finer
+constexpr uint64_t kSmallRoundPairs = 1u << 14; // rounds at or below this many pairs are latency-bound: split finer (bind launch + one lane per
+                                                // (combination, pair)).  2^16 until round 4: at 2^16 and 2^15 pairs that pair of launches moves 2.2x
+                                                // the bytes of the fused tree kernel (every node's combination re-reads its product's tables) and
+                                                // is memory-bound, 95 and 58 us a round; swept again with this round's kernels: 2^14 is the minimum
+                                                // (config 3 5.125 -> 5.07 ms same-box, profiles/r4l_small_boundary_sweep.txt)
 
 struct FrHost {
     uint64_t l[4];

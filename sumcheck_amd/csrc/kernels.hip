@@ -27,7 +27,7 @@
 //   k_round_tile<M>    LDS-tiled variant (SC_KERNEL=2), a measured negative result.
 //   k_fold_multi<L>    evaluation at a point: all tables, L <= 3 variables per pass (sc_poly_evaluate).
 //   k_sum_generic/k_fix  any M, any aliasing pattern; used beyond kMaxFusedM and for > 32 tables.
-//   k_fix_multi + k_sum_combos   latency-oriented pair for rounds with <= 2^16 pairs.
+//   k_fix_multi + k_sum_combos   latency-oriented pair for rounds with <= 2^14 pairs (kSmallRoundPairs).
 //   k_tail_rounds      every round with <= 2048 pairs in one persistent launch (grid barrier, host mailbox).
 //   k_finalize_mb, k_finalize   partial sums -> round message (Lagrange matrix, c_k, sum over products).
 #include "kernel_common.hpp"

@@ -1,4 +1,4 @@
-// kernels_big.hip -- the big-round kernels of the sumcheck prover hot path (rounds with more than 2^16 pairs): the fused bind + sum
+// kernels_big.hip -- the big-round kernels of the sumcheck prover hot path (rounds with more than kSmallRoundPairs = 2^14 pairs): the fused bind + sum
 // over the hypercube (reference src/ml_sumcheck/protocol/prover.rs:84-89 + 110-148) as a static product tree in carry-free arithmetic.
 // Its own translation unit so that it compiles beside kernels.hip (both are minutes of hipcc); see kernels.hip for the overview.
 #include "kernel_common.hpp"

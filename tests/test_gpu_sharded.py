@@ -327,6 +327,93 @@ def test_sharded_proof_world1_rccl():
         assert np.array_equal(proof, want) and np.array_equal(rand, wrand)
 
 
+def _comm_probe(c, kind, G):
+    """sc_comm_info and sc_comm_exchange_bench on a live communicator"""
+    r, n, k = C.c_int(), C.c_int(), C.c_int()
+    _lib.check(sc.lib().sc_comm_info(c._h, C.byref(r), C.byref(n), C.byref(k)))
+    assert (n.value, k.value) == (G, kind) and 0 <= r.value < G
+    mean, mn = C.c_double(), C.c_double()
+    _lib.check(sc.lib().sc_comm_exchange_bench(c._h, 40, 20, C.byref(mean), C.byref(mn)))  # 40 words = a degree-4 message
+    assert 0 < mn.value <= mean.value
+    assert sc.lib().sc_comm_exchange_bench(c._h, 65, 1, C.byref(mean), None) == _lib.SC_ERR_BAD_ARG  # more words than an inbox slot holds
+    return r.value
+
+
+def test_comm_info_and_exchange_bench_on_every_kind_of_communicator():
+    """the measurement hooks bench.py's N > 1 line uses (config.ranks_seen / config.exchange), on one GPU: RCCL with one rank, the
+    peer-to-peer communicator and the host transport with thread ranks; the publish timeout is a process-wide setting"""
+    _lib.check(sc.lib().sc_set_device(0))
+    c = sharded.NativeComm("cuda:0")
+    assert _comm_probe(c, 1, 1) == 0
+    c.close()
+    for kind in (3, 2):
+        G = 4
+        _P2P_GROUP[0] += 1
+        gid = _P2P_GROUP[0]
+        ex = sharded.ThreadExchange(G)
+        out = [None] * G
+
+        def work(rank):
+            try:
+                _lib.check(sc.lib().sc_set_device(0))
+                c = sharded.P2PComm(gid, rank, G, "cuda:0") if kind == 3 else ex.comm(rank)
+                out[rank] = _comm_probe(c, kind, G)
+                c.close()
+            except Exception as e:  # noqa: BLE001
+                out[rank] = e
+        ts = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+        assert out == list(range(G)), out
+    assert sc.lib().sc_set_publish_timeout_ms(5000) == 0 and sc.lib().sc_set_publish_timeout_ms(0) == 0  # (0 restores the default)
+
+
+def test_peer_to_peer_refuses_messages_longer_than_an_inbox_slot_before_touching_the_handle():
+    """a product of 8 multiplicands has 9 evaluations = 72 words > 64.  sc_ml_prove_sharded over a p2p communicator must
+    refuse it up front -- SC_ERR_BAD_ARG, the handle still at round 0 and usable -- not fail mid-proof"""
+    nv, nt, shapes = 6, 8, [[0, 1, 2, 3, 4, 5, 6, 7]]
+    tabs, coefs, want, wrand = _oracle(nv, shapes, nt, 71)
+    _P2P_GROUP[0] += 1
+    gid = _P2P_GROUP[0]
+    G, out = 2, [None, None]
+
+    ex = sharded.ThreadExchange(G)
+
+    def work(rank):
+        try:
+            _lib.check(sc.lib().sc_set_device(0))
+            n_loc = (1 << nv) // G
+            eng = sharded.HipShardEngine(nv - 1, shapes, coefs, [t[rank * n_loc:(rank + 1) * n_loc] for t in tabs], "cuda:0", borrow=True)
+            c = sharded.P2PComm(gid, rank, G, "cuda:0")
+            proof, rand = np.empty((nv, 9, 4), np.uint64), np.empty((nv, 4), np.uint64)
+            rc = sc.lib().sc_ml_prove_sharded(eng._h, c._h, None, nv, C.c_void_p(proof.ctypes.data), C.c_void_p(rand.ctypes.data))
+            msg = sc.lib().sc_last_error().decode()
+            rnd = C.c_uint32(99)
+            _lib.check(sc.lib().sc_prover_state(eng._h, None, None, None, C.byref(rnd)))
+            c.close()
+            hc = ex.comm(rank)
+            got = sharded.prove_sharded_library(eng, hc, nv)
+            hc.close()
+            eng.close()
+            out[rank] = (rc, msg, rnd.value, got)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            out[rank] = RuntimeError(f"{e}\n{traceback.format_exc()}")
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    for r in range(G):
+        assert not isinstance(out[r], Exception) and out[r] is not None, out[r]
+        rc, msg, rnd, (proof, rand) = out[r]
+        assert rc == _lib.SC_ERR_BAD_ARG and "at most 8 evaluations" in msg and rnd == 0
+        assert np.array_equal(proof, want) and np.array_equal(rand, wrand)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
