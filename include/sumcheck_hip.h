@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 4 /* 4: sc_comm_info, sc_comm_exchange_bench, sc_set_publish_timeout_ms, sc_prover_get_round_timing (additions only); 3: sc_prover_set_polling, sc_prover_set_resident, SC_NO_DEVICE_POLLING, sc_set_cache_limit, sc_comm_init_p2p, sc_gkr_prove_sharded (additions only) */
+#define SC_ABI_VERSION 4 /* 4: sc_comm_info, sc_comm_exchange_bench, sc_set_publish_timeout_ms, sc_prover_get_round_timing, sc_library_stats (additions only); 3: sc_prover_set_polling, sc_prover_set_resident, SC_NO_DEVICE_POLLING, sc_set_cache_limit, sc_comm_init_p2p, sc_gkr_prove_sharded (additions only) */
 #define SC_API __attribute__((visibility("default")))
 
 enum sc_status {
@@ -332,6 +332,12 @@ SC_API int sc_release_caches(void);
 /* Upper bound, in bytes of device memory, of what EACH of those three caches may keep between calls (default 16 GiB; 0 = nothing is
  * kept: every call allocates and frees its own, as a library without caches would).  Lowering the limit releases what is cached now. */
 SC_API int sc_set_cache_limit(uint64_t bytes);
+/* process-wide counters (monotone; n <= 8 words): which path the latency-bound rounds took and what had to be repeated -- what a host
+ * that runs several provers on one GPU cannot see otherwise.  out[0] persistent-tail launches; [1] times a prover found the device's
+ * one tail slot taken and ran its late rounds as pipelined launches instead; [2] times the slot was taken over from an interactive
+ * handle whose resident kernel had already left; [3] resident kernels started by sc_prove_round; [4] calls that found theirs gone
+ * (patience expired) and took the ordinary path; [5] proofs repeated after an expired device-side wait. */
+SC_API int sc_library_stats(uint64_t *out, uint32_t n);
 
 /* ---- synthetic inputs + instrumentation (bench / tests) ------------------------------------- */
 /* SplitMix64-keyed uniform field elements, generated on the device: n elements of

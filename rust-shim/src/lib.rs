@@ -86,6 +86,7 @@ extern "C" {
     pub fn sc_prover_free(p: *mut sc_prover);
     pub fn sc_release_caches() -> c_int;
     pub fn sc_set_cache_limit(bytes: u64) -> c_int;
+    pub fn sc_library_stats(out: *mut u64, n: u32) -> c_int;
     pub fn sc_prover_set_polling(p: *mut sc_prover, allow: c_int) -> c_int;
     pub fn sc_prover_set_resident(p: *mut sc_prover, patience_polls: u32) -> c_int;
     pub fn sc_fix_variables(input: *const u64, nv: u32, point: *const u64, k: u32, out: *mut u64, flags: u32) -> c_int;

@@ -65,6 +65,7 @@ SIGNATURES = {
     "sc_prover_set_polling": (C.c_int, [_V, C.c_int]),
     "sc_prover_set_resident": (C.c_int, [_V, C.c_uint32]),
     "sc_set_cache_limit": (C.c_int, [C.c_uint64]),
+    "sc_library_stats": (C.c_int, [u64p, C.c_uint32]),
     "sc_prove_round_partial": (C.c_int, [_V, _V, _V]),
     "sc_wide_reduce": (C.c_int, [_V, C.c_uint32, _V]),
     "sc_prover_bind_final": (C.c_int, [_V, _V, _V]),

@@ -1463,6 +1463,9 @@ constexpr size_t kTailSyncBytes = 4 * (16 + (size_t)scd::kTailMaxGrid);
 // its verifier likes and only notices that its kernel left on its next call.  So a slot whose holder is a resident kernel that has
 // raised its exit marker (sig[1], host-mapped: the kernel's last store before every block returns) counts as free: the next prover
 // takes it over, and the former holder's release becomes a no-op.
+// process-wide counters a host can read (sc_library_stats): which path the late rounds took, what was retried
+static std::atomic<uint64_t> g_stat[8];
+enum { kStatTailLaunches = 0, kStatTailSlotBusy = 1, kStatTailSlotReclaims = 2, kStatResidentStarts = 3, kStatResidentGone = 4, kStatProofRetries = 5 };
 struct TailOwner {
     std::mutex mu;
     sc_prover *owner = nullptr;
@@ -1474,7 +1477,11 @@ static bool tail_slot_acquire(sc_prover *p, bool resident) {
     TailOwner &t = g_tail_owner[(unsigned)p->device & 63u];
     std::lock_guard<std::mutex> lk(t.mu);
     if (t.owner && t.owner != p) {
-        if (!(t.resident && t.marker && __atomic_load_n(t.marker, __ATOMIC_ACQUIRE) != 0)) return false;
+        if (!(t.resident && t.marker && __atomic_load_n(t.marker, __ATOMIC_ACQUIRE) != 0)) {
+            g_stat[kStatTailSlotBusy].fetch_add(1, std::memory_order_relaxed);
+            return false;
+        }
+        g_stat[kStatTailSlotReclaims].fetch_add(1, std::memory_order_relaxed);
     }
     t.owner = p;
     t.resident = resident;
@@ -1605,6 +1612,7 @@ static int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, co
     int grid = 1;
     int rc_l = tail_launch(p, n_rounds, r_or_null, scd::wait_spins_default(), A, grid);
     if (rc_l) return rc_l;
+    g_stat[kStatTailLaunches].fetch_add(1, std::memory_order_relaxed);
     gate.release();
     p->seq += n_rounds;
     p->sig_seq += n_rounds - 1;
@@ -1721,6 +1729,7 @@ static int resident_wait(sc_prover *p, uint32_t j, uint64_t *out_evals) {
             if (wait_gave_up(p)) { // (re-check the flag: the message may have been published just before an exit for another reason)
                 if (__atomic_load_n(p->h_flag, __ATOMIC_ACQUIRE) == want) break;
                 int rc = resident_finish(p);
+                g_stat[kStatResidentGone].fetch_add(1, std::memory_order_relaxed);
                 return rc ? rc : kResidentGone;
             }
             if (std::chrono::steady_clock::now() - t_start > publish_timeout()) {
@@ -1762,6 +1771,7 @@ static int resident_start(sc_prover *p, const uint64_t *r_or_null, uint64_t *out
             return rc;
         }
     }
+    g_stat[kStatResidentStarts].fetch_add(1, std::memory_order_relaxed);
     p->res.active = true;
     p->res.first_has_bind = r_or_null != nullptr;
     p->res.seq0 = A.seq0;
@@ -2362,6 +2372,7 @@ extern "C" int sc_ml_prove_handle(sc_prover *p, sc_rng *rng_or_null, uint64_t *o
             rc = run_rounds(p, rng, p->nv, out_proof, ch.data(), trace ? &t_launch : nullptr, &t_wait, &t_fs);
             p->pipeline_ok = was;
             ++p->n_retries;
+            g_stat[kStatProofRetries].fetch_add(1, std::memory_order_relaxed);
         }
     }
     if (rc) {
@@ -2437,6 +2448,12 @@ void sc_internal_release_handle_pool() { // sc_release_caches (gkr.hip)
         g_pool.h = nullptr;
     }
     if (old) prover_destroy(old);
+}
+
+extern "C" int sc_library_stats(uint64_t *out, uint32_t n) {
+    if (!out) return fail(SC_ERR_BAD_ARG, "null argument");
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < 8 ? g_stat[i].load(std::memory_order_relaxed) : 0;
+    return SC_OK;
 }
 
 extern "C" int sc_set_cache_limit(uint64_t bytes) {

@@ -142,7 +142,8 @@ struct ComboMeta {
 #endif
 constexpr uint64_t kTailMaxPairs = SC_TAIL_MAX_PAIRS; // rounds above this many pairs are throughput- rather than latency-bound: separate (pipelined) launches
                                                       // with full-chip grids beat a resident grid that pays a barrier per phase (measured: 32 vs 54 us at 4096 pairs)
-static_assert(kTailMaxPairs / kBlock <= 8 || SC_TAIL_MAX_PAIRS != 2048, "k_tail_rounds' block 0 adds up a combination's partial blocks itself: at most 8 of them");
+static_assert(kTailMaxPairs >= kBlock && (kTailMaxPairs & (kTailMaxPairs - 1)) == 0 && kTailMaxPairs <= kSmallRoundPairs, "a power of two within the small rounds");
+// (at the default, a combination has at most kTailMaxPairs / kBlock = 8 partial blocks: block 0 adds them up with eight lanes each)
 constexpr int kTailMaxGrid = 1024; // at most 4 resident blocks per CU (120 VGPRs), all co-resident on a 256-CU device
 constexpr int kTailFlatPairs = 16; // rounds with at most this many pairs run in block 0 alone, one lane per (combination, pair)
 // ... and with few combinations (one product of two or three multiplicands: the GKR phases, configs 1 and 2) up to 64 pairs do: as long as

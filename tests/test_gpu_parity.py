@@ -877,6 +877,66 @@ def test_out_of_memory_is_a_status_code_and_a_resident_kernel_does_not_block_oth
     b.close()
 
 
+def _stats():
+    out = (C.c_uint64 * 8)()
+    _lib.check(sc.lib().sc_library_stats(out, 8))
+    return dict(zip(("tail_launches", "slot_busy", "slot_reclaims", "resident_starts", "resident_gone", "proof_retries"), [int(x) for x in out]))
+
+
+def test_tail_slot_of_an_idle_interactive_handle_is_reclaimed_and_pooled_handles_start_from_default_policy():
+    """ADVICE r3.  (1) An interactive handle that sits idle mid-protocol keeps the device's tail slot only while its resident kernel is
+    actually on the GPU: once the kernel's patience (~0.5 ms) has expired another prover TAKES THE SLOT OVER (sc_library_stats: a
+    reclaim, a persistent-tail launch, no 'slot busy') instead of falling back to pipelined launches for as long as the idle handle
+    lives; the idle handle then finds its kernel gone and carries on through the ordinary path with the right messages.
+    (2) What one owner set on a handle (the resident kernel's patience) does not reach the next owner through the handle pool."""
+    import time
+    nv, nt, shapes = 12, 4, [[0, 1, 2], [3, 3]]
+    tabs = [cref.synth_table(7500, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(7500, 1000, len(shapes))
+    dd = H.desc_from(nv, shapes, tabs, coefs)
+    want, _ = cref.ml_prove(dd, threads=4)
+    chal = cref.synth_table(7500, 2000, nv)
+    op = cref.Prover(dd, threads=4)
+    wmsgs = [op.prove_round(None if i == 0 else chal[i - 1]) for i in range(nv)]  # (first: the dialogue below must not pause for the CPU)
+    poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device="cuda:0")
+    a = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+    b = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+    v = None
+    for i in range(nv):
+        got = sc.IPForMLSumcheck.prove_round(a, v).evaluations
+        assert np.array_equal(got, wmsgs[i]), i
+        v = sc.VerifierMsg(chal[i])
+        if i == 3:  # a's resident kernel is on the GPU (it started with the first late round); let its patience run out
+            assert _stats()["resident_starts"] >= 1
+            time.sleep(0.05)
+            s0 = _stats()
+            b.reset()
+            assert np.array_equal(b.prove(sc.Blake2b512Rng.setup()), want)
+            s1 = _stats()
+            assert s1["slot_reclaims"] == s0["slot_reclaims"] + 1 and s1["tail_launches"] == s0["tail_launches"] + 1 and s1["slot_busy"] == s0["slot_busy"], (s0, s1)
+    assert _stats()["resident_gone"] >= 1  # a noticed on its next call and took the ordinary path: every message above was still right
+    a.close()
+    b.close()
+    # (2) the pool: sc_ml_prove builds (or takes) a handle of this shape, an owner makes its resident kernel very patient, frees it;
+    # the next owner of the pooled handle gets the default patience back: its idle kernel is gone after ~0.5 ms, not after seconds
+    dsc, keep = poly._desc(True)
+    h = C.c_void_p()
+    _lib.check(sc.lib().sc_prover_init(C.byref(dsc), C.byref(h)))
+    _lib.check(sc.lib().sc_prover_set_resident(h, 1 << 20))
+    sc.lib().sc_prover_free(h)  # offered to the pool
+    h2 = C.c_void_p()
+    _lib.check(sc.lib().sc_prover_init(C.byref(dsc), C.byref(h2)))
+    out = np.empty((4, 4), dtype=np.uint64)
+    ch = [np.ascontiguousarray(chal[i]) for i in range(nv)]  # (kept alive: the calls below take raw pointers)
+    for i in range(4):
+        _lib.check(sc.lib().sc_prove_round(h2, C.c_void_p(ch[i - 1].ctypes.data) if i else None, C.c_void_p(out.ctypes.data)))
+    g0 = _stats()["resident_gone"]
+    time.sleep(0.05)  # default patience: the kernel has left by now (with 2^20 polls it would still be there)
+    _lib.check(sc.lib().sc_prove_round(h2, C.c_void_p(ch[3].ctypes.data), C.c_void_p(out.ctypes.data)))
+    assert _stats()["resident_gone"] == g0 + 1
+    sc.lib().sc_prover_free(h2)
+
+
 def test_provers_on_several_threads_share_one_gpu():
     """Three host threads, one GPU: two whole-proof provers (pipelined late rounds + persistent tail kernel) and a GKR prover,
     each repeating its proof.  The library serialises its HIP calls per device (api.hip: DeviceGate) so that a kernel waiting
