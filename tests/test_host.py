@@ -265,3 +265,22 @@ def test_header_is_a_c_header_and_the_library_links_from_plain_c(tmp_path):
     env["LD_LIBRARY_PATH"] = ":".join(extra + [env.get("LD_LIBRARY_PATH", "")])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0 and "ABI-SMOKE-OK" in r.stdout, (r.returncode, r.stdout, r.stderr[-2000:])
+
+
+def test_bench_refuses_a_multi_gpu_run_it_cannot_place():
+    """`bench.py --gpus N` is self-launching; without N visible devices it says so
+    and exits 2 before any rank is started (no silent single-GPU or CPU run)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SC_BENCH_ONE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64",
+                        "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=root)
+    assert r.returncode == 2, (r.stdout, r.stderr)
+    assert "needs 64 visible GPUs" in r.stderr
+    assert not r.stdout.strip()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 2 and "power of two" in r.stderr
