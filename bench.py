@@ -40,6 +40,10 @@ import time
 # the CPU leg's OpenMP threads: one per core, pinned (set before any OpenMP runtime is loaded; a caller's own settings win)
 os.environ.setdefault("OMP_PROC_BIND", "spread")
 os.environ.setdefault("OMP_PLACES", "cores")
+# The CPUs this command may use, taken BEFORE any OpenMP runtime exists: with OMP_PROC_BIND the first runtime that loads binds this
+# process's main thread to one core, and a child process inherits that one-core mask -- the ranks `--gpus N` starts would then run
+# rank 0's CPU leg on a single core (seen: 1.2e8 instead of 8.9e8 field-ops/s).  self_launch() hands the ranks this mask back.
+CPUS_AT_START = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
 
 import numpy as np
 
@@ -144,7 +148,7 @@ def cpu_baseline(shapes, n_tables, nv_full=24, budget_s=12.0):
         # torch.distributed.run exports OMP_NUM_THREADS=1 to every rank it starts unless the caller set it.  The CPU leg is rank 0's
         # alone (the other ranks wait) and is meant to use the host's cores: the hardware threads, capped by the container's quota.
         q = cref.cpu_quota_cores()
-        hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        hw = len(CPUS_AT_START) if CPUS_AT_START else (os.cpu_count() or 1)  # (not sched_getaffinity now: the main thread is bound by then)
         threads = max(1, min(hw, q) if q else hw)
     coefs = cref.synth_table(SEED, 1000, len(shapes))
 
@@ -193,6 +197,7 @@ def cpu_baseline(shapes, n_tables, nv_full=24, budget_s=12.0):
             "sample": allc["sample"] + f", OpenMP {threads} threads, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}",
             "phases_s": allc["phases_s"], "whole_prove": allc["whole_prove"],
             "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "cpu_quota_cores": cref.cpu_quota_cores(),
+            "cpus_allowed": len(CPUS_AT_START) if CPUS_AT_START else None,  # this process's affinity mask when it started
             "one_thread": one, "all_cores_improved_bind": imp,
             "note": "port = oracle/oracle.c, a C restatement of the reference algorithm (the Rust reference cannot be built here). value = the "
                     "prove_round loop with the tables already copied (what the GPU clock covers); whole_prove adds prover_init's deep copy "
@@ -722,7 +727,13 @@ def self_launch(args):
         if "OMP_NUM_THREADS" not in env:  # (torch.distributed.run would set it to 1 for every rank: rank 0's CPU leg wants the cores)
             env["OMP_NUM_THREADS"] = str(os.cpu_count() or 1)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+        def full_mask():  # (runs in the child between fork and exec)
+            if CPUS_AT_START:
+                try:
+                    os.sched_setaffinity(0, CPUS_AT_START)
+                except OSError:
+                    pass
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT, preexec_fn=full_mask)
         line, _ = last_json_line(r.stdout)
         for l in r.stdout.splitlines():  # anything else the ranks wrote to stdout goes to stderr: the JSON line stays the last (and only) stdout line
             if l != line and l.strip():

@@ -82,6 +82,9 @@ def test_bench_two_gpus_as_the_driver_types_it():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
     assert d["cpu_baseline"]["cores"] >= min(2, os.cpu_count() or 1)  # (not the OMP_NUM_THREADS=1 a launcher hands its ranks)
+    # ... and its threads may run where this test's process may: the launching bench.py's main thread is bound to ONE core by its own
+    # OpenMP runtime (OMP_PROC_BIND), a mask its child processes would inherit -- sixteen threads on one core
+    assert d["cpu_baseline"]["cpus_allowed"] == len(os.sched_getaffinity(0)), d["cpu_baseline"]["cpus_allowed"]
     par = d["parity"]
     assert par["ok"] is True and par["rounds_equal"] == 16 and par["rounds_equal_after_timed_region"] == 16 and par["ranks_compared"] == 2, par
     c = d["config"]
@@ -105,6 +108,8 @@ def test_bench_line_two_ranks_external_launcher():
     d = _two_ranks(["--config", "4", "--nv", "17"], launcher="external")
     assert d["config"]["tables"] == 3 and d["config"]["nv_per_gpu"] == 16 and "config 4" in d["config"]["workload"]
     assert d["config"]["launcher"] == "processes (external launcher)" and d["cpu_baseline"]["value"] > 0
+    from oracle import cref  # (the launcher hands its ranks OMP_NUM_THREADS=1: the CPU leg still takes the cores this process may use)
+    assert d["cpu_baseline"]["cores"] == max(1, min(len(os.sched_getaffinity(0)), cref.cpu_quota_cores() or 1 << 30)), d["cpu_baseline"]["cores"]
     assert d["parity"]["ok"] is True and d["parity"]["rounds_equal"] == 17, d["parity"]  # (config 4 at nv <= 24: the CPU leg proves the instance itself)
     d = _two_ranks(["--nv", "17", "--scaling", "weak", "--no-cpu-baseline"], launcher="external")
     assert d["parity"]["ok"] is True and d["parity"]["verifier_accepts"] and d["parity"]["oracle_query_matches"], d["parity"]

@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python -c "import torch; p=torch.cuda.get_device_properties(0); print(p.name, p.multi_processor_count, p.total_memory)"
-P=sumcheck_amd/libsumcheck_hip.so
-bash tools/ab.sh -r 1 -w rounds -R "25 c4" $P tools/ab/k1_512.so tools/ab/k1_640.so tools/ab/k1_704.so tools/ab/k1_736.so tools/ab/k1_760.so > gpurun_out/r4x_k1_grid_ab2.txt 2>&1
-grep -A5 "== rounds" gpurun_out/r4x_k1_grid_ab2.txt
+echo "== single process"; python tools/_diag.py 2>&1 | grep -v amdgpu.ids | grep "R0\|RANK" 
+for M in hip sleep; do for T in 256 16; do echo "== torchrun 2 ranks mode=$M OMP_NUM_THREADS=$T"; DIAG_MODE=$M OMP_NUM_THREADS=$T python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29541 tools/_diag.py 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo" ; done; done
