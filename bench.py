@@ -38,11 +38,14 @@ import threading
 import time
 
 # the CPU leg's OpenMP threads: one per core, pinned (set before any OpenMP runtime is loaded; a caller's own settings win)
+OMP_DEFAULTS_SET_HERE = [k for k in ("OMP_PROC_BIND", "OMP_PLACES") if k not in os.environ]
 os.environ.setdefault("OMP_PROC_BIND", "spread")
 os.environ.setdefault("OMP_PLACES", "cores")
 # The CPUs this command may use, taken BEFORE any OpenMP runtime exists: with OMP_PROC_BIND the first runtime that loads binds this
 # process's main thread to one core, and a child process inherits that one-core mask -- the ranks `--gpus N` starts would then run
-# rank 0's CPU leg on a single core (seen: 1.2e8 instead of 8.9e8 field-ops/s).  self_launch() hands the ranks this mask back.
+# rank 0's CPU leg on a single core (seen: 1.2e8 instead of 8.9e8 field-ops/s).  self_launch() hands the launcher this mask back and
+# keeps the two variables above out of the LAUNCHER's environment (it loads an OpenMP runtime too, and the ranks are its children);
+# every rank is this file again and sets them for itself.
 CPUS_AT_START = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
 
 import numpy as np
@@ -702,6 +705,25 @@ def last_json_line(text):
     return None, None
 
 
+def launcher_env():
+    """environment and pre-exec hook for the process that starts the ranks: the CPUs this command started with (see CPUS_AT_START), no
+    OpenMP binding variables that only this file set (the launcher would bind ITS main thread and its children, the ranks, inherit)"""
+    env = dict(os.environ, SC_BENCH_SELF_LAUNCHED="1")
+    if "OMP_NUM_THREADS" not in env:  # (torch.distributed.run would set it to 1 for every rank: rank 0's CPU leg wants the cores)
+        env["OMP_NUM_THREADS"] = str(os.cpu_count() or 1)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in OMP_DEFAULTS_SET_HERE:
+        env.pop(k, None)
+
+    def full_mask():  # (runs in the child between fork and exec)
+        if CPUS_AT_START:
+            try:
+                os.sched_setaffinity(0, CPUS_AT_START)
+            except OSError:
+                pass
+    return env, full_mask
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: start the ranks ourselves"""
     N = args.gpus
@@ -723,16 +745,7 @@ def self_launch(args):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={N}", "--master-addr", "127.0.0.1", "--master-port", str(port),
                os.path.abspath(__file__)] + sys.argv[1:]
         log(f"[bench] --gpus {N} without a launcher: starting {N} ranks: {' '.join(cmd[1:9])} bench.py ...")
-        env = dict(os.environ, SC_BENCH_SELF_LAUNCHED="1")
-        if "OMP_NUM_THREADS" not in env:  # (torch.distributed.run would set it to 1 for every rank: rank 0's CPU leg wants the cores)
-            env["OMP_NUM_THREADS"] = str(os.cpu_count() or 1)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        def full_mask():  # (runs in the child between fork and exec)
-            if CPUS_AT_START:
-                try:
-                    os.sched_setaffinity(0, CPUS_AT_START)
-                except OSError:
-                    pass
+        env, full_mask = launcher_env()
         r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT, preexec_fn=full_mask)
         line, _ = last_json_line(r.stdout)
         for l in r.stdout.splitlines():  # anything else the ranks wrote to stdout goes to stderr: the JSON line stays the last (and only) stdout line

@@ -284,3 +284,27 @@ def test_bench_refuses_a_multi_gpu_run_it_cannot_place():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert r.returncode == 2 and "power of two" in r.stderr
+
+
+def test_bench_hands_its_ranks_the_cpus_it_started_with():
+    """bench.py pins the CPU leg's OpenMP threads (OMP_PROC_BIND); the first OpenMP runtime a process loads then binds its main thread
+    to one core, and child processes inherit that mask.  `--gpus N` starts its ranks through a launcher that loads such a runtime
+    too: without bench.launcher_env() rank 0's sixteen CPU-leg threads shared one core (seen on the GPU box)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("one CPU")
+    prog = (
+        "import os, sys, subprocess\n"
+        f"sys.path.insert(0, {root!r}); sys.argv = ['bench.py']\n"
+        "import bench, torch\n"  # (bench sets the binding variables, torch's OpenMP runtime binds this process's main thread)
+        "env, pre = bench.launcher_env()\n"
+        "inner = 'import torch, subprocess, sys; subprocess.run([sys.executable, \"-c\", \"import os; print(len(os.sched_getaffinity(0)))\"])'\n"
+        "print(len(bench.CPUS_AT_START), flush=True)\n"
+        "subprocess.run([sys.executable, '-c', inner], env=env, preexec_fn=pre)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_PROC_BIND", "OMP_PLACES")}
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    started_with, rank_sees = [int(x) for x in r.stdout.split()[-2:]]
+    assert started_with == len(os.sched_getaffinity(0)) and rank_sees == started_with, r.stdout
