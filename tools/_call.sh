@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-export GIT_HEAD=cc6c106
+export GIT_HEAD=1e9ae78
 timeout 900 python -m pytest tests/test_gpu_bench.py -q -m gpu -x 2>&1 | tail -3
 SC_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 20 --warmup 5 2>gpurun_out/r4v_driver_n2.err | tail -1 > gpurun_out/r4v_driver_n2_one_gpu.json
 python - <<'PY'
