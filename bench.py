@@ -225,9 +225,21 @@ class ProcWorld:
         self.launcher = ("processes (self-launched torch.distributed.run)" if os.environ.get("SC_BENCH_SELF_LAUNCHED") == "1"
                          else "processes (external launcher)") if self.world > 1 else "single process"
         self.dist = None
+        # SC_BENCH_FORCE_SHARDED=1 with one rank (tests): everything an N > 1 RCCL run calls -- the "nccl" process group with its barrier,
+        # device all-reduce and all-gather, the library's RCCL communicator, the sharded proof -- runs with a world of one
+        self.force_dist = self.world == 1 and os.environ.get("SC_BENCH_FORCE_SHARDED") == "1" and not self.one_gpu
+        if self.force_dist:
+            self.launcher = "single process (the N > 1 code path forced: one-rank RCCL world)"
 
     def init(self, dev):
-        if self.world > 1:
+        if self.force_dist:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1]))
+            s.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        if self.world > 1 or self.force_dist:
             import datetime
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

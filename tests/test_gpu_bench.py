@@ -116,6 +116,22 @@ def test_bench_line_two_ranks_external_launcher():
     assert d["cpu_baseline"] is None
 
 
+def test_bench_rccl_code_path_with_a_world_of_one():
+    """what an N > 1 run over RCCL calls -- torch.distributed's "nccl" group (barrier, device all-reduce / all-gather), the library's
+    RCCL communicator, its self-test and exchange timing, sc_ml_prove_sharded -- with one rank (RCCL refuses two ranks on one device)"""
+    env = dict(os.environ, SC_BENCH_FORCE_SHARDED="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SC_BENCH_ONE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--nv", "19", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    c = d["config"]
+    assert c["communicator"] == "rccl" and c["ranks_seen"] == 1 and c["round_loop"] == "library+rccl" and "forced" in c["launcher"], c
+    assert c["exchange"]["exchange_us"] > 0 and "selftest passed" in c["round_loop_reason"]
+    assert d["parity"]["ok"] is True and d["parity"]["rounds_equal"] == 19, d["parity"]
+
+
 def test_bench_refuses_more_gpus_than_visible():
     env = dict(os.environ)
     env.pop("SC_BENCH_ONE_GPU", None)
