@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsumcheck_hip.so")
 OUT_EXP = os.path.join(HERE, "libsumcheck_hip_exp.so")
 SOURCES = ["kernels_big.hip", "kernels.hip", "gkr.hip", "api.hip"]
-HEADERS = ["fr_device.hpp", "fe_device.hpp", "kernel_common.hpp", "finalize_device.hpp", "fr_mac.inc", "fr_mul_gen.inc", "kernels.h", "host_fr.hpp", "transcript.hpp", os.path.join("..", "..", "include", "sumcheck_hip.h")]
+HEADERS = ["fr_device.hpp", "fe_device.hpp", "kernel_common.hpp", "finalize_device.hpp", "fe_mad_chain.inc", "fr_mac.inc", "fr_mul_gen.inc", "kernels.h", "host_fr.hpp", "transcript.hpp", os.path.join("..", "..", "include", "sumcheck_hip.h")]
 EXTRA = os.environ.get("SC_BUILD_EXTRA", "").split()  # e.g. SC_BUILD_EXTRA="-DSC_TAIL_CLOCKS" for a one-off local build
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
@@ -30,11 +30,17 @@ def _stale(out: str) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def _obj_stale(obj: str, src: str) -> bool:
+def _obj_stale(obj: str, src: str, cmd: list) -> bool:
     """per object: recompile only when the source, a header the compiler saw it include (the -MD dependency file of the last
-    compile) or this script is newer than the object -- kernels.hip alone is 2.5 minutes"""
+    compile) or this script is newer than the object, or when the object was compiled with ANOTHER command line (obj.cmd: a one-off
+    SC_BUILD_EXTRA=-DSC_TAIL_CLOCKS build must not leave its instrumented objects to the next plain build) -- kernels.hip alone is 2.5 minutes"""
     dep = obj + ".d"
     if not (os.path.exists(obj) and os.path.exists(dep)):
+        return True
+    try:
+        if open(obj + ".cmd").read() != " ".join(cmd):
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(obj)
     try:
@@ -50,14 +56,18 @@ def _start(experiments: bool, verbose: bool, force: bool = False):
     bdir = os.path.join(HERE, "build_exp" if experiments else "build")
     os.makedirs(bdir, exist_ok=True)
     procs, objs = [], []
+    stale_any = False
     for s in SOURCES:
         o = os.path.join(bdir, s + ".o")
         objs.append(o)
         src = os.path.join(CSRC, s)
-        if not force and not _obj_stale(o, src):
-            continue
         # -Rpass-analysis: registers / scratch / LDS / occupancy of every kernel, for free with every build (tools/kernel_resources.py prints them)
         cmd = [hipcc] + FLAGS + (["-DSC_EXPERIMENTS"] if experiments else []) + EXTRA + ["-Rpass-analysis=kernel-resource-usage", "-MD", "-MF", o + ".d", "-c", src, "-o", o]
+        if not force and not _obj_stale(o, src, cmd):
+            continue
+        stale_any = True
+        if os.path.exists(o + ".cmd"):
+            os.remove(o + ".cmd")  # (written again once the compile has succeeded: _finish)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, o, subprocess.Popen(cmd, stderr=open(o + ".log", "w"))))
@@ -75,13 +85,32 @@ def _finish(hipcc, procs, objs, out):
                 if os.path.exists(f):
                     os.remove(f)
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
+        with open(o + ".cmd", "w") as f:
+            f.write(" ".join(cmd))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
     return out
 
 
+def _cmd_mismatch(experiments: bool) -> bool:
+    """an object of this build directory was compiled with another command line than this run would use (SC_BUILD_EXTRA changed)"""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    bdir = os.path.join(HERE, "build_exp" if experiments else "build")
+    for s in SOURCES:
+        o = os.path.join(bdir, s + ".o")
+        cmd = [hipcc] + FLAGS + (["-DSC_EXPERIMENTS"] if experiments else []) + EXTRA + ["-Rpass-analysis=kernel-resource-usage", "-MD", "-MF", o + ".d", "-c", os.path.join(CSRC, s), "-o", o]
+        try:
+            if open(o + ".cmd").read() != " ".join(cmd):
+                return True
+        except OSError:
+            # no record: an object built before records existed (or no object at all, e.g. a shipped .so without its build directory)
+            if os.path.exists(o):
+                return True
+    return False
+
+
 def build(force: bool = False, verbose: bool = False, experiments: bool = False) -> str:
     out = OUT_EXP if experiments else OUT
-    if not force and not _stale(out):
+    if not force and not _stale(out) and not _cmd_mismatch(experiments):
         return out
     return _finish(*_start(experiments, verbose, force), out)
 
@@ -90,7 +119,7 @@ def build_all(force: bool = False, verbose: bool = False):
     """both libraries, compiled concurrently"""
     jobs = []
     for exp, out in ((False, OUT), (True, OUT_EXP)):
-        if force or _stale(out):
+        if force or _stale(out) or _cmd_mismatch(exp):
             jobs.append((_start(exp, verbose, force), out))
     for st, out in jobs:
         _finish(*st, out)

@@ -20,7 +20,7 @@ def _last_json(out: str):
 
 
 def test_bench_line_single_gpu():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--nv", "19"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--nv", "19", "--min-gpu-seconds", "0.5"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
@@ -50,6 +50,11 @@ def test_bench_line_single_gpu():
     mu = rf["multiplier"]
     assert 0 < mu["frac_executed"] < 1 and mu["executed_products_per_s"] < mu["reference_muls_per_s"] and "modmul_fraction" not in rf
     assert d["config"]["gpu_leg"]["proofs_after_the_clock"] >= 1 and d["config"]["launcher"] == "single process"
+    # the whole proof against the roof, and what it pays beside its big-round kernels
+    assert abs(rf["whole_proof_frac"] - rf["whole_proof_GBps"] / rf["peak"]) < 1e-12 and 0 < rf["whole_proof_frac"] < rf["frac"]
+    fc = rf["fixed_cost"]
+    assert 0 < rf["fixed_cost_ms"] < d["ms_per_step"] and abs(fc["big_round_kernels_ms"] + rf["fixed_cost_ms"] - d["ms_per_step"]) < 1e-9
+    assert fc["latency_bound_rounds"] == 19 - 4 and fc["finalize_inside_big_rounds_ms"] >= 0 and fc["turnaround_and_latency_bound_rounds_ms"] > 0
 
 
 def _two_ranks(extra, launcher=None, timeout=900):
@@ -58,7 +63,7 @@ def _two_ranks(extra, launcher=None, timeout=900):
     env = dict(os.environ, SC_BENCH_ONE_GPU="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--min-gpu-seconds", "0.5"] + extra
     if launcher == "external":
         s = socket.socket()
         s.bind(("127.0.0.1", 0))

@@ -117,6 +117,38 @@ def streamed(nv, shapes, nt, reps=3):
             "pcie_GBps": 2 * U * (1 << nv) * 32 / med / 1e9, "note": "the input crosses PCIe twice (rounds 1 and 2); PCIe-bound"}
 
 
+def wide(nv, ms, reps=7):
+    """the reference's own test shapes (ml_sumcheck/test.rs:122-167: products of 4..12 multiplicands over fresh tables), at a size where
+    they matter: every product over its own tables.  Next to the time: algorithmic GB/s (32 U (4 2^nv - 6)), the reference
+    algorithm's multiplications per second and the products the kernels execute per second (a product of M multiplicands at M + 1 nodes:
+    (M - 1)(M + 1) products per pair + M binds per pair of the next round) against the 160 G/s carry-free ceiling."""
+    shapes, nt = [], 0
+    for m in ms:
+        shapes.append(list(range(nt, nt + m)))
+        nt += m
+    r = ml(nv, shapes, nt, reps=reps, cpu=False)
+    med = r["gpu_ms_median"] * 1e-3
+    D = max(ms) + 1
+    r["reference_muls_per_s"] = ((1 << nv) - 1) * sum(m * D for m in ms) / med + nt * ((1 << nv) - 2) / med
+    exe = sum(((m - 1) * (m + 1) + m * 97 / 153) for m in ms) * ((1 << nv) - 1)
+    r["executed_products_per_s"] = exe / med
+    r["frac_of_fe_mul_ceiling"] = exe / med / 160e9
+    r["frac_of_hbm_peak"] = r["algorithmic_GBps"] / 8000.0
+    r["multiplicands"] = ms
+    r["kernels"] = ("k_round1_tree_split / k_round_tree_split (every product <= 4)" if max(ms) <= 4 else
+                    "k_prod_tree (<= 4) + k_prod_round_fe<M> (5..8), one launch per product" if max(ms) <= 8 else "k_fix per table + k_sum_generic per product")
+    return r
+
+
+if "--wide" in sys.argv:  # VERDICT r4 item 5: the M >= 5 paths, timed
+    nvw = 20
+    print(json.dumps({"test_normal_shape_nv20_5_products_of_4_to_8": wide(nvw, [4, 5, 6, 7, 8]),
+                      "five_products_of_5": wide(nvw, [5, 5, 5, 5, 5]),
+                      "five_products_of_8": wide(nvw, [8, 8, 8, 8, 8]),
+                      "one_product_of_12": wide(nvw, [12]),
+                      "one_product_of_6": wide(nvw, [6]),
+                      "for_scale_five_products_of_4": wide(nvw, [4, 4, 4, 4, 4])}, indent=1))
+    sys.exit(0)
 if "--only-streamed" in sys.argv:
     print(json.dumps({"streamed_nv26_3tables": streamed(26, [[0, 1, 2]], 3)}, indent=1))
     sys.exit(0)
