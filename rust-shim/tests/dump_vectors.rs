@@ -5,24 +5,31 @@
 //!   * `CanonicalSerialize` of `PolynomialInfo`, `ProverMsg`, `Proof` (ml_*.json: "fs_proof" as the serialised proof bytes);
 //!   * the challenges of a whole non-interactive proof (ml_*.json: "fs_randomness" vs `ProverState::randomness`) and the verifier's
 //!     sub-claim ("subclaim_expected");
+//!   * THE HOT PATH ITSELF, round by round with fixed (non-transcript) challenges: `IPForMLSumcheck::prover_init / prove_round`
+//!     (ml_*.json: "challenges" -> "rounds", and the bound tables left in `ProverState` -> "final_tables"), and the Montgomery limbs
+//!     of an element as they sit in memory ("tables_mont0": what crosses the C ABI);
 //!   * `SparseMultilinearExtension::fix_variables` inside `initialize_phase_one / _two` (gkr_*.json: "h_g", "f1_g_idx",
 //!     "f1_g_vals" -- zero-valued entries included -- and "f1_gu");
 //!   * `GKRRoundSumcheck::prove` + `verify` end to end (gkr_*.json: "sum", "u", "v", "expected": the sub-claim depends on every
-//!     message of both phases through the transcript).
+//!     message of both phases through the transcript), and the messages of both phases themselves ("phase1", "phase2": crate-private in
+//!     `GKRProof`, so the test replays `GKRRoundSumcheck::prove`'s loop from its public building blocks).
+//! tests/test_oracle.py::test_pin_reads_every_fixture_field fails when a fixture gains a field this file does not read.
 //!
 //! One command on a machine with cargo:  `cd rust-shim && cargo test --release --test dump_vectors -- --nocapture`
 //! (no GPU and no libsumcheck_hip needed: set SUMCHECK_HIP_LIB_DIR to any directory holding a stub if the linker insists).
 //! Every comparison names the first differing field, so a failure says WHICH recalled semantic is wrong.
 //! NOT BUILT in this repository's image (no cargo).
 use ark_ff::{BigInteger, PrimeField};
-use ark_poly::{DenseMultilinearExtension, SparseMultilinearExtension};
+use ark_poly::{DenseMultilinearExtension, Polynomial, SparseMultilinearExtension};
 use ark_serialize::{CanonicalSerialize, Compress, SerializationError, Valid};
 use ark_std::io::Write;
 use ark_std::rand::RngCore;
 use ark_std::rc::Rc;
 use ark_std::UniformRand;
-use ark_sumcheck::gkr_round_sumcheck::{initialize_phase_one, initialize_phase_two, GKRRoundSumcheck};
+use ark_sumcheck::gkr_round_sumcheck::{initialize_phase_one, initialize_phase_two, start_phase1_sumcheck, start_phase2_sumcheck, GKRRoundSumcheck};
 use ark_sumcheck::ml_sumcheck::data_structures::{ListOfProductsOfPolynomials, PolynomialInfo};
+use ark_sumcheck::ml_sumcheck::protocol::verifier::VerifierMsg;
+use ark_sumcheck::ml_sumcheck::protocol::IPForMLSumcheck;
 use ark_sumcheck::ml_sumcheck::MLSumcheck;
 use ark_sumcheck::rng::{Blake2b512Rng, FeedableRNG};
 use ark_test_curves::bls12_381::Fr;
@@ -90,6 +97,12 @@ fn transcript_vectors() {
             _ => assert_eq!(fr_hex(&Fr::rand(&mut rng)), op[1].as_str().unwrap(), "transcript op {n}: F::rand"),
         }
     }
+    // RFC 7693's "abc": the first 64 bytes squeezed after feeding b"abc" ARE the BLAKE2b-512 digest of "abc" (fill_bytes finalises a clone)
+    let mut rng = Blake2b512Rng::setup();
+    rng.feed(&Raw(b"abc".to_vec())).unwrap();
+    let mut abc = [0u8; 64];
+    rng.fill_bytes(&mut abc);
+    first_diff("blake2b-512(\"abc\") through feed + fill_bytes", &abc, &unhex(t["blake2b_abc"].as_str().unwrap()));
     // feed(&PolynomialInfo), feed(&ProverMsg)-shaped Vec<F>, then F::rand and 64 more bytes
     let s = &t["structured"];
     let mut rng = Blake2b512Rng::setup();
@@ -154,6 +167,47 @@ fn ml_proof_vectors() {
     }
 }
 
+/// the hot path with the transcript taken out: `prove_round` driven by the fixture's fixed challenges
+#[test]
+fn ml_interactive_vectors() {
+    for name in ["nv1_trivial", "nv2_single", "nv3_c1shape", "nv5_deg12", "nv6_c3shape", "nv6_shared", "nv7_c2shape", "nv8_bench"] {
+        let case = load(&format!("ml_{name}"));
+        assert_eq!(case["name"].as_str().unwrap(), name, "{name}: fixture name");
+        let nv = case["nv"].as_u64().unwrap() as usize;
+        assert_eq!(case["tables"].as_array().unwrap().len() as u64, case["n_tables"].as_u64().unwrap(), "{name}: n_tables");
+        // the in-memory form of a field element: Fp<MontBackend<FrConfig, 4>, 4>(BigInt([u64; 4])) holds the MONTGOMERY limbs, little-endian
+        for (u, t) in case["tables"].as_array().unwrap().iter().enumerate() {
+            let x = fr(&t[0]);
+            let want: Vec<u64> = case["tables_mont0"][u].as_array().unwrap().iter().map(|l| l.as_u64().unwrap()).collect();
+            assert_eq!((x.0).0.to_vec(), want, "{name}: Montgomery limbs of tables[{u}][0] (the C ABI's element layout)");
+        }
+        let poly = build_poly(&case);
+        let mut state = IPForMLSumcheck::prover_init(&poly);
+        let chal = frs(&case["challenges"]);
+        let mut v_msg: Option<VerifierMsg<Fr>> = None;
+        for i in 0..nv {
+            let msg = IPForMLSumcheck::prove_round(&mut state, &v_msg);
+            let want = frs(&case["rounds"][i]);
+            assert_eq!(msg.evaluations.len(), want.len(), "{name}: round {} message length", i + 1);
+            for (t, (a, b)) in msg.evaluations.iter().zip(&want).enumerate() {
+                assert_eq!(fr_hex(a), fr_hex(b), "{name}: round {} evaluation {t} (prove_round)", i + 1);
+            }
+            v_msg = Some(VerifierMsg { randomness: chal[i] });
+        }
+        // what prove_round left behind: every flattened table bound nv - 1 times (two entries each), in first-occurrence order
+        let ids: Vec<usize> = case["flattened_table_ids"].as_array().unwrap().iter().map(|x| x.as_u64().unwrap() as usize).collect();
+        assert_eq!(state.flattened_ml_extensions.len(), ids.len(), "{name}: flattened tables");
+        for (j, t) in state.flattened_ml_extensions.iter().enumerate() {
+            let want = frs(&case["final_tables"][j]);
+            assert_eq!(t.evaluations.len(), want.len(), "{name}: final table {j} (table {}) length", ids[j]);
+            for (e, (a, b)) in t.evaluations.iter().zip(&want).enumerate() {
+                assert_eq!(fr_hex(a), fr_hex(b), "{name}: final table {j} entry {e} (DenseMultilinearExtension::fix_variables)");
+            }
+        }
+        println!("ml_{name}: interactive rounds and bound tables match");
+    }
+}
+
 #[test]
 fn gkr_vectors() {
     for dim in [2usize, 4, 6] {
@@ -192,6 +246,27 @@ fn gkr_vectors() {
         }
         assert_eq!(fr_hex(&sub.expected_evaluation), g["expected"].as_str().unwrap(), "gkr dim {dim}: expected_evaluation");
         assert!(sub.verify_subclaim(&f1, &f2, &f3, &gg), "gkr dim {dim}: verify_subclaim");
+        // the messages of both phases: GKRRoundSumcheck::prove's loop (gkr_round_sumcheck/mod.rs:100-139) from its public parts
+        assert_eq!(g["dim"].as_u64().unwrap() as usize, dim, "gkr dim {dim}: fixture dim");
+        let mut rng = Blake2b512Rng::setup();
+        let mut replay = |mut state: ark_sumcheck::ml_sumcheck::protocol::prover::ProverState<Fr>, want: &Value, key: &str| -> Vec<Fr> {
+            let mut v_msg: Option<VerifierMsg<Fr>> = None;
+            let mut point = Vec::new();
+            for i in 0..dim {
+                let msg = IPForMLSumcheck::prove_round(&mut state, &v_msg);
+                for (t, (a, b)) in msg.evaluations.iter().zip(frs(&want[i])).enumerate() {
+                    assert_eq!(fr_hex(a), fr_hex(&b), "gkr dim {dim}: {key} round {} evaluation {t}", i + 1);
+                }
+                rng.feed(&msg).unwrap();
+                let r = IPForMLSumcheck::sample_round(&mut rng);
+                point.push(r.randomness);
+                v_msg = Some(r);
+            }
+            point
+        };
+        let u2 = replay(start_phase1_sumcheck(&h_g, &f2), &g["phase1"], "phase1");
+        assert_eq!(u2.iter().map(fr_hex).collect::<Vec<_>>(), u.iter().map(fr_hex).collect::<Vec<_>>(), "gkr dim {dim}: replayed u");
+        let _ = replay(start_phase2_sumcheck(&f1_gu, &f3, f2.evaluate(&u2)), &g["phase2"], "phase2");
         println!("gkr_dim{dim}: phase-one / phase-two initialisation, sum and sub-claim match");
     }
 }

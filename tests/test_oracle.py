@@ -319,3 +319,38 @@ def test_gkr_naive_sum_and_subclaim_pyoracle():
     assert (m1[0][0] + m1[0][1]) % po.P == naive  # test_extract
     uu, vv, exp = po.gkr_verify(po.Blake2b512Rng(), dim, m1, m2, naive)
     assert po.gkr_verify_subclaim(f1, f2, f3, g, uu, vv, exp)  # test_small
+
+
+def test_pin_reads_every_fixture_field():
+    """rust-shim/tests/dump_vectors.rs is the one-command pin against real arkworks (it cannot be built here: no cargo).  It must stay in
+    step with tests/golden/: every field make_golden.py writes is read by the Rust file (as `["field"]`), and every fixture file is
+    loaded by it -- so the day cargo exists nothing the fixtures hold goes uncompared.  `seed` only documents how the tables were
+    synthesised (the Rust side reads the tables themselves)."""
+    import glob
+    import json
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rs = open(os.path.join(root, "rust-shim", "tests", "dump_vectors.rs")).read()
+    read = set(re.findall(r'\["([A-Za-z0-9_]+)"\]', rs))
+    metadata_only = {"seed"}
+    files = sorted(glob.glob(os.path.join(root, "tests", "golden", "*.json")))
+    assert len(files) >= 12
+    for f in files:
+        stem = os.path.basename(f)[:-5]
+        if stem.startswith("ml_"):
+            assert f'"{stem[3:]}"' in rs, f"{stem}: not in ml_proof_vectors' / ml_interactive_vectors' case lists"
+        elif stem.startswith("gkr_dim"):
+            assert re.search(r"for dim in \[[^\]]*(?<![0-9])%s(?![0-9])" % stem[7:], rs), f"{stem}: not in gkr_vectors' dim list"
+        else:
+            assert f'load("{stem}")' in rs, f"{stem}: never loaded"
+        d = json.load(open(f))
+        keys = set(d)
+        if stem == "transcript":
+            keys |= set(d["structured"])
+        missing = sorted(k for k in keys - metadata_only if k not in read)
+        assert not missing, f"{stem}.json: fields the Rust pin never reads: {missing}"
+    # ... and the generator writes nothing else: the keys of its `case = {...}` literals are the keys of the fixtures
+    gen = open(os.path.join(root, "tests", "golden", "make_golden.py")).read()
+    gen_keys = set(re.findall(r'"([A-Za-z0-9_]+)": ', gen))  # ("key": value -- not `if __name__ == "__main__":`)
+    assert gen_keys - metadata_only <= read, sorted(gen_keys - metadata_only - read)
