@@ -338,11 +338,55 @@ class ThreadWorld:
         self.sh.bar.wait(timeout=3600)
 
 
+# ---- the scaling model: written down BEFORE a multi-GPU node exists, so that the first N > 1 line tests it ----------------
+# One-GPU whole-proof times of the shard shapes, ms (profiles/r5c_single_gpu_shards.json: `python bench.py --config C --nv n` on one
+# MI355X, round 5).  A rank of an N-GPU proof holds nv - log2 N variables per table.
+T1_MS = {3: {24: 5.14, 23: 2.82, 22: 1.69, 21: 1.12, 20: 0.80}, 4: {28: 24.0, 27: 12.07, 26: 6.30, 25: 3.44}}
+EXCHANGE_ASSUMED_US = {"rccl": {2: 12.0, 4: 15.0, 8: 20.0, 16: 25.0}, "p2p": {2: 6.0, 4: 7.0, 8: 8.0, 16: 10.0}}  # ASSUMED (no two-GPU box seen yet)
+GATHER_ASSUMED_GBPS, GATHER_ASSUMED_LATENCY_US = 50.0, 30.0  # all-gather over xGMI: per-rank receive rate, plus bind / launch / tail-reset latency
+REPLICATED_ROUND_US = {14: 42.0, 13: 31.0, 12: 29.0, 11: 25.0}  # a latency-bound round by log2(pairs), measured on one GPU
+
+
+def t1_ms(config, nv):
+    """one-GPU proof time of an nv-variable instance of the config's shape: the table, else scaled from the nearest entry (bytes halve per variable)"""
+    tab = T1_MS[config]
+    if nv in tab:
+        return tab[nv], "measured"
+    near = min(tab, key=lambda q: abs(q - nv))
+    fixed = 0.55 if config == 3 else 0.6  # the latency-bound rounds' share, ms: does not scale
+    return fixed + (tab[near] - fixed) * 2.0 ** (nv - near), f"scaled from nv={near}"
+
+
+def predict_ms(config, nv_total, world, U, comm_kind, exchange_us=None):
+    """predicted ms per proof at `world` GPUs: the shard's own one-GPU time + one exchange per sharded round + the early gather + the
+    log2(world) extra replicated rounds (the replicated tail starts at 2^14 pairs whatever the shard size)"""
+    k = world.bit_length() - 1
+    nv_local = nv_total - k
+    m = min(max(15 - k, 0), nv_local - 1) if k else 0
+    nl = nv_local - m
+    t1, t1_src = t1_ms(config, nv_local)
+    if world == 1:
+        return {"predicted_ms_per_step": t1, "t1_ms": t1, "t1_source": t1_src}
+    kind = "p2p" if comm_kind == "p2p" else "rccl"
+    x = EXCHANGE_ASSUMED_US[kind].get(world, 25.0)
+    gather_bytes = U * (1 << m) * 32 * (world - 1)  # received per rank
+    gather_us = gather_bytes / (GATHER_ASSUMED_GBPS * 1e3) + GATHER_ASSUMED_LATENCY_US
+    extra_us = sum(REPLICATED_ROUND_US.get(14 - j, 25.0) for j in range(k))
+    out = {"model": "T1(nv per GPU) + sharded_rounds * exchange + gather + log2(N) extra replicated rounds",
+           "t1_ms": t1, "t1_source": t1_src + " (profiles/r5c_single_gpu_shards.json)", "sharded_rounds": nl, "replicated_rounds": m + k,
+           "exchange_assumed_us": x, "gather_bytes_received_per_rank": gather_bytes, "gather_assumed_us": gather_us,
+           "gather_assumption": f"{GATHER_ASSUMED_GBPS:.0f} GB/s per rank + {GATHER_ASSUMED_LATENCY_US:.0f} us", "extra_replicated_rounds_us": extra_us,
+           "predicted_ms_per_step": t1 + (nl * x + gather_us + extra_us) * 1e-3}
+    if exchange_us:  # the same with the exchange this run measured on its communicator
+        out["predicted_ms_per_step_with_measured_exchange"] = t1 + (nl * exchange_us + gather_us + extra_us) * 1e-3
+    return out
+
+
 def comm_info(sc, comm):
     r, n, k = C.c_int(), C.c_int(), C.c_int()
     from sumcheck_amd import _lib
     _lib.check(sc.lib().sc_comm_info(comm._h, C.byref(r), C.byref(n), C.byref(k)))
-    return r.value, n.value, {1: "rccl", 2: "host-transport", 3: "p2p"}.get(k.value, str(k.value))
+    return r.value, n.value, {1: "rccl", 2: "host-transport", 3: "p2p"}.get(k.value & 0xff, str(k.value)), bool(k.value & 0x100)
 
 
 def run_rank(args, W, result):
@@ -396,7 +440,7 @@ def run_rank(args, W, result):
     round_loop = "library"
     sharded_path = world > 1 or force_sharded
     exchange = None
-    ranks_seen, comm_kind = 1, "none"
+    ranks_seen, comm_kind, direct_pub = 1, "none", False
     box = {"comm": None, "python": False, "why": "single GPU: no exchange"}
     if not sharded_path:
         mles = [sc.DenseMultilinearExtension(nv_local, t) for t in tables]
@@ -420,7 +464,7 @@ def run_rank(args, W, result):
                 # collective self-test BEFORE the warm-up: one all-reduce and one all-gather of known patterns, checked on every rank
                 _lib.check(sc.lib().sc_comm_selftest(box["comm"]._h))
                 box["why"] = "sc_comm_selftest passed on every rank"
-                _, ranks_seen, comm_kind = comm_info(sc, box["comm"])
+                _, ranks_seen, comm_kind, direct_pub = comm_info(sc, box["comm"])
             except Exception as e:
                 box["why"] = f"in-library communicator unavailable or failed its self-test: {e}"
                 box["python"] = True
@@ -444,6 +488,8 @@ def run_rank(args, W, result):
                 exchange = {"exchange_us": None, "reason": err or "the measurement failed on another rank"}
             else:
                 exchange = {"exchange_us": W.max_float(us_mean.value), "exchange_us_min": us_min.value, "bytes": 64 * D, "iters": iters,
+                            "publication": ("direct: ncclAllReduce delivers tagged lanes into the host-mapped page, no publish kernel" if direct_pub else
+                                            "the exchange kernel publishes" if comm_kind == "p2p" else "publish kernel behind the all-reduce"),
                             "what": f"{iters} back-to-back all-reduces of one round message on the {comm_kind} communicator, host-waited like a round's (max over ranks of the mean)"}
         dcomm = sharded.DistComm() if isinstance(W, ProcWorld) else None
         tail_factory = sharded.TailEngines(shapes, coefs, dev)  # only the Python loop uses it
@@ -631,6 +677,8 @@ def run_rank(args, W, result):
         ms_step = elapsed / args.steps * 1e3
         whole_gbps = algorithmic_bytes(nv_local, U) * args.steps / elapsed / 1e9
         big_kernels_ms = sum(r["ms"] for r in per_round)
+        pred = predict_ms(args.config, nv_total, world, U, comm_kind, (exchange or {}).get("exchange_us"))
+        pred["measured_over_predicted"] = ms_step / pred["predicted_ms_per_step"]
         cfg_name = ("BASELINE config 4" if args.config == 4 else "BASELINE config 3") + (f", {scaling} scaling" if world > 1 else "")
         ref_muls = reference_muls(nv_total, shapes, U)
         exe = executed_products(nv_local, shapes, U) * world + (executed_products(k, shapes, U) if k else 0)
@@ -646,6 +694,8 @@ def run_rank(args, W, result):
                        "field_ops_per_step": ops, "sharding": f"high-bit x{world}" if world > 1 else "none",
                        "launcher": W.launcher, "ranks_seen": ranks_seen, "communicator": comm_kind, "exchange": exchange,
                        "round_loop": round_loop, "round_loop_reason": box["why"],
+                       # the scaling model's figure for THIS line, written down before any N > 1 hardware run: the line tests it
+                       "predicted_ms_per_step": pred["predicted_ms_per_step"], "exchange_assumed_us": pred.get("exchange_assumed_us"), "prediction": pred,
                        "gpu_leg": {"warmup_proofs": args.warmup, "timed_proofs": args.steps, "proofs_after_the_clock": cooldown + (1 if all_have else 0),
                                    "gpu_leg_seconds_target": args.min_gpu_seconds,
                                    "note": "the proofs after the clock keep the GPU busy for --min-gpu-seconds in all (an outside activity sampler with a 5 s period sees the run); they are not timed"}},

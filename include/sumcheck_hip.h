@@ -194,9 +194,13 @@ SC_API void sc_comm_free(sc_comm *comm);
 #define SC_COMM_RCCL 1
 #define SC_COMM_HOST 2
 #define SC_COMM_P2P 3
+#define SC_COMM_DIRECT_PUBLISH 0x100 /* flag on SC_COMM_RCCL: the communicator's all-reduces deliver a round's (tagged) lanes straight into the
+                                      * host-mapped page the host polls -- no publishing kernel behind them (probed by sc_comm_init; SC_RCCL_DIRECT=0
+                                      * switches it off) */
 SC_API int sc_comm_info(sc_comm *comm, int *rank_out, int *nranks_out, int *kind_out);
 /* measurement, collective (every rank calls it): `iters` back-to-back exchanges of n_words (<= 64) uint64 lanes in exactly the form a
- * sharded round uses on this communicator (RCCL: ncclAllReduce + publishing kernel + the host's poll; peer-to-peer: the one exchange
+ * sharded round uses on this communicator (RCCL: ncclAllReduce into the host-mapped page + the host's poll of the tagged words, or
+ * ncclAllReduce + publishing kernel + poll where direct publication is unavailable; peer-to-peer: the one exchange
  * kernel + poll; host transport: publishing kernel + poll + the caller's all-reduce), each waited for before the next is issued; the
  * sums are checked.  *us_mean_out / *us_min_out_or_null: this rank's wall time per exchange.  The per-round cost a sharded proof pays
  * on top of its kernels (the reference's counterpart, the rayon reduce of prover.rs:139-148, is in-process). */

@@ -37,13 +37,13 @@ using scd::FrHost;
 using scd::FrU;
 using scd::kBlock;
 
-int sc_internal_fail(int code, const char *fmt, ...); // api.hip
-void sc_internal_gate_lock(int device);                // api.hip: the device gate (serialises the library's HIP calls per device)
+int sc_internal_fail(int code, const char *fmt, ...); // abi.hip
+void sc_internal_gate_lock(int device);                // abi.hip: the device gate (serialises the library's HIP calls per device)
 void sc_internal_gate_unlock(int device);
-int sc_internal_device();                             // api.hip: the calling thread's device (sc_set_device)
-uint64_t sc_internal_cache_limit();                   // api.hip: sc_set_cache_limit
-void sc_internal_release_eval_cache();                // api.hip: sc_poly_evaluate's cached work areas
-void sc_internal_release_handle_pool();               // api.hip: the prover sc_ml_prove keeps between one-shot proofs
+int sc_internal_device();                             // abi.hip: the calling thread's device (sc_set_device)
+uint64_t sc_internal_cache_limit();                   // abi.hip: sc_set_cache_limit
+void sc_internal_release_eval_cache();                // abi.hip: sc_poly_evaluate's cached work areas
+void sc_internal_release_handle_pool();               // abi.hip: the prover sc_ml_prove keeps between one-shot proofs
 int sc_internal_run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_t *out_msgs, sch::Fr *out_challenges); // api.hip
 struct sc_rng {
     sch::Blake2b512Rng rng;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void k_widen(const Fr *__restrict__ in, con
     }
 }
 // ... and back: V = sum_j lane_j 2^(32 j) (lanes < 2^63) = lo + hi 2^256, V mod p = (lo mod p) + hi * (2^256 mod p).  The device
-// twin of sc_wide_reduce (api.hip).
+// twin of sc_wide_reduce (abi.hip).
 __global__ __launch_bounds__(kBlock) void k_wide_fold(const uint64_t *__restrict__ lanes, const uint64_t n, Fr *__restrict__ out) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kBlock) void k_wide_fold(const uint64_t *__restrict
     do {                                                                                                                 \
         hipError_t e_ = (expr);                                                                                          \
         if (e_ != hipSuccess) {                                                                                          \
-            (void)hipGetLastError(); /* (not left behind as the thread's sticky error: see api.hip, HIP_TRY) */          \
+            (void)hipGetLastError(); /* (not left behind as the thread's sticky error: see prover_internal.hpp, HIP_TRY) */          \
             return sc_internal_fail(e_ == hipErrorOutOfMemory ? SC_ERR_OOM : SC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
                                     hipGetErrorString(e_), __FILE__, __LINE__);                                          \
         }                                                                                                                \
@@ -944,7 +944,7 @@ extern "C" int sc_gkr_phase_two(const uint64_t *f1g_idx, const uint64_t *f1g_val
     return SC_OK;
 }
 
-int sc_internal_allreduce_lanes(sc_comm *c, uint64_t *d_lanes, size_t n_words, hipStream_t s); // api.hip
+int sc_internal_allreduce_lanes(sc_comm *c, uint64_t *d_lanes, size_t n_words, hipStream_t s); // comm.hip
 int sc_internal_comm_ranks(sc_comm *c);
 
 // ---- f4: GKR initialisation with f1's non-zeros spread over several GPUs -------------------------------------------

@@ -244,11 +244,17 @@ struct ClaimArgs {
     FrHost lam[14];    // lam[claim_off(M) + s], s = 0..M, for M = 1..4
 };
 __host__ __device__ constexpr int claim_off(int M) { return (M - 1) * (M + 2) / 2; }
+// Widened lanes (8 x 64-bit per evaluation: 32-bit limbs zero-extended, summable across ranks) may carry a TAG in their top bits:
+// every rank's finalize step ORs wide_tag_of(seq) << kWideTagShift into its lanes, the integer all-reduce adds the tags up, and a word
+// whose top bits read nranks * tag is this round's total -- RCCL can then deliver straight into host-mapped memory and the host's
+// poll is the fetch (no publish kernel, no flag).  The lanes themselves stay below 2^40 (sums of 32-bit limbs over <= 16 ranks).
+constexpr int kWideTagShift = 44;
+__host__ __device__ constexpr uint32_t wide_tag_of(uint32_t seq) { return (seq & 0x7fffu) + 1u; } // 1 .. 2^15: nranks * tag < 2^20 for <= 16 ranks
 bool finalize_keeps_sums(int K, int D, int nblocks, bool have_host_prods, bool have_counter);
 // h_prods_or_null: host copy of the records; with at most kMetaProds products they travel as a kernel argument
 hipError_t launch_finalize(const FinProd *d_prods, const FinProd *h_prods_or_null, const FrHost *d_W, int K, int D, int nblocks, const FrHost *d_partials, FrHost *d_scratch,
                            FrHost *d_out, uint64_t *d_out_wide, FrHost *h_out_mapped, uint32_t *h_flag_mapped, uint32_t seq,
-                           int scaled, uint32_t *d_counter_or_null, hipStream_t stream, const ClaimArgs *claim_or_null = nullptr);
+                           int scaled /* bit 0: scaled partials; bit 1: tagged lanes */, uint32_t *d_counter_or_null, hipStream_t stream, const ClaimArgs *claim_or_null = nullptr);
 // (d_counter_or_null: one zeroed device word owned by the caller selects the multi-block form, which needs d_scratch for K * D sums
 // and leaves the word at zero)
 hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);

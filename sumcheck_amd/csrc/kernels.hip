@@ -179,7 +179,7 @@ hipError_t launch_wait_challenge(uint32_t *flag_dev, uint32_t want, const FrHost
     return hipGetLastError();
 }
 
-// r_mail != nullptr: the launch was enqueued before the challenge existed (pipelined rounds, api.hip); the challenge is read from
+// r_mail != nullptr: the launch was enqueued before the challenge existed (pipelined rounds, protocol.hip); the challenge is read from
 // the device-memory mailbox that k_wait_challenge, the kernel in front of this one, filled
 __global__ __launch_bounds__(kBlock) void k_fix_multi(const TablePtrs tp, const FrHost r_h, const FrHost *__restrict__ r_mail, const uint64_t n_out) {
     const FrU r = fru_from_host(r_mail ? *r_mail : r_h); // uniform: scalar loads either way

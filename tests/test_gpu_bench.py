@@ -95,6 +95,12 @@ def test_bench_two_gpus_as_the_driver_types_it():
     c = d["config"]
     assert c["nv"] == 16 and c["nv_per_gpu"] == 15 and c["round_loop"].startswith("library") and "self-launched" in c["launcher"]
     assert c["ranks_seen"] == 2 and c["communicator"] == "host-transport" and c["exchange"]["exchange_us"] > 0 and c["exchange"]["bytes"] == 320
+    # every N > 1 line carries the scaling model's prediction for itself and what it assumed
+    pr = c["prediction"]
+    assert c["predicted_ms_per_step"] == pr["predicted_ms_per_step"] > 0 and c["exchange_assumed_us"] == pr["exchange_assumed_us"] > 0
+    assert pr["sharded_rounds"] + pr["replicated_rounds"] == 16 and pr["t1_ms"] > 0 and pr["gather_assumed_us"] > 0
+    assert abs(pr["measured_over_predicted"] - d["ms_per_step"] / pr["predicted_ms_per_step"]) < 1e-9
+    assert pr["predicted_ms_per_step_with_measured_exchange"] > pr["t1_ms"]
     assert "selftest passed" in c["round_loop_reason"]
 
 
@@ -127,14 +133,21 @@ def test_bench_rccl_code_path_with_a_world_of_one():
     env = dict(os.environ, SC_BENCH_FORCE_SHARDED="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SC_BENCH_ONE_GPU"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--nv", "19", "--steps", "2", "--warmup", "1"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--nv", "19", "--steps", "2", "--warmup", "1", "--min-gpu-seconds", "0.5"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     c = d["config"]
     assert c["communicator"] == "rccl" and c["ranks_seen"] == 1 and c["round_loop"] == "library+rccl" and "forced" in c["launcher"], c
     assert c["exchange"]["exchange_us"] > 0 and "selftest passed" in c["round_loop_reason"]
+    assert c["exchange"]["publication"].startswith("direct"), c["exchange"]  # the RCCL rounds run without a publish kernel (probed at sc_comm_init)
     assert d["parity"]["ok"] is True and d["parity"]["rounds_equal"] == 19, d["parity"]
+    # ... and with SC_RCCL_DIRECT=0 through the publish kernel, to the same bits
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--nv", "19", "--steps", "2", "--warmup", "1", "--min-gpu-seconds", "0.5",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env, SC_RCCL_DIRECT="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d0 = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d0["config"]["exchange"]["publication"].startswith("publish kernel") and d0["parity"]["ok"] is True, d0["config"]["exchange"]
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -939,7 +939,7 @@ def test_tail_slot_of_an_idle_interactive_handle_is_reclaimed_and_pooled_handles
 
 def test_provers_on_several_threads_share_one_gpu():
     """Three host threads, one GPU: two whole-proof provers (pipelined late rounds + persistent tail kernel) and a GKR prover,
-    each repeating its proof.  The library serialises its HIP calls per device (api.hip: DeviceGate) so that a kernel waiting
+    each repeating its proof.  The library serialises its HIP calls per device (prover_internal.hpp: DeviceGate) so that a kernel waiting
     for one thread's challenge never sits in front of another thread's blocked call; every proof must equal the oracle's."""
     import threading
 

@@ -331,7 +331,10 @@ def _comm_probe(c, kind, G):
     """sc_comm_info and sc_comm_exchange_bench on a live communicator"""
     r, n, k = C.c_int(), C.c_int(), C.c_int()
     _lib.check(sc.lib().sc_comm_info(c._h, C.byref(r), C.byref(n), C.byref(k)))
-    assert (n.value, k.value) == (G, kind) and 0 <= r.value < G
+    assert (n.value, k.value & 0xff) == (G, kind) and 0 <= r.value < G
+    # RCCL: direct publication (the all-reduce delivers tagged lanes into the host-mapped page) is probed at init and holds on this box;
+    # the other communicators never carry the flag
+    assert bool(k.value & 0x100) == (kind == 1 and os.environ.get("SC_RCCL_DIRECT") != "0"), k.value
     mean, mn = C.c_double(), C.c_double()
     _lib.check(sc.lib().sc_comm_exchange_bench(c._h, 40, 20, C.byref(mean), C.byref(mn)))  # 40 words = a degree-4 message
     assert 0 < mn.value <= mean.value
