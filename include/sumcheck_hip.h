@@ -340,7 +340,8 @@ SC_API int sc_set_cache_limit(uint64_t bytes);
  * that runs several provers on one GPU cannot see otherwise.  out[0] persistent-tail launches; [1] times a prover found the device's
  * one tail slot taken and ran its late rounds as pipelined launches instead; [2] times the slot was taken over from an interactive
  * handle whose resident kernel had already left; [3] resident kernels started by sc_prove_round; [4] calls that found theirs gone
- * (patience expired) and took the ordinary path; [5] proofs repeated after an expired device-side wait. */
+ * (patience expired) and took the ordinary path; [5] proofs repeated after an expired device-side wait; [6] of the launches in [0],
+ * those that kept the tables resident in LDS (k_tail_slices). */
 SC_API int sc_library_stats(uint64_t *out, uint32_t n);
 
 /* ---- synthetic inputs + instrumentation (bench / tests) ------------------------------------- */

@@ -62,4 +62,21 @@ __device__ __forceinline__ Fr block_sum(Fr acc, uint32_t (*sm)[8]) {
     return acc;
 }
 
+// the line through (lo, hi) at node nv (0, 1, inf, -1, 2, -2, 3, ...), limbs re-tightened to [-4, 2^29 + 4): fits either operand of fe_mul
+__device__ __forceinline__ Fe fe_line(const Fe &lo, const Fe &hi, const int32_t nv) {
+    if (nv == 0) return lo;
+    if (nv == 1) return hi;
+    const Fe step = fe_sub(hi, lo); // limbs in (-2^29, 2^29)
+    if (nv == kNodeInf) return step;
+    Fe cur;
+    if (nv < 0) {
+        cur = fe_sub(lo, step); // -1: 2 lo - hi, within 2^30
+        for (int32_t k = -1; k > nv; --k) cur = fe_sub(fe_carry_pass(cur), step);
+    } else {
+        cur = fe_add(hi, step); // 2: 2 hi - lo
+        for (int32_t k = 2; k < nv; ++k) cur = fe_add(fe_carry_pass(cur), step);
+    }
+    return fe_carry_pass(cur);
+}
+
 } // namespace scd

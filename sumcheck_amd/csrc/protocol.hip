@@ -787,7 +787,26 @@ bool tail_possible(sc_prover *p) {
 
 // Launch k_tail_rounds for the handle's next n_rounds rounds (the caller holds the device gate and the device's tail slot);
 // r_or_null = the challenge the first of them binds; max_spins = how long block 0 waits for each later challenge.
-int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null, uint32_t max_spins, scd::TailArgs &A, int &grid) {
+// The tables resident in LDS for the whole tail (kernels_tail.hip: k_tail_slices) where the shape allows: every product in carry-free
+// arithmetic, the slices within a CU's LDS.  SC_TAIL_SLICES=0: k_tail_rounds everywhere (A/B runs, tests of the older path).
+int tail_slices_blocks_for(sc_prover *p) {
+    static const bool env_on = !(std::getenv("SC_TAIL_SLICES") && std::atoi(std::getenv("SC_TAIL_SLICES")) == 0);
+    if (!env_on || p->max_mult > (uint32_t)scd::kMaxFusedM || p->round >= p->nv) return 0;
+    const int B = scd::tail_slices_blocks(1ULL << (p->nv - (p->round + 1)), (int)p->U, (int)p->K, (int)p->D, p->n_combos);
+    if (B <= 0) return 0;
+    if (!p->d_tail_xw) { // tagged hand-over words, owned by the handle: zero once, tags only ever grow
+        if (hipMalloc(reinterpret_cast<void **>(&p->d_tail_xw), scd::kTsXwWords * 8) != hipSuccess ||
+            hipMemsetAsync(p->d_tail_xw, 0, scd::kTsXwWords * 8, p->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            if (p->d_tail_xw) (void)hipFree(p->d_tail_xw);
+            p->d_tail_xw = nullptr;
+            return 0;
+        }
+        p->ts_tag = 1;
+    }
+    return B;
+}
+int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null, uint32_t max_spins, scd::TailArgs &A, int &grid, int slices_B = 0) {
     const uint32_t D = p->D;
     std::memset(&A, 0, sizeof(A));
     for (uint32_t u = 0; u < p->U; ++u) {
@@ -827,6 +846,18 @@ int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null, uint3
         grid = (int)std::min<uint64_t>((uint64_t)p->tail_max_blocks, std::max(bind_blocks, sum_blocks));
     }
     HIP_TRY(scd::launch_zero_words(p->d_tail_sync, (uint32_t)((kTailSyncBytes + 64) / 4), p->stream));
+    if (slices_B > 0) {
+        scd::TailSlicesArgs S;
+        std::memset(&S, 0, sizeof(S));
+        S.base = A;
+        S.B = slices_B;
+        S.xw = p->d_tail_xw;
+        S.tag0 = p->ts_tag;
+        p->ts_tag += n_rounds;
+        grid = slices_B;
+        HIP_TRY(scd::launch_tail_slices(S, p->meta, fm, p->stream));
+        return SC_OK;
+    }
     HIP_TRY(scd::launch_tail_rounds(A, p->meta, fm, grid, p->stream));
     return SC_OK;
 }
@@ -869,9 +900,11 @@ int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, const sch
     const uint32_t D = p->D;
     scd::TailArgs A;
     int grid = 1;
-    int rc_l = tail_launch(p, n_rounds, r_or_null, scd::wait_spins_default(), A, grid);
+    const int slices_B = tail_slices_blocks_for(p);
+    int rc_l = tail_launch(p, n_rounds, r_or_null, scd::wait_spins_default(), A, grid, slices_B);
     if (rc_l) return rc_l;
     g_stat[kStatTailLaunches].fetch_add(1, std::memory_order_relaxed);
+    if (slices_B > 0) g_stat[kStatTailSlices].fetch_add(1, std::memory_order_relaxed);
     gate.release();
     p->seq += n_rounds;
     p->sig_seq += n_rounds - 1;

@@ -161,6 +161,8 @@ struct sc_prover {
     FrHost *h_mail_dev = nullptr;
     FrHost *d_mail = nullptr;       // device-memory copy of the slot in use (two slots), filled by the wait kernel
     uint32_t *d_tail_sync = nullptr; // persistent tail kernel: 4 sync words + 2 challenge slots (device)
+    uint64_t *d_tail_xw = nullptr;   // k_tail_slices: tagged hand-over words (kTsXwWords), and the next launch's first tag
+    uint32_t ts_tag = 1;
     int tail_max_blocks = 0;        // blocks of it the device holds at once (its grid never exceeds that)
     uint64_t arena_bytes = 0;       // size of the bound-table arena (what a pooled handle keeps allocated)
     std::vector<uint8_t> pool_key;  // non-empty: created by sc_ml_prove; sc_prover_free offers it back to the pool (handle_pool_*)
@@ -221,7 +223,7 @@ uint64_t sc_internal_cache_limit();
 // ---- protocol.hip ----
 constexpr int kResidentGone = -1; // internal: no resident kernel serves this round; take the ordinary path
 extern std::atomic<uint64_t> g_stat[8]; // process-wide counters a host can read (sc_library_stats)
-enum { kStatTailLaunches = 0, kStatTailSlotBusy = 1, kStatTailSlotReclaims = 2, kStatResidentStarts = 3, kStatResidentGone = 4, kStatProofRetries = 5 };
+enum { kStatTailLaunches = 0, kStatTailSlotBusy = 1, kStatTailSlotReclaims = 2, kStatResidentStarts = 3, kStatResidentGone = 4, kStatProofRetries = 5, kStatTailSlices = 6 };
 int resident_quiesce(sc_prover *p); // the interactive protocol's resident kernel leaves before anything else touches the handle
 int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool publish_to_host, bool deferred = false);
 int await_round(sc_prover *p, uint64_t *out_evals, uint32_t want);

@@ -1,6 +1,7 @@
 """GPU parity tests (-m gpu): the HIP path through the C ABI against the golden fixtures and the C oracle,
 bit-exact on identical inputs; plus size-independent properties at BASELINE's full sizes."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1070,3 +1071,57 @@ def test_one_shot_proofs_reuse_the_kept_prover():
         if it == 4:
             _lib.check(sc.lib().sc_release_caches())
     torch.cuda.synchronize()
+
+
+TAIL_SHAPES = [
+    (12, 10, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]),  # 2048 pairs: 64 blocks, six hand-over rounds, then block 0 alone
+    (13, 2, [[0, 1]]),                                 # a GKR phase's shape; the tail starts behind a pipelined round (its first round binds)
+    (8, 3, [[0, 1, 2]]),                               # 128 pairs: the block count follows the tail's length
+    (5, 12, [[0, 1, 2, 3, 4, 5, 6, 7], [8, 9, 10], [11, 11]]),  # one block from the start; eight multiplicands, a repeated table
+    (16, 7, [[0, 1, 2, 3], [4, 5, 6], [1, 1], [2], [3, 3, 3], [5, 6, 6, 0]]),  # tables arrive from the big rounds in the internal format
+]
+
+
+@pytest.mark.parametrize("nv,nt,shapes", TAIL_SHAPES)
+def test_tail_with_tables_resident_in_lds(nv, nt, shapes):
+    """k_tail_slices (kernels_tail.hip): the latency-bound rounds of a whole proof out of LDS.  Whole Fiat-Shamir proofs against the
+    oracle, the state the tail leaves behind (randomness, the final two-entry tables: written back from LDS), the library's count of
+    such launches -- and the same proof through k_tail_rounds (SC_TAIL_SLICES=0, its own process) to the same bits."""
+    import subprocess
+    import sys
+    tabs = [cref.synth_table(4242 + nv, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(4242 + nv, 1000, len(shapes))
+    d = H.desc_from(nv, shapes, tabs, coefs)
+    want, wrand = cref.ml_prove(d, threads=cref.max_threads())
+    poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device="cuda:0")
+    stats = (C.c_uint64 * 8)()
+    _lib.check(sc.lib().sc_library_stats(stats, 8))
+    before = (stats[0], stats[6])
+    st = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+    for rep in range(3):  # (the handle's tags only grow: a second and third proof on the rewound handle)
+        st.reset()
+        proof = st.prove()
+        assert np.array_equal(np.asarray(proof).reshape(want.shape), want), f"proof {rep}"
+    _lib.check(sc.lib().sc_library_stats(stats, 8))
+    assert stats[0] - before[0] == 3 and stats[6] - before[1] == 3, (list(stats), before)  # every tail ran out of LDS
+    op = cref.Prover(d, threads=cref.max_threads())
+    v = None
+    for i in range(nv):
+        op.prove_round(v)
+        v = wrand[i]
+    _, otabs, _ = op.state()
+    assert np.array_equal(st.randomness, wrand)
+    for u, t in enumerate(st.flattened_ml_extensions):
+        assert np.array_equal(t.evaluations, otabs[u]), f"final table {u}"
+    code = (
+        "import sys, numpy as np, ctypes as C\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "import sumcheck_amd as sc\nfrom oracle import cref\nfrom tests import helpers as H\nfrom sumcheck_amd import _lib\n"
+        f"nv, nt, shapes = {nv}, {nt}, {shapes!r}\n"
+        "tabs = [cref.synth_table(4242 + nv, s, 1 << nv) for s in range(nt)]\ncoefs = cref.synth_table(4242 + nv, 1000, len(shapes))\n"
+        "poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device='cuda:0')\nproof = sc.MLSumcheck.prove(poly)\n"
+        "stats = (C.c_uint64 * 8)()\n_lib.check(sc.lib().sc_library_stats(stats, 8))\nassert stats[0] == 1 and stats[6] == 0, list(stats)\n"
+        "sys.stdout.write(np.stack([m.evaluations for m in proof]).tobytes().hex())\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, SC_TAIL_SLICES="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert bytes.fromhex(r.stdout.strip().splitlines()[-1]) == want.tobytes()
