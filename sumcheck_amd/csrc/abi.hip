@@ -141,6 +141,7 @@ void prover_destroy(sc_prover *p) {
     if (p->d_mail) (void)hipFree(p->d_mail);
     if (p->d_tail_sync) (void)hipFree(p->d_tail_sync);
     if (p->d_tail_xw) (void)hipFree(p->d_tail_xw);
+    if (p->d_vram_mail) (void)hipFree(p->d_vram_mail);
     if (p->d_cur_tables) (void)hipFree(p->d_cur_tables);
     if (p->h_cur_tables) (void)hipHostFree(p->h_cur_tables);
     if (p->d_slot_table) (void)hipFree(p->d_slot_table);

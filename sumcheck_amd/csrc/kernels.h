@@ -183,19 +183,25 @@ struct TailArgs {
 };
 // The same rounds with the tables resident in LDS (kernels_tail.hip: k_tail_slices): block g of B owns a contiguous range of every
 // table for the whole launch; one hand-over per round (its sums -> block 0) as self-validating words in `xw`.
-constexpr int kTsBlock = 256, kTsMaxBlocks = 64;
-constexpr size_t kTsXwWords = (size_t)kTsMaxBlocks * kMetaCombos * 8 + (size_t)kTsMaxBlocks * kMaxSmallTables * 10 + 8; // partial sums | last entries (nine limbs + a filler) | the challenge
+constexpr int kTsBlock = 256, kTsMaxBlocks = 256;
+constexpr uint64_t kTsMaxPairs = 1u << 16; // it takes over from the first latency-bound round (kSmallRoundPairs) where the slices fit LDS, and up to two
+                                           // rounds earlier for shapes with few multiplications per pair (tail_slices_blocks)
+// hand-over area (64-bit words): a ring of four accumulator sets (8 groups x kMetaCombos x 8 words) | the last entries of merging blocks
+// ([table][block][9 limbs + a filler]) | the challenge as block 0 passes it on
+constexpr size_t kTsAccWords = 4 * 8 * (size_t)kMetaCombos * 8;
+constexpr size_t kTsXwWords = kTsAccWords + (size_t)kTsMaxBlocks * kMaxSmallTables * 10 + 8;
 struct TailSlicesArgs {
     TailArgs base;        // the rounds, tables, finalize data and host mailbox, as k_tail_rounds takes them (sync[3] = the stop word)
     int B;                // blocks: a power of two <= kTsMaxBlocks (tail_slices_blocks)
-    uint64_t *xw;         // device, kTsXwWords words, zero when allocated and owned by the handle: words carry value | tag << 32
+    uint64_t *xw;         // device, kTsXwWords words, owned by the handle; zero when allocated, its first kTsAccWords zeroed before every launch
+    const uint64_t *mail_vram; // non-null: the challenge mailbox in device memory (the host stores into it over the BAR); EVERY block polls it
     uint32_t tag0;        // tag of this launch's first round; >= 1 and above every tag an earlier launch of the handle used
     uint32_t fin_bytes;   // (filled in by the launcher: LDS layout)
     uint32_t lds_entries;
     uint32_t stage_off;
 };
 // blocks for a tail that starts with `first_pairs` pairs, or 0 when the slices do not fit LDS (the caller then takes k_tail_rounds)
-int tail_slices_blocks(uint64_t first_pairs, int n_tables, int K, int D, int n_combos);
+int tail_slices_blocks(uint64_t first_pairs, int n_tables, int K, int D, int n_combos, int max_multiplicands);
 hipError_t launch_tail_slices(TailSlicesArgs args, const ComboMeta &meta, const FinMeta &fin, hipStream_t stream);
 int tail_max_resident_blocks(int device); // co-resident blocks of the tail kernel (0: unknown -> the tail kernel is not used)
 uint32_t wait_spins_default(); // bound of the device-side polls for a challenge (SC_WAIT_SPINS overrides it: tests)

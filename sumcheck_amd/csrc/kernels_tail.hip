@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
     const TailArgs &A = S.base;
     extern __shared__ uint4 dyn_lds[];
     uint4 *fin_lds = dyn_lds;                                                                     // finalize_message's scratch
-    int32_t *tabs = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(dyn_lds) + S.fin_bytes); // [table][entry][9]
+    int32_t *tabs = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(dyn_lds) + S.fin_bytes); // [table][entry][kTsEnt]
     __shared__ uint64_t r_sh[4];
     __shared__ uint32_t stop_sh;
     __shared__ Combo combo_sh[kMetaCombos];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
     __shared__ uint32_t part_sh[kMetaCombos * 8]; // this block's sums of the round, canonical words, on their way out
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(S.xw, 0, (int)(kTsXwWords * 8), 0x00020000); // (kernel argument: uniform)
     const int tid = threadIdx.x;
-    const uint32_t g = blockIdx.x, B = gridDim.x;
+    uint32_t g = blockIdx.x, B = gridDim.x; // this block's index among the B blocks still at work (both shrink when blocks merge)
     const int U = A.n_tables;
     const uint32_t cap = S.lds_entries; // entries per table the LDS area holds
     for (int i = tid; i < kMetaCombos; i += kTsBlock) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
     }
     if (tid == 0) stop_sh = 0;
     auto prod_of = [&](int k) -> FinProd { return fin.prod[k]; };
-    auto tab_at = [&](int u, uint32_t e) -> int32_t * { return tabs + ((size_t)u * cap + e) * kTsEnt; };
+    auto tab_at = [&](int u, uint32_t e) -> int32_t * { return tabs + ((uint32_t)u * cap + e) * (uint32_t)kTsEnt; }; // (32-bit index arithmetic: LDS)
     const uint32_t wait_spins = A.max_spins > (1u << 20) ? A.max_spins : (1u << 20); // hand-overs between blocks: bounded, but never by the patience for the host
     uint32_t *stop_word = A.sync + kTsStop;
     uint32_t *giveup = A.sig + 1;
@@ -110,27 +110,46 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
     while (L * A.n_combos > kTsBlock) L >>= 1;
     const int my_combo = tid / L, my_q = tid % L;
     const bool combo_live = my_combo < A.n_combos;
+    const uint32_t wpb = (uint32_t)A.n_combos * 8; // words of a block's sums
+    __syncthreads(); // (the metadata above)
+    // this lane's combination, once: its node and, per slot, the table's LDS base (in entries) and the multiplicity
+    const Combo my_c = combo_sh[combo_live ? my_combo : 0];
+    const int32_t my_nv = node_value((int)my_c.t);
+    uint32_t my_base[kMaxFusedM], my_exp[kMaxFusedM];
+#pragma unroll
+    for (int sl = 0; sl < kMaxFusedM; ++sl) {
+        const bool in = (uint32_t)sl < my_c.n_slots;
+        my_base[sl] = in ? slot_table_sh[my_c.slot_off + sl] * cap : 0u;
+        my_exp[sl] = in ? slot_exp_sh[my_c.slot_off + sl] : 0u;
+    }
 
     uint64_t n_pairs = A.first_pairs; // pairs of the round in hand, over all blocks
-    bool solo = B == 1;               // this block holds every entry that is left
     uint32_t E = 0;                   // entries per table this block holds
     int binds = 0;
     for (int j = 0; j < A.n_rounds; ++j, n_pairs >>= 1) {
         const uint32_t tag = S.tag0 + (uint32_t)j;
         const bool has_bind = j > 0 || A.first_has_bind;
         TS_STAMP(j, 0); // round start
-        // ---- the round's challenge: with the launch (round 0), or from the host-mapped mailbox -- every block fetches it itself --------
+        // ---- the round's challenge: with the launch (round 0), or from the mailbox ---------------------------------------------------
         if (has_bind) {
             if (j == 0) {
                 if (tid < 4) r_sh[tid] = A.r0.l[tid];
             } else if (tid < 64) {
-                // block 0 asks the host (one poller: 64 blocks polling over PCIe would queue up behind each other's reads); the others take
-                // the challenge from eight tagged words block 0 leaves in device memory -- again the poll is the fetch
                 const uint32_t want = A.sig0 + (uint32_t)j;
-                uint64_t *bc = S.xw + kTsXwWords - 8;
                 uint64_t w = 0;
                 bool seen = false;
-                if (g == 0) {
+                if (S.mail_vram) {
+                    // the mailbox is in device memory (the host stores into it over the BAR): every block polls it itself, locally
+                    for (uint32_t spin = 0; spin < 8 * A.max_spins; ++spin) { // (a local poll is ~10x shorter than one over PCIe: same patience)
+                        if (tid < 8) w = __hip_atomic_load(S.mail_vram + 8 * (want & 1u) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const bool mine = tid >= 8 || (uint32_t)w == want;
+                        if (__all(mine)) { seen = true; break; }
+                        if ((spin & 255u) == 255u && __hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                } else if (g == 0) {
+                    // block 0 asks the host (one poller: many blocks polling over PCIe queue up behind each other's reads); the others take
+                    // the challenge from eight tagged words block 0 leaves in device memory -- again the poll is the fetch
                     for (uint32_t spin = 0; spin < A.max_spins; ++spin) {
                         if (tid < 8) w = __hip_atomic_load(A.mail_host + 8 * (want & 1u) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         const bool mine = tid >= 8 || (uint32_t)w == want;
@@ -144,6 +163,7 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
                         if (seen && tid < 4) ts_store_pair(xrs, (uint32_t)(kTsXwWords - 8) + 2 * (uint32_t)tid, a, b2, tag);
                     }
                 } else {
+                    const uint64_t *bc = S.xw + kTsXwWords - 8;
                     for (uint32_t spin = 0; spin < wait_spins; ++spin) {
                         if (tid < 8) w = __hip_atomic_load(bc + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const bool mine = tid >= 8 || (uint32_t)(w >> 32) == tag;
@@ -222,24 +242,23 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
             binds += 1;
             __syncthreads();
         }
-        // ---- fewer pairs than blocks from here on: every block ships its last entry of every table to block 0 and leaves -------------
-        if (!solo && E == 1) {
-            // (layout [table][block][limb]: word i of the area goes to LDS word i of a table area with B entries per table -- no index arithmetic
-            // beyond a division by the constant 9 on block 0's side)
-            const int shB = 31 - __builtin_clz(B);
-            // (an entry = nine limbs + one filler word = five 16-byte pairs)
-            const uint32_t xfer_w0 = (uint32_t)kTsMaxBlocks * kMetaCombos * 8;
+        // ---- fewer pairs than blocks: groups of R adjacent blocks ship their last entry of every table to the group's first block
+        // and leave; the survivors hold R entries each and carry on (R = 16, or all that are left) ----------------------------------------
+        if (B > 1 && E == 1) {
+            const uint32_t R = B < 16u ? B : 16u;
+            const int shR = 31 - __builtin_clz(R);
+            // (an entry = nine limbs + one filler word = five 16-byte pairs; layout [table][block][10 words])
             for (int i = tid; i < U * 5; i += kTsBlock) {
                 const int u = i / 5, pr = i % 5;
                 const int32_t *e0 = tab_at(u, 0);
-                ts_store_pair(xrs, xfer_w0 + ((uint32_t)u * B + g) * 10 + 2 * (uint32_t)pr, (uint32_t)e0[2 * pr], pr < 4 ? (uint32_t)e0[2 * pr + 1] : 0u, tag);
+                ts_store_pair(xrs, (uint32_t)kTsAccWords + ((uint32_t)u * B + g) * 10 + 2 * (uint32_t)pr, (uint32_t)e0[2 * pr], pr < 4 ? (uint32_t)e0[2 * pr + 1] : 0u, tag);
             }
-            if (g != 0) return;
-            __syncthreads(); // (block 0's own entry 0 of every table is about to be overwritten by the same value: harmless, but ordered)
+            if ((g & (R - 1)) != 0) return;
+            __syncthreads(); // (the leader's own entry 0 of every table is about to be overwritten by the same value: harmless, but ordered)
             // (requests in batches of kXferBatch pairs per lane, all in flight before the first is looked at: one trip to memory per batch)
             bool ok = true;
-            constexpr int kXferBatch = 16;
-            const uint32_t total_p = B * (uint32_t)U * 5; // pairs
+            constexpr int kXferBatch = 12;
+            const uint32_t per_table = R * 5, total_p = (uint32_t)U * per_table; // pairs: [table][member][5]
             for (uint32_t c0 = 0; c0 < total_p && ok; c0 += kXferBatch * kTsBlock) {
                 ts_v4 w[kXferBatch];
                 bool got = false;
@@ -247,7 +266,11 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
                     got = true;
 #pragma unroll
                     for (int k = 0; k < kXferBatch; ++k) {
-                        if (c0 + (uint32_t)k * kTsBlock < total_p) w[k] = ts_load_pair(xrs, xfer_w0 + 2 * min(c0 + (uint32_t)k * kTsBlock + (uint32_t)tid, total_p - 1));
+                        if (c0 + (uint32_t)k * kTsBlock < total_p) {
+                            const uint32_t i = min(c0 + (uint32_t)k * kTsBlock + (uint32_t)tid, total_p - 1);
+                            const uint32_t ent = i / 5, pr = i - 5 * ent; // ent = table * R + member
+                            w[k] = ts_load_pair(xrs, (uint32_t)kTsAccWords + ((ent >> shR) * B + g + (ent & (R - 1))) * 10 + 2 * pr);
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < kXferBatch; ++k)
@@ -262,8 +285,8 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
                 for (int k = 0; k < kXferBatch; ++k) {
                     if (c0 + (uint32_t)k * kTsBlock < total_p) {
                         const uint32_t i = min(c0 + (uint32_t)k * kTsBlock + (uint32_t)tid, total_p - 1);
-                        const uint32_t ent = i / 5, pr = i - 5 * ent; // ent = table * B + block
-                        int32_t *dst = tab_at((int)(ent >> shB), ent & (B - 1));
+                        const uint32_t ent = i / 5, pr = i - 5 * ent;
+                        int32_t *dst = tab_at((int)(ent >> shR), ent & (R - 1));
                         dst[2 * pr] = (int32_t)w[k].x;
                         if (pr < 4) dst[2 * pr + 1] = (int32_t)w[k].z;
                     }
@@ -275,72 +298,72 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
                 if (tid == 0) give_up(A.sig0 + (uint32_t)j + 1u);
                 return;
             }
-            E = B;
-            solo = true;
+            E = R;
+            g >>= shR;
+            B >>= shR;
         }
-        TS_STAMP(j, 2); // slice bound (and, once, collected in block 0)
+        TS_STAMP(j, 2); // slice bound (and, where blocks merged, collected)
         // ---- sums: lane (combination, q) multiplies out the combination's pairs q, q + L, ... of this block ---------------------------
         const uint32_t pairs_here = E / 2;
         Fe acc = fe_zero();
         if (combo_live) {
-            const Combo c = combo_sh[my_combo];
-            const int32_t nv = node_value((int)c.t);
+            const int32_t nv = my_nv;
             uint32_t iter = 0;
             for (uint32_t pr = (uint32_t)my_q; pr < pairs_here; pr += (uint32_t)L, ++iter) {
                 Fe prod = fe_zero();
                 bool first = true;
-                for (uint32_t s = 0; s < c.n_slots; ++s) {
-                    const int u = (int)slot_table_sh[c.slot_off + s];
+#pragma unroll
+                for (int sl = 0; sl < kMaxFusedM; ++sl) {
+                    if (my_exp[sl] == 0) break; // (slots are dense: the first empty one ends the list)
+                    const int32_t *lo_p = tabs + (my_base[sl] + 2 * pr) * (uint32_t)kTsEnt;
                     Fe val;
-                    if (nv == 0) val = ts_lds_load(tab_at(u, 2 * pr));
-                    else if (nv == 1) val = ts_lds_load(tab_at(u, 2 * pr + 1));
-                    else val = fe_line(ts_lds_load(tab_at(u, 2 * pr)), ts_lds_load(tab_at(u, 2 * pr + 1)), nv);
+                    if (nv == 0) val = ts_lds_load(lo_p);
+                    else if (nv == 1) val = ts_lds_load(lo_p + kTsEnt);
+                    else val = fe_line(ts_lds_load(lo_p), ts_lds_load(lo_p + kTsEnt), nv);
                     uint32_t k = 0;
                     if (first) { prod = val; k = 1; first = false; }
-                    for (const uint32_t e = slot_exp_sh[c.slot_off + s]; k < e; ++k) prod = fe_mul<true>(val, prod);
+                    for (const uint32_t e = my_exp[sl]; k < e; ++k) prod = fe_mul<true>(val, prod);
                 }
                 acc = fe_carry_pass(fe_add(acc, prod));
-                if ((iter & 31u) == 31u) acc = fe_from_fr(fe_to_fr(acc)); // (keeps the top limb far from 2^31; never reached with <= 2048 pairs)
+                if ((iter & 31u) == 31u) acc = fe_from_fr(fe_to_fr(acc)); // (keeps the top limb far from 2^31; never reached here)
             }
         }
         for (int off = L >> 1; off >= 1; off >>= 1) acc = fe_carry_pass(fe_add(acc, fe_shfl_down(acc, off)));
         TS_STAMP(j, 3); // this block's sums
-        if (solo) {
+        if (B == 1) {
             if (combo_live && my_q == 0) fr_store(fin_lds + 2 * (prod_index_sh[my_combo] * A.D + (int)combo_sh[my_combo].t), fe_to_fr(acc));
         } else {
-            // this block's sums -> block 0, canonical, as eight self-validating words per combination: through LDS, so that the words of
-            // a combination leave as four 16-byte stores of four lanes of ONE instruction (block 0 keeps its own in LDS)
-            const uint32_t wpb = (uint32_t)A.n_combos * 8;
+            // ---- this block's sums -> block 0.  The canonical 32-bit words are ADDED, by the memory system, into 64-bit accumulators:
+            // (1 << 44 | word) per block, so that a word whose top bits read the number of its contributors IS complete -- block 0's poll
+            // of the accumulators is the fetch of the sums (a few hundred words whatever the number of blocks).  Eight groups of blocks
+            // (g & 7) keep a sum below 32 p (fe_to_fr's range); a ring of four accumulator sets, the one of round j + 2 zeroed by block 0.
             if (combo_live && my_q == 0) {
                 const Fr sv = fe_to_fr(acc);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) part_sh[my_combo * 8 + i] = sv.v[i];
             }
             __syncthreads();
-            if (g != 0 && (uint32_t)tid < wpb / 2) ts_store_pair(xrs, g * wpb + 2 * (uint32_t)tid, part_sh[2 * tid], part_sh[2 * tid + 1], tag);
+            const uint32_t groups = B < 8u ? B : 8u, per_group = B / groups;
+            uint64_t *ring = S.xw + (size_t)(j & 3) * (8 * kMetaCombos * 8);
+            if ((uint32_t)tid < wpb)
+                (void)__hip_atomic_fetch_add(ring + (g & (groups - 1)) * wpb + (uint32_t)tid, (1ULL << 44) | (uint64_t)part_sh[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (g == 0) {
-                // block 0 collects (B - 1) x n_combos x 8 words.  Lane <-> pair of words, in memory order (a block's words are contiguous:
-                // every wave instruction reads whole lines), every request of a lane in flight before it looks at the first, every wave
-                // sweeping on its own until its pairs carry the tag; the values go to LDS, where the 32-bit words of a combination are added
-                // up over the blocks in 64-bit lanes (no carries: < 2^38) -- two halves of the blocks separately, so that each half
-                // (< 32 p) is within fe_to_fr's range -- and folded back into field elements.
-                constexpr int kGatherMax = (kMetaCombos * kTsMaxBlocks * 4 + kTsBlock - 1) / kTsBlock;
-                const uint32_t total_w = B * wpb, total_p = (B - 1) * (wpb / 2); // pairs of the other blocks, from word wpb on
-                uint32_t *stage = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dyn_lds) + S.stage_off); // [block][combination * 8 + word]
-                if ((uint32_t)tid < wpb) stage[tid] = part_sh[tid];
+                constexpr int kGatherMax = (8 * kMetaCombos * 4 + kTsBlock - 1) / kTsBlock; // pairs of words per lane
+                const uint32_t total_p = groups * wpb / 2, ring_w0 = (uint32_t)(j & 3) * (8 * kMetaCombos * 8);
+                uint64_t *stage = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(dyn_lds) + S.stage_off); // [group][combination * 8 + word]
                 ts_v4 w[kGatherMax];
                 bool got = false;
                 for (uint32_t spins = 0; spins <= wait_spins && !got; ++spins) {
                     bool mine = true;
                     // (no per-lane predication: a lane past the end re-reads the last pair -- clamped address -- and only wave-uniform
-                    // branches skip the unused passes; predicated loads would wait for each other and cost a mask dance per pass)
+                    // branches skip the unused passes)
 #pragma unroll
                     for (int k = 0; k < kGatherMax; ++k) {
-                        if ((uint32_t)k * kTsBlock < total_p) w[k] = ts_load_pair(xrs, wpb + 2 * min((uint32_t)k * kTsBlock + (uint32_t)tid, total_p - 1));
+                        if ((uint32_t)k * kTsBlock < total_p) w[k] = ts_load_pair(xrs, ring_w0 + 2 * min((uint32_t)k * kTsBlock + (uint32_t)tid, total_p - 1));
                     }
 #pragma unroll
                     for (int k = 0; k < kGatherMax; ++k)
-                        if ((uint32_t)k * kTsBlock < total_p) mine = mine && w[k].y == tag && w[k].w == tag;
+                        if ((uint32_t)k * kTsBlock < total_p) mine = mine && (w[k].y >> 12) == per_group && (w[k].w >> 12) == per_group;
                     got = __all(mine) != 0;
                     if (!got) {
                         if ((spins & 63u) == 63u && __hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
@@ -348,43 +371,24 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
                     }
                 }
                 if (!got) stop_sh = 1; // (benign race: every writer stores 1)
-                TS_STAMP(j, 6); // every block's words seen (this wave's)
+                TS_STAMP(j, 6); // every block's words are in (this wave's share)
 #pragma unroll
                 for (int k = 0; k < kGatherMax; ++k) {
                     if ((uint32_t)k * kTsBlock < total_p) { // (lanes past the end store the last pair again)
                         const uint32_t pi = min((uint32_t)k * kTsBlock + (uint32_t)tid, total_p - 1);
-                        stage[wpb + 2 * pi] = w[k].x;
-                        stage[wpb + 2 * pi + 1] = w[k].z;
+                        stage[2 * pi] = (uint64_t)w[k].x | ((uint64_t)(w[k].y & 0xfffu) << 32);
+                        stage[2 * pi + 1] = (uint64_t)w[k].z | ((uint64_t)(w[k].w & 0xfffu) << 32);
                     }
                 }
                 __syncthreads();
-                uint64_t *wsum = reinterpret_cast<uint64_t *>(stage + total_w); // [half][combination * 8 + word]
-                for (uint32_t i = tid; i < 2 * wpb; i += kTsBlock) {
-                    const uint32_t half = i / wpb, cq = i % wpb;
-                    uint64_t acc64 = 0;
-                    const uint32_t *col = stage + (size_t)half * (B / 2) * wpb + cq;
-                    uint32_t bb = 0;
-                    for (; bb + 8 <= B / 2; bb += 8) { // eight LDS reads in flight
-                        uint32_t x[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) x[q] = col[(bb + q) * wpb];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) acc64 += x[q];
-                    }
-                    for (; bb < B / 2; ++bb) acc64 += col[bb * wpb];
-                    wsum[i] = acc64;
-                }
-                __syncthreads();
-                TS_STAMP(j, 7); // word sums
-                Fr *hsum = reinterpret_cast<Fr *>(wsum + 2 * wpb); // [half][combination]
-                if (tid < 2 * A.n_combos) {
-                    const uint32_t half = (uint32_t)tid / (uint32_t)A.n_combos, ci = (uint32_t)tid % (uint32_t)A.n_combos;
-                    // sum_q S_q 2^(32 q), S_q < 2^38: carry through eight 32-bit words; what is left over (< 2^6) sits at 2^256 = 2^24 in limb 8
+                Fr *hsum = reinterpret_cast<Fr *>(stage + groups * wpb); // [group][combination]
+                if ((uint32_t)tid < groups * (uint32_t)A.n_combos) {
+                    // sum_q S_q 2^(32 q), S_q < 2^37: carry through eight 32-bit words; what is left over (< 2^6) sits at 2^256 = 2^24 in limb 8
                     Fr x;
                     uint64_t carry = 0;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const uint64_t t = wsum[half * wpb + ci * 8 + q] + carry;
+                        const uint64_t t = stage[(uint32_t)tid * 8 + q] + carry; // (group-major, combination, word: the same order as the lanes)
                         x.v[q] = (uint32_t)t;
                         carry = t >> 32;
                     }
@@ -392,8 +396,13 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
                     v.l[8] += (int32_t)(carry << 24);
                     hsum[tid] = fe_to_fr(v);
                 }
+                TS_STAMP(j, 7); // folded per group
                 __syncthreads();
-                if (tid < A.n_combos) fr_store(fin_lds + 2 * (prod_index_sh[tid] * A.D + (int)combo_sh[tid].t), fr_add(hsum[tid], hsum[A.n_combos + tid]));
+                if (tid < A.n_combos) {
+                    Fr r = hsum[tid];
+                    for (uint32_t q = 1; q < groups; ++q) r = fr_add(r, hsum[q * (uint32_t)A.n_combos + (uint32_t)tid]);
+                    fr_store(fin_lds + 2 * (prod_index_sh[tid] * A.D + (int)combo_sh[tid].t), r);
+                }
             }
         }
         if (g == 0) {
@@ -402,41 +411,52 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
                 if (tid == 0) give_up(A.sig0 + (uint32_t)j + 1u);
                 return;
             }
-            TS_STAMP(j, 4); // node sums complete (every block's partials in)
+            TS_STAMP(j, 4); // node sums complete (every block's in)
             finalize_message<kTsBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 1, (const Fr *)nullptr);
             TS_STAMP(j, 5); // message published
+            if (B > 1) { // the accumulators of round j + 2 (last used in round j - 2: complete and read long ago)
+                const uint32_t z0 = (uint32_t)((j + 2) & 3) * (8 * kMetaCombos * 8);
+                for (uint32_t i = tid; i < 8 * kMetaCombos * 4; i += kTsBlock) ts_store_pair(xrs, z0 + 2 * i, 0u, 0u, 0u);
+            }
             __syncthreads(); // (fin_lds is written again by the next round's sums)
         }
     }
     // ---- the tables as the rounds left them, in the reference layout, where the handle expects them after `binds` binds ------------------
     if (binds > 0) {
         const uint32_t total = E * (uint32_t)U;
+        const int shE = 31 - __builtin_clz(E);
         for (uint32_t i = tid; i < total; i += kTsBlock) {
-            const uint32_t u = i / E, e = i % E;
+            const uint32_t u = i >> shE, e = i & (E - 1);
             uint4 *dst = (binds & 1) ? A.t.b0[u] : A.t.b1[u];
-            fr_store(dst + 2 * ((solo ? 0u : (uint64_t)g * E) + e), fe_to_fr(ts_lds_load(tab_at((int)u, e))));
+            fr_store(dst + 2 * ((uint64_t)g * E + e), fe_to_fr(ts_lds_load(tab_at((int)u, e))));
         }
     }
 }
 
-// LDS a launch needs: finalize's scratch + the table area (entries per table: a block's slice, and everything that is left once block 0 is alone)
-static size_t ts_lds_entries(uint64_t first_pairs, int B) { return (size_t)std::max<uint64_t>(2 * first_pairs / (uint64_t)B, B > 1 ? (uint64_t)B : 0); }
+// LDS a launch needs: finalize's scratch + the table area (entries per table: a block's slice, and the sixteen a merge leaves its survivors)
+// + block 0's staging of the accumulators
+static size_t ts_lds_entries(uint64_t first_pairs, int B) { return (size_t)std::max<uint64_t>(2 * first_pairs / (uint64_t)B, B > 1 ? 16 : 0); }
 static size_t ts_fin_bytes(int K, int D) { return ((size_t)K * D * (D + 2) * 32 + 15) & ~(size_t)15; }
-// block 0's gather area: the B x n_combos x 8 collected words, their sums over the two halves of the blocks (64-bit), the two halves as elements
-static size_t ts_stage_bytes(int n_combos, int B) { return B > 1 ? (size_t)B * n_combos * 32 + 2 * (size_t)n_combos * 64 + 2 * (size_t)n_combos * 32 + 16 : 0; }
+static size_t ts_stage_bytes(int n_combos, int B) { return B > 1 ? 8 * (size_t)n_combos * 64 + 8 * (size_t)n_combos * 32 + 16 : 0; }
 constexpr size_t kTsLdsMax = 144 * 1024; // of the CU's 160 KB (one block per CU; its static LDS is ~3 KB)
 
-int tail_slices_blocks(uint64_t first_pairs, int n_tables, int K, int D, int n_combos) {
-    if (first_pairs == 0 || (first_pairs & (first_pairs - 1)) != 0 || first_pairs > kTailMaxPairs) return 0;
-    // as many blocks as leave every block two multi-block rounds (B <= first_pairs / 2), one block for short tails
+int tail_slices_blocks(uint64_t first_pairs, int n_tables, int K, int D, int n_combos, int max_multiplicands) {
+    if (first_pairs == 0 || (first_pairs & (first_pairs - 1)) != 0 || first_pairs > kTsMaxPairs) return 0;
+    if (first_pairs > kSmallRoundPairs) {
+        // Above the big / small round boundary the fused tree kernels stream the tables at memory speed; a resident block, one wavefront
+        // per SIMD, beats them only while its lanes have few dependent products in a row: passes over its pairs x multiplicands <= 12
+        // (config 2's and the GKR phases' shapes up to 2^16 pairs, two products of three up to 2^15; config 3's shape not at all).
+        int L = 64;
+        while (L * n_combos > kTsBlock) L >>= 1;
+        const uint64_t pairs_b = first_pairs / kTsMaxBlocks, passes = (pairs_b + L - 1) / L;
+        if (passes * (uint64_t)max_multiplicands > 12) return 0;
+    }
+    // as many blocks as leave every block two hand-over rounds (B <= first_pairs / 2), one block for short tails
     int B = kTsMaxBlocks;
     while (B > 1 && (uint64_t)B > first_pairs / 2) B >>= 1;
     if (first_pairs <= 32) B = 1;
-    for (;; B <<= 1) { // (more blocks = smaller slices, should the slices not fit)
-        const size_t bytes = ts_fin_bytes(K, D) + ts_lds_entries(first_pairs, B) * (size_t)n_tables * (kTsEnt * 4) + ts_stage_bytes(n_combos, B);
-        if (bytes <= kTsLdsMax) return B;
-        if (B >= kTsMaxBlocks || (uint64_t)(2 * B) > first_pairs / 2) return 0;
-    }
+    const size_t bytes = ts_fin_bytes(K, D) + ts_lds_entries(first_pairs, B) * (size_t)n_tables * (kTsEnt * 4) + ts_stage_bytes(n_combos, B);
+    return bytes <= kTsLdsMax ? B : 0; // (more blocks than kTsMaxBlocks would be needed: the caller runs this round as launches and asks again)
 }
 
 hipError_t launch_tail_slices(TailSlicesArgs args, const ComboMeta &meta, const FinMeta &fin, hipStream_t stream) {

@@ -769,10 +769,15 @@ bool tail_shape_ok(const sc_prover *p) {
     return p->use_tail && p->K > 0 && p->U <= (uint32_t)scd::kMaxSmallTables && p->has_meta && p->K <= (uint32_t)scd::kMetaProds &&
            (size_t)p->K * p->D * (p->D + 2) * 32 <= 48 * 1024;
 }
-bool tail_possible(sc_prover *p) {
+int tail_slices_blocks_for(sc_prover *p);
+// `slices`: the caller runs every remaining round (sc_ml_prove*, GKR): where the tables fit LDS as slices (k_tail_slices) the persistent
+// kernel takes over from the first latency-bound round (<= 2^14 pairs); k_tail_rounds -- the interactive protocol's resident kernel, and
+// shapes whose slices do not fit -- from 2048 pairs
+bool tail_possible(sc_prover *p, bool slices = false) {
     if (!tail_shape_ok(p) || p->exhausted || p->round >= p->nv || p->deferred_pending) return false;
     if (p->streamed && p->round < 2) return false;
-    if ((1ULL << (p->nv - (p->round + 1))) > std::min<uint64_t>(small_pairs_limit(), scd::kTailMaxPairs)) return false;
+    const uint64_t next_pairs = 1ULL << (p->nv - (p->round + 1));
+    if (next_pairs > scd::kTailMaxPairs && !(slices && next_pairs <= scd::kTsMaxPairs && tail_slices_blocks_for(p) > 0)) return false;
     if (!ensure_mailbox(p)) return false;
     if (!p->d_tail_sync) {
         // 16 sync words + one arrival flag per block | 2 challenge slots | K * D node sums
@@ -792,7 +797,7 @@ bool tail_possible(sc_prover *p) {
 int tail_slices_blocks_for(sc_prover *p) {
     static const bool env_on = !(std::getenv("SC_TAIL_SLICES") && std::atoi(std::getenv("SC_TAIL_SLICES")) == 0);
     if (!env_on || p->max_mult > (uint32_t)scd::kMaxFusedM || p->round >= p->nv) return 0;
-    const int B = scd::tail_slices_blocks(1ULL << (p->nv - (p->round + 1)), (int)p->U, (int)p->K, (int)p->D, p->n_combos);
+    const int B = scd::tail_slices_blocks(1ULL << (p->nv - (p->round + 1)), (int)p->U, (int)p->K, (int)p->D, p->n_combos, (int)p->max_mult);
     if (B <= 0) return 0;
     if (!p->d_tail_xw) { // tagged hand-over words, owned by the handle: zero once, tags only ever grow
         if (hipMalloc(reinterpret_cast<void **>(&p->d_tail_xw), scd::kTsXwWords * 8) != hipSuccess ||
@@ -803,6 +808,18 @@ int tail_slices_blocks_for(sc_prover *p) {
             return 0;
         }
         p->ts_tag = 1;
+        // the mailbox in device memory, where the host may store into it (SC_VRAM_MAILBOX=0: block 0 polls the host-mapped one and passes it on)
+        int large_bar = 0;
+        const char *env = std::getenv("SC_VRAM_MAILBOX");
+        if (!(env && std::atoi(env) == 0) && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, p->device) == hipSuccess && large_bar) {
+            void *m = nullptr;
+            if (hipExtMallocWithFlags(&m, 256, hipDeviceMallocFinegrained) == hipSuccess && hipMemsetAsync(m, 0, 256, p->stream) == hipSuccess &&
+                hipStreamSynchronize(p->stream) == hipSuccess)
+                p->d_vram_mail = static_cast<uint64_t *>(m);
+            else if (m)
+                (void)hipFree(m);
+        }
+        (void)hipGetLastError();
     }
     return B;
 }
@@ -847,12 +864,14 @@ int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null, uint3
     }
     HIP_TRY(scd::launch_zero_words(p->d_tail_sync, (uint32_t)((kTailSyncBytes + 64) / 4), p->stream));
     if (slices_B > 0) {
+        HIP_TRY(scd::launch_zero_words(reinterpret_cast<uint32_t *>(p->d_tail_xw), (uint32_t)(scd::kTsAccWords * 2), p->stream)); // the accumulator ring
         scd::TailSlicesArgs S;
         std::memset(&S, 0, sizeof(S));
         S.base = A;
         S.B = slices_B;
         S.xw = p->d_tail_xw;
         S.tag0 = p->ts_tag;
+        S.mail_vram = p->d_vram_mail;
         p->ts_tag += n_rounds;
         grid = slices_B;
         HIP_TRY(scd::launch_tail_slices(S, p->meta, fm, p->stream));
@@ -874,8 +893,17 @@ void tail_epilogue_tables(sc_prover *p, uint32_t nb) {
 }
 // the host writes challenge `vm` for the poll that waits for tag `sv`: 32-bit limb i, tagged -- every word validates itself, the
 // device's poll IS the fetch
-void tail_post_challenge(sc_prover *p, uint32_t sv, const sch::Fr &vm) {
+void tail_post_challenge(sc_prover *p, uint32_t sv, const sch::Fr &vm, bool vram = false) {
     uint64_t *slot = reinterpret_cast<uint64_t *>(p->h_mail) + 16 + 8 * (sv & 1u);
+    if (vram) {
+        // k_tail_slices with a mailbox IN DEVICE MEMORY (large-BAR systems: the host stores straight into VRAM): every block polls its own
+        // HBM -- 0.11 us a poll instead of a 1.1 us PCIe read, and nobody has to pass the challenge on (profiles/r5f_host_visible_vram_probe.txt).
+        // The mapping is write-combining: the eight self-validating words are pushed out by the fence.
+        volatile uint64_t *vslot = p->d_vram_mail + 8 * (sv & 1u);
+        for (int i = 0; i < 8; ++i) vslot[i] = ((uint64_t)(uint32_t)(vm.l[i >> 1] >> (32 * (i & 1))) << 32) | sv;
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        return;
+    }
     for (int i = 0; i < 8; ++i) {
         const uint32_t limb = (uint32_t)(vm.l[i >> 1] >> (32 * (i & 1)));
         __atomic_store_n(slot + i, ((uint64_t)limb << 32) | sv, __ATOMIC_RELEASE);
@@ -950,7 +978,7 @@ int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, const sch
             if (out_challenges) out_challenges[j] = vm;
         }
         if (j + 1 < n_rounds) { // (on the error path: a zero challenge, so that the kernel runs to its end and the stream drains)
-            tail_post_challenge(p, A.sig0 + j + 1, vm);
+            tail_post_challenge(p, A.sig0 + j + 1, vm, slices_B > 0 && p->d_vram_mail != nullptr);
             if (rc == SC_OK) p->randomness.push_back(vm);
         }
     }
@@ -1107,7 +1135,7 @@ int run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_
         uint64_t *pm = out_msgs + (size_t)i * D * 4;
         const auto t0 = clk::now();
         int rc;
-        if (!enqueued && tail_possible(p)) { // from here on every round is latency-bound: one persistent kernel runs them all
+        if (!enqueued && tail_possible(p, true)) { // from here on every round is latency-bound: one persistent kernel runs them all
             TailSlot slot(p);                // (unless another prover's tail kernel has the device: then pipelined launches, below)
             if (slot.held) return run_tail(p, rng, n_rounds - i, have ? &vm : nullptr, pm, out_challenges_or_null ? out_challenges_or_null + i : nullptr);
         }
@@ -1119,8 +1147,9 @@ int run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_
         uint32_t want_next = 0;
         bool next_enqueued = false;
         // round i+1 goes in now, behind the wait -- unless it is one the persistent tail kernel will take (it starts after round i's challenge)
-        const bool next_is_tail = tail_shape_ok(p) && p->round < p->nv && (1ULL << (p->nv - (p->round + 1))) <= scd::kTailMaxPairs &&
-                                  !(p->streamed && p->round < 2);
+        const bool next_is_tail = tail_shape_ok(p) && p->round < p->nv && !(p->streamed && p->round < 2) &&
+                                  ((1ULL << (p->nv - (p->round + 1))) <= scd::kTailMaxPairs ||
+                                   ((1ULL << (p->nv - (p->round + 1))) <= scd::kTsMaxPairs && tail_slices_blocks_for(p) > 0));
         if (i + 1 < n_rounds && !next_is_tail && can_defer_next(p)) {
             gate_lock(p->device); // held until the challenge is handed over: see DeviceGate
             rc = launch_round(p, nullptr, nullptr, true, true);

@@ -163,6 +163,7 @@ struct sc_prover {
     uint32_t *d_tail_sync = nullptr; // persistent tail kernel: 4 sync words + 2 challenge slots (device)
     uint64_t *d_tail_xw = nullptr;   // k_tail_slices: tagged hand-over words (kTsXwWords), and the next launch's first tag
     uint32_t ts_tag = 1;
+    uint64_t *d_vram_mail = nullptr; // ... and its mailbox in (host-visible, fine-grained) device memory: two slots of eight tagged words
     int tail_max_blocks = 0;        // blocks of it the device holds at once (its grid never exceeds that)
     uint64_t arena_bytes = 0;       // size of the bound-table arena (what a pooled handle keeps allocated)
     std::vector<uint8_t> pool_key;  // non-empty: created by sc_ml_prove; sc_prover_free offers it back to the pool (handle_pool_*)

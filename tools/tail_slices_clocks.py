@@ -20,12 +20,12 @@ for rep in range(4):
     st.prove()
 assert lib.sc_debug_tail_slices_clocks(clk) == 0
 c = np.array(list(clk), dtype=np.int64).reshape(64, 8)
-n_tail = min(nv, 12)
+n_tail = min(nv, 15)  # the slices tail takes over at 2^14 pairs
 print(f"nv={nv} shape={shapes}: k_tail_slices rounds (pairs from {1 << (n_tail - 1)} down), us per phase (block 0)")
 print("  j  pairs   challenge     bind    own sums   partials in   finalize+publish   total (start to published)   to next start")
 for j in range(n_tail):
     r = c[j]
     ph = [(r[i + 1] - r[i]) / 100.0 for i in range(5)]
     nxt = (c[j + 1][0] - r[5]) / 100.0 if j + 1 < n_tail else 0.0
-    extra = f"   [partials: words seen +{(r[6] - r[3]) / 100.0:.2f}, summed +{(r[7] - r[6]) / 100.0:.2f}, folded +{(r[4] - r[7]) / 100.0:.2f}]" if r[6] > r[3] else ""
+    extra = f"   [partials: accumulators complete +{(r[6] - r[3]) / 100.0:.2f}, folded +{(r[7] - r[6]) / 100.0:.2f}, added +{(r[4] - r[7]) / 100.0:.2f}]" if r[6] > r[3] else ""
     print(f" {j:2d} {1 << (n_tail - 1 - j):6d}   {ph[0]:8.2f} {ph[1]:8.2f} {ph[2]:10.2f} {ph[3]:12.2f} {ph[4]:16.2f} {(r[5] - r[0]) / 100.0:18.2f} {nxt:20.2f}{extra}")
