@@ -339,12 +339,12 @@ class ThreadWorld:
 
 
 # ---- the scaling model: written down BEFORE a multi-GPU node exists, so that the first N > 1 line tests it ----------------
-# One-GPU whole-proof times of the shard shapes, ms (profiles/r5c_single_gpu_shards.json: `python bench.py --config C --nv n` on one
+# One-GPU whole-proof times of the shard shapes, ms (profiles/r5n_single_gpu_shards.json: `python bench.py --config C --nv n` on one
 # MI355X, round 5).  A rank of an N-GPU proof holds nv - log2 N variables per table.
-T1_MS = {3: {24: 5.14, 23: 2.82, 22: 1.69, 21: 1.12, 20: 0.80}, 4: {28: 24.0, 27: 12.07, 26: 6.30, 25: 3.44}}
+T1_MS = {3: {24: 5.00, 23: 2.77, 22: 1.63, 21: 1.03, 20: 0.71}, 4: {28: 23.0, 27: 12.28, 26: 6.28, 25: 3.33}}
 EXCHANGE_ASSUMED_US = {"rccl": {2: 12.0, 4: 15.0, 8: 20.0, 16: 25.0}, "p2p": {2: 6.0, 4: 7.0, 8: 8.0, 16: 10.0}}  # ASSUMED (no two-GPU box seen yet)
 GATHER_ASSUMED_GBPS, GATHER_ASSUMED_LATENCY_US = 50.0, 30.0  # all-gather over xGMI: per-rank receive rate, plus bind / launch / tail-reset latency
-REPLICATED_ROUND_US = {14: 42.0, 13: 31.0, 12: 29.0, 11: 25.0}  # a latency-bound round by log2(pairs), measured on one GPU
+REPLICATED_ROUND_US = {14: 29.0, 13: 20.0, 12: 16.0, 11: 15.5}  # a latency-bound round by log2(pairs), measured on one GPU out of LDS
 
 
 def t1_ms(config, nv):
@@ -353,7 +353,7 @@ def t1_ms(config, nv):
     if nv in tab:
         return tab[nv], "measured"
     near = min(tab, key=lambda q: abs(q - nv))
-    fixed = 0.55 if config == 3 else 0.6  # the latency-bound rounds' share, ms: does not scale
+    fixed = 0.45 if config == 3 else 0.5  # the latency-bound rounds' share, ms: does not scale
     return fixed + (tab[near] - fixed) * 2.0 ** (nv - near), f"scaled from nv={near}"
 
 
@@ -373,7 +373,7 @@ def predict_ms(config, nv_total, world, U, comm_kind, exchange_us=None):
     gather_us = gather_bytes / (GATHER_ASSUMED_GBPS * 1e3) + GATHER_ASSUMED_LATENCY_US
     extra_us = sum(REPLICATED_ROUND_US.get(14 - j, 25.0) for j in range(k))
     out = {"model": "T1(nv per GPU) + sharded_rounds * exchange + gather + log2(N) extra replicated rounds",
-           "t1_ms": t1, "t1_source": t1_src + " (profiles/r5c_single_gpu_shards.json)", "sharded_rounds": nl, "replicated_rounds": m + k,
+           "t1_ms": t1, "t1_source": t1_src + " (profiles/r5n_single_gpu_shards.json)", "sharded_rounds": nl, "replicated_rounds": m + k,
            "exchange_assumed_us": x, "gather_bytes_received_per_rank": gather_bytes, "gather_assumed_us": gather_us,
            "gather_assumption": f"{GATHER_ASSUMED_GBPS:.0f} GB/s per rank + {GATHER_ASSUMED_LATENCY_US:.0f} us", "extra_replicated_rounds_us": extra_us,
            "predicted_ms_per_step": t1 + (nl * x + gather_us + extra_us) * 1e-3}
