@@ -122,6 +122,23 @@ __device__ __forceinline__ Fr fin_prefetch_weight(const ProdFn &prod_of, const u
     const uint64_t woff = prod_of(k).w_off + (((scaled & 1) && M <= kMaxFusedM) ? (uint64_t)D * (M + 1) : 0);
     return fr_load(Wm + 2 * (woff + (uint64_t)t * (M + 1) + sN));
 }
+// The message is in host-mapped memory (the stores above); raise its sequence flag behind it: every writing wave drains its stores (they
+// have reached the L2 / the fabric once acknowledged), the block meets, ONE lane raises the flag with system-scope release semantics -- its
+// write-back covers the whole L2.  Until round 5 every thread fenced to system scope first (a second write-back + invalidate per round:
+// ~0.5 us of every round of every proof, profiles/r5i_publish_fence_ab.txt; -DSC_PUBLISH_MODE=0 builds that form).  A RELAXED flag store
+// behind the drained stores is NOT enough: the message is cached in L2, the host saw flags before their data (parity failure, same file).
+#ifndef SC_PUBLISH_MODE
+#define SC_PUBLISH_MODE 1
+#endif
+__device__ __forceinline__ void fin_publish_flag(uint32_t *__restrict__ h_flag, const uint32_t seq) {
+#if SC_PUBLISH_MODE == 0
+    __threadfence_system();
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // phases 2 and 3: the node sums in scratch[k * D + t] -> the round message.  w_pre: this thread's fin_prefetch_weight, or null
 template <int BLOCK, typename ProdFn>
 __device__ __forceinline__ void finalize_message(const ProdFn &prod_of, const uint4 *__restrict__ Wm, const int K, const int D, uint4 *__restrict__ scratch,
@@ -149,11 +166,7 @@ __device__ __forceinline__ void finalize_message(const ProdFn &prod_of, const ui
             }
         }
         FIN_STAMP(4);
-        if (h_flag) {
-            __threadfence_system();
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        if (h_flag) fin_publish_flag(h_flag, seq);
         return;
     }
     // phase 2: message point t of product k = sum_s (c_k W_k)[t][s] * S_k[s].  One thread per (k, t, s) does the single
@@ -191,13 +204,7 @@ __device__ __forceinline__ void finalize_message(const ProdFn &prod_of, const ui
         }
     }
     FIN_STAMP(4);
-    if (h_flag) { // publish: every writer fences to system scope, then one lane raises the sequence flag
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    if (h_flag) fin_publish_flag(h_flag, seq);
 }
 template <int BLOCK, typename ProdFn>
 __device__ __forceinline__ void finalize_body(const ProdFn &prod_of, const uint4 *__restrict__ Wm, const int K, const int D, const int nblocks,
