@@ -289,8 +289,9 @@ int prover_build(const sc_poly_desc *d, sc_prover *p) {
 #ifdef SC_EXPERIMENTS
     if (const char *e = std::getenv("SC_F29")) p->use_f29 = p->use_f29 && std::atoi(e) != 0;
 #endif
+    // (every big-round kernel of the handle must read the format: the tree kernels do, for up to eight factors with kernels_wide.hip)
     for (uint32_t k = 0; k < d->n_products; ++k)
-        if (d->prod_offsets[k + 1] - d->prod_offsets[k] > 4) p->use_f29 = false;
+        if (d->prod_offsets[k + 1] - d->prod_offsets[k] > (wide_tree_enabled() ? 8u : 4u)) p->use_f29 = false;
     // with more tables than the small-round kernels take, the big-round kernels also run the short rounds, whose tables are
     // smaller than one 128-entry block of the chunk-planar layout
     if (d->n_tables > (uint32_t)scd::kMaxSmallTables) p->use_f29 = false;

@@ -223,6 +223,9 @@ hipError_t launch_prod_round_fe(int M, const ProdArgs &args, const FrHost &r32, 
 // multiplication tree per M; same partial layout and 2^(-5(M-1)) scaling as launch_prod_round_fe
 hipError_t launch_prod_tree(int M, const ProdArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid,
                             hipStream_t stream);
+// five to eight factors: the halves' product trees, extended to the product's nodes by integer combinations, one product per node
+// (kernels_wide.hip); launch_prod_tree forwards to it
+hipError_t launch_prod_tree_wide(int M, const ProdArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
 // all products of a round in one launch (see RoundArgs); d_partials is the base of the partial-sum array
 // one product per block row: grid x n_prod blocks, `grid` partial blocks per product.  (split = false, experiments build only: the
 // previous kernels, every block walking all products)

@@ -3,6 +3,7 @@
 // Its own translation unit so that it compiles beside kernels.hip (both are minutes of hipcc); see kernels.hip for the overview.
 #include "kernel_common.hpp"
 #include "finalize_device.hpp"
+#include "load_factor.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -169,70 +170,6 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
 // Slot modes: 0 read this round's table; 1 bind the previous table, store, use; 3 bind without storing (a repeated
 // factor, or a table that an earlier product of the same launch stores).
 // ------------------------------------------------------------------------------------------------
-// factor F of the product at pair b: its line's two end points (lo, hi), binding / storing as the slot's mode says
-// kR1: round 1 of a proof -- every factor is read from the caller's canonical table, nothing is bound (k_round1_tree)
-template <int F, bool kR1 = false, bool kChain = kChainDefault>
-struct LoadFactor {
-    static __device__ __forceinline__ void run(const Slot *S, const uint64_t b, const int32_t (&r)[kBindLds], Fe &lo_out, Fe &hi_out) {
-        const Slot &sl = S[F];
-        if constexpr (kR1) {
-            const uint4 *p = sl.src + 4 * b;
-            lo_out = fe_from_fr(fr_load(p));
-            hi_out = fe_from_fr(fr_load(p + 2));
-            return;
-        }
-        const uint32_t mode = sl.mode;
-        const int32_t *stop = sl.src_top; // non-null: the source table is in the internal F29 format
-        if (mode == 0) {
-            const uint4 *p = sl.src + 4 * b;
-            if (stop) {
-                const int2 t = *reinterpret_cast<const int2 *>(stop + 2 * b);
-                lo_out = fe_load_f29(sl.src, 2 * b, t.x);
-                hi_out = fe_load_f29(sl.src, 2 * b + 1, t.y);
-            } else {
-                lo_out = fe_from_fr(fr_load(p));
-                hi_out = fe_from_fr(fr_load(p + 2));
-            }
-        } else {
-            const uint4 *p = sl.src + 8 * b; // entries 4b..4b+3 of the previous table: 128 contiguous bytes
-            Fe e0, e1, e2, e3;
-            if (stop) {
-                const int4 t = *reinterpret_cast<const int4 *>(stop + 4 * b);
-                const uint4 *m = sl.src;
-                e0 = fe_load_f29(m, 4 * b, t.x); e1 = fe_load_f29(m, 4 * b + 1, t.y);
-                e2 = fe_load_f29(m, 4 * b + 2, t.z); e3 = fe_load_f29(m, 4 * b + 3, t.w);
-            } else {
-                e0 = fe_from_fr(fr_load(p)); e1 = fe_from_fr(fr_load(p + 2)); e2 = fe_from_fr(fr_load(p + 4)); e3 = fe_from_fr(fr_load(p + 6));
-            }
-            const Fe l0 = fe_add(e0, fe_mul_bind<kChain>(fe_sub(e1, e0), r));
-            asm volatile("" : "+v"(e3.l[8]) : "v"(l0.l[8])); // one product at a time: interleaving the two doubles the live constants
-            const Fe h0 = fe_add(e2, fe_mul_bind<kChain>(fe_sub(e3, e2), r));
-            if (sl.dst_top || (mode == 3 && stop)) {
-                // internal F29 tables: ONE parallel carry pass, no modular reduction.  The value moves by < p + 2^231 per bind
-                // (fe_mul_bind: r*(e1-e0) comes back in (-p - 2^230, 2^230)), i.e. stays within (rounds+1) p < 2^261 in magnitude for any
-                // nv <= 40, which every consumer tolerates: the multipliers' bounds depend on limb sizes only (limbs 0..7 are
-                // re-tightened here, the top limb stays below 2^28), and fe_to_fr reduces any |v| < 2^260 exactly.
-                lo_out = fe_carry_pass(l0);
-                hi_out = fe_carry_pass(h0);
-                if (mode == 1) {
-                    fe_store_f29(sl.dst, 2 * b, lo_out);
-                    fe_store_f29(sl.dst, 2 * b + 1, hi_out);
-                    *reinterpret_cast<int2 *>(sl.dst_top + 2 * b) = make_int2(lo_out.l[8], hi_out.l[8]);
-                }
-            } else { // tables stay canonical in the reference layout
-                const Fr lc = fe_to_fr(l0), hc = fe_to_fr(h0);
-                if (mode == 1) {
-                    uint4 *q = sl.dst + 4 * b;
-                    fr_store(q, lc);
-                    fr_store(q + 2, hc);
-                }
-                lo_out = fe_from_fr(lc);
-                hi_out = fe_from_fr(hc);
-            }
-        }
-    }
-};
-
 // one product's pass of a block over its share of the pairs: row = this block's M+1 partial sums of that product
 // kSkip1: node 1's sum is not computed -- the finalize step derives it from the previous round (S(0) + S(1) = that round's
 // polynomial at the challenge, product by product: ClaimArgs in kernels.h); binding rounds only
@@ -835,7 +772,7 @@ hipError_t launch_prod_tree(int M, const ProdArgs &args, const BindConst &r32, u
     case 2: return launch_prod_tree_t<2>(args, r32, n_pairs, d_partials, grid, stream);
     case 3: return launch_prod_tree_t<3>(args, r32, n_pairs, d_partials, grid, stream);
     case 4: return launch_prod_tree_t<4>(args, r32, n_pairs, d_partials, grid, stream);
-    default: return hipErrorInvalidValue; // 5..8 multiplicands run node by node in k_prod_round_fe
+    default: return launch_prod_tree_wide(M, args, r32, n_pairs, d_partials, grid, stream); // 5..8 factors: kernels_wide.hip
     }
 }
 

@@ -98,6 +98,11 @@ bool skip1_enabled() {
     return true;
 #endif
 }
+// products of five to eight multiplicands as a product tree with node extension (kernels_wide.hip); SC_WIDE_TREE=0: node by node (k_prod_round_fe)
+bool wide_tree_enabled() {
+    static const bool on = !(std::getenv("SC_WIDE_TREE") && std::atoi(std::getenv("SC_WIDE_TREE")) == 0);
+    return on;
+}
 bool fin_mb_enabled() {
 #ifdef SC_EXPERIMENTS
     static const bool on = !(std::getenv("SC_FIN_MB") && std::atoi(std::getenv("SC_FIN_MB")) == 0);
@@ -532,7 +537,7 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
         const Product &pr = p->prods[k];
         FrHost *partials = p->d_partials + pr.partial_off;
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[2 * k], p->stream));
-        if (pr.fused && p->kernel_variant == 3 && pr.M <= 4) {
+        if (pr.fused && p->kernel_variant == 3 && (pr.M <= 4 || wide_tree_enabled())) {
             // product tree: one argument slot per FACTOR.  The first factor touching a table this round binds and stores it;
             // a repeat inside the same product re-binds from the old table without storing (mode 3).
             ProdArgs a;

@@ -225,6 +225,7 @@ uint64_t sc_internal_cache_limit();
 constexpr int kResidentGone = -1; // internal: no resident kernel serves this round; take the ordinary path
 extern std::atomic<uint64_t> g_stat[8]; // process-wide counters a host can read (sc_library_stats)
 enum { kStatTailLaunches = 0, kStatTailSlotBusy = 1, kStatTailSlotReclaims = 2, kStatResidentStarts = 3, kStatResidentGone = 4, kStatProofRetries = 5, kStatTailSlices = 6 };
+bool wide_tree_enabled(); // products of five to eight multiplicands through kernels_wide.hip (SC_WIDE_TREE=0: node by node)
 int resident_quiesce(sc_prover *p); // the interactive protocol's resident kernel leaves before anything else touches the handle
 int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool publish_to_host, bool deferred = false);
 int await_round(sc_prover *p, uint64_t *out_evals, uint32_t want);

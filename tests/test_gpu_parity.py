@@ -1125,3 +1125,38 @@ def test_tail_with_tables_resident_in_lds(nv, nt, shapes):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, SC_TAIL_SLICES="0"))
     assert r.returncode == 0, r.stderr[-2000:]
     assert bytes.fromhex(r.stdout.strip().splitlines()[-1]) == want.tobytes()
+
+
+WIDE_SHAPES = [
+    (17, 5, [[0, 1, 2, 3, 4]]),
+    (17, 6, [[0, 1, 2, 3, 4, 5]]),
+    (17, 7, [[0, 1, 2, 3, 4, 5, 6]]),
+    (17, 8, [[0, 1, 2, 3, 4, 5, 6, 7]]),
+    (18, 13, [[0, 1, 2, 3, 4], [5, 6, 7, 8, 9, 10, 11, 12], [2, 2, 3, 9, 9, 1], [4, 4, 4, 4, 4, 4, 4], [12]]),  # repeated factors, shared tables, a mix of lengths
+]
+
+
+@pytest.mark.parametrize("nv,nt,shapes", WIDE_SHAPES)
+def test_wide_products_product_tree_with_node_extension(nv, nt, shapes):
+    """k_prod_tree_wide<5..8> (kernels_wide.hip): the big rounds of products of five to eight multiplicands -- the reference's own test
+    shapes (ml_sumcheck/test.rs:122-167) at a size that runs them -- round by round against the oracle with fixed challenges (every
+    message and the bound tables), then whole Fiat-Shamir proofs."""
+    tabs = [cref.synth_table(9090 + nv, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(9090 + nv, 1000, len(shapes))
+    chal = cref.synth_table(9090 + nv, 2000, nv)
+    d = H.desc_from(nv, shapes, tabs, coefs)
+    poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device="cuda:0")
+    op = cref.Prover(d, threads=cref.max_threads())
+    st = sc.IPForMLSumcheck.prover_init(poly)
+    v = None
+    for i in range(nv):
+        want = op.prove_round(None if v is None else v.randomness)
+        got = sc.IPForMLSumcheck.prove_round(st, v).evaluations
+        assert np.array_equal(got, want), f"round {i + 1}"
+        v = sc.VerifierMsg(chal[i])
+    _, otabs, _ = op.state()
+    for u, t in enumerate(st.flattened_ml_extensions):
+        assert np.array_equal(t.evaluations, otabs[u])
+    proof = sc.MLSumcheck.prove(poly)
+    want, _ = cref.ml_prove(d, threads=cref.max_threads())
+    assert np.array_equal(np.stack([m.evaluations for m in proof]), want)

@@ -130,13 +130,23 @@ def wide(nv, ms, reps=7):
     med = r["gpu_ms_median"] * 1e-3
     D = max(ms) + 1
     r["reference_muls_per_s"] = ((1 << nv) - 1) * sum(m * D for m in ms) / med + nt * ((1 << nv) - 2) / med
-    exe = sum(((m - 1) * (m + 1) + m * 97 / 153) for m in ms) * ((1 << nv) - 1)
+    tree = {1: 0, 2: 3, 3: 7, 4: 11}
+
+    def products(m):  # Montgomery-product equivalents per pair: the product tree (<= 4), the halves' trees + one product per node + the
+        if m <= 4:    # extensions at half a product each (5..8, kernels_wide.hip), node by node beyond that
+            return tree[m]
+        if m <= 8:
+            mb = m - 4
+            ext = (m + 1 - 5) + (m + 1 - (mb + 1 if mb >= 2 else 3))
+            return 11 + tree[mb] + (m + 1) + 0.5 * ext
+        return (m - 1) * (m + 1)
+    exe = sum((products(m) + m * 97 / 153) for m in ms) * ((1 << nv) - 1)
     r["executed_products_per_s"] = exe / med
     r["frac_of_fe_mul_ceiling"] = exe / med / 160e9
     r["frac_of_hbm_peak"] = r["algorithmic_GBps"] / 8000.0
     r["multiplicands"] = ms
     r["kernels"] = ("k_round1_tree_split / k_round_tree_split (every product <= 4)" if max(ms) <= 4 else
-                    "k_prod_tree (<= 4) + k_prod_round_fe<M> (5..8), one launch per product" if max(ms) <= 8 else "k_fix per table + k_sum_generic per product")
+                    "k_prod_tree (<= 4) + k_prod_tree_wide<M> (5..8: halves' trees, node extension), one launch per product" if max(ms) <= 8 else "k_fix per table + k_sum_generic per product")
     return r
 
 
