@@ -182,7 +182,9 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
                 if (tid < 8 && (tid & 1) == 0) r_sh[tid >> 1] = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
             }
             __syncthreads();
-            if (stop_sh) return;
+            // no challenge (the interactive protocol's verifier took longer than the kernel's patience, or the host asked it to leave):
+            // every block is between two rounds, its slice as round j - 1 left it -- written back below, so the handle carries on from there
+            if (stop_sh) break;
         }
         TS_STAMP(j, 1); // challenge in hand
         FeU r32;

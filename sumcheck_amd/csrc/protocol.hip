@@ -828,7 +828,7 @@ int tail_slices_blocks_for(sc_prover *p) {
     }
     return B;
 }
-int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null, uint32_t max_spins, scd::TailArgs &A, int &grid, int slices_B = 0) {
+int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null, uint32_t max_spins, scd::TailArgs &A, int &grid, int slices_B = 0, bool host_mailbox_only = false) {
     const uint32_t D = p->D;
     std::memset(&A, 0, sizeof(A));
     for (uint32_t u = 0; u < p->U; ++u) {
@@ -876,7 +876,7 @@ int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null, uint3
         S.B = slices_B;
         S.xw = p->d_tail_xw;
         S.tag0 = p->ts_tag;
-        S.mail_vram = p->d_vram_mail;
+        S.mail_vram = host_mailbox_only ? nullptr : p->d_vram_mail;
         p->ts_tag += n_rounds;
         grid = slices_B;
         HIP_TRY(scd::launch_tail_slices(S, p->meta, fm, p->stream));
@@ -1083,14 +1083,21 @@ int resident_start(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals)
         std::memcpy(&r, r_or_null, 32);
         if (sch::geq_p(r)) return kResidentGone;
     }
-    if (!resident_enabled(p) || !tail_possible(p)) return kResidentGone;
+    if (!resident_enabled(p) || !tail_possible(p, true)) return kResidentGone;
     if (!tail_slot_acquire(p, true)) return kResidentGone;
     const uint32_t n_rounds = p->nv - p->round;
     scd::TailArgs A;
     int grid = 1;
     {
         DeviceGate gate_(p->device);
-        int rc = hipSetDevice(p->device) == hipSuccess ? tail_launch(p, n_rounds, r_or_null ? &r : nullptr, p->resident_spins, A, grid) : SC_ERR_HIP;
+        // (k_tail_slices where the shape allows, its block 0 the only one that listens to the host: one poller decides for all whether a
+        // challenge came in time, and on the way out every block writes its slice back)
+        int rc = SC_ERR_HIP, slices_B = 0;
+        if (hipSetDevice(p->device) == hipSuccess) {
+            slices_B = tail_slices_blocks_for(p);
+            rc = tail_launch(p, n_rounds, r_or_null ? &r : nullptr, p->resident_spins, A, grid, slices_B, true);
+        }
+        if (rc == SC_OK && slices_B > 0) g_stat[kStatTailSlices].fetch_add(1, std::memory_order_relaxed);
         if (rc) {
             resident_release_slot(p);
             return rc;

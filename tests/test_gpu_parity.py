@@ -774,7 +774,8 @@ def test_cache_limit_and_polling_switch_do_not_change_results():
     assert np.array_equal(proof, want)
 
 
-@pytest.mark.parametrize("nv,nt,shapes", [(14, 10, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]), (9, 3, [[0, 1, 2], [2, 2]]), (13, 2, [[0, 1]])])
+@pytest.mark.parametrize("nv,nt,shapes", [(14, 10, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]]), (9, 3, [[0, 1, 2], [2, 2]]), (13, 2, [[0, 1]]),
+                                          (16, 3, [[0, 1, 2]])])
 def test_interactive_rounds_resident_kernel(nv, nt, shapes):
     """IPForMLSumcheck::prove_round round by round (prover.rs:74-77): the late rounds are served by ONE kernel that stays on the GPU
     between calls.  Every message against the oracle's, through every way the dialogue can go: back to back; a verifier that takes
@@ -819,6 +820,7 @@ def test_interactive_rounds_resident_kernel(nv, nt, shapes):
     dialogue(st)                                                     # back to back
     st.reset(); dialogue(st, pause_at={nv - 3, nv - 1})              # the kernel's patience expires twice
     st.reset(); dialogue(st, export_at={max(nv - 5, 1), nv - 2})     # quiesced for a state export, twice
+    st.reset(); dialogue(st, export_at={1, 2, 3}, pause_at={2, 5})   # ... and early: before its first bind, while its blocks still hold slices
     st.reset(); dialogue(st, misuse_at={nv - 4, nv - 2})             # errors in between do not disturb it
     st.reset(); dialogue(st, stop_after=nv - 2)                      # abandoned two rounds before the end ...
     st.reset(); dialogue(st)                                         # ... reset while it waits, and proved again
