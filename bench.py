@@ -519,8 +519,8 @@ def run_rank(args, W, result):
     except Exception:
         pass
     # The dominant kernel's duration is measured live, with HIP events on the launch stream inside the timed region -- on a sample of
-    # the steps only: the events are instrumentation (four records and a collect per big round, ~1 % of a proof), and the other steps
-    # run as a caller's proofs do.  At least 8 steps are sampled whatever --steps is.  The sampled steps are part of the K timed steps.
+    # the steps only: the events are instrumentation (four records and a collect per big round, ~3 % of a proof: gpu_leg.ms_per_event_sampled_proof), and the other steps
+    # run as a caller's proofs do.  At least 4 steps are sampled whatever --steps is (kernel durations repeat to a percent).  The sampled steps are part of the K timed steps.
     K = len(shapes)
     ms_acc, ln_acc, rounds_ms_acc, timed_steps = [0.0] * K, [0] * K, 0.0, 0
     rms_acc, rln_acc = [0.0] * nv_local, [0] * nv_local
@@ -529,7 +529,7 @@ def run_rank(args, W, result):
     rms = (C.c_double * nv_local)()
     rln = (C.c_uint64 * nv_local)()
     rounds_ms = C.c_double()
-    every = max(1, min(args.time_every, args.steps // 8))
+    every = max(1, min(args.time_every, args.steps // 4))  # (a sampled proof costs ~0.15 ms more than the others: 36 event records and 9 collects)
     barrier()
     t0 = time.perf_counter()
     step_s = []  # a step returns when its last round's message is on the host, so per-step wall times cost nothing extra
@@ -697,6 +697,9 @@ def run_rank(args, W, result):
                        # the scaling model's figure for THIS line, written down before any N > 1 hardware run: the line tests it
                        "predicted_ms_per_step": pred["predicted_ms_per_step"], "exchange_assumed_us": pred.get("exchange_assumed_us"), "prediction": pred,
                        "gpu_leg": {"warmup_proofs": args.warmup, "timed_proofs": args.steps, "proofs_after_the_clock": cooldown + (1 if all_have else 0),
+                                   "event_sampled_proofs": timed_steps,
+                                   "ms_per_event_sampled_proof": float(np.mean([t for i, t in enumerate(step_s) if i % every == 0])) * 1e3,
+                                   "ms_per_other_proof": float(np.mean([t for i, t in enumerate(step_s) if i % every != 0] or [float("nan")])) * 1e3,
                                    "gpu_leg_seconds_target": args.min_gpu_seconds,
                                    "note": "the proofs after the clock keep the GPU busy for --min-gpu-seconds in all (an outside activity sampler with a 5 s period sees the run); they are not timed"}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -864,7 +867,7 @@ def main():
     ap.add_argument("--nv", type=int, default=0, help="override the GLOBAL number of variables (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-every", type=int, default=8,
-                    help="HIP events around the dominant kernel's launches (the roofline's live duration) on every N-th timed step (at least 8 steps are sampled); 1 = every step")
+                    help="HIP events around the dominant kernel's launches (the roofline's live duration) on every N-th timed step (at least 4 steps are sampled); 1 = every step")
     ap.add_argument("--launcher", default="auto", choices=("auto", "processes", "threads"),
                     help="--gpus N > 1 without an external launcher: one process per GPU via torch.distributed.run (RCCL), or N thread ranks of this "
                          "process over the library's peer-to-peer communicator; auto = processes, threads if that cannot start")

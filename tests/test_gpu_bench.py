@@ -43,7 +43,7 @@ def test_bench_line_single_gpu():
     assert "phases_s" in cb and cb["phases_s"]["sums"] > 0 and cb["whole_prove"]["value"] > 0
     assert "traffic_source" in rf
     # measurement hygiene: per-round roofline from the live events, the multiplier figures, the sampling floor
-    assert d["roofline"]["event_timed_steps"] == 2 and rf["event_timed_every"] == 1  # at least 8 sampled steps, or all of them
+    assert d["roofline"]["event_timed_steps"] == 2 and rf["event_timed_every"] == 1  # at least 4 sampled steps, or all of them
     pr = rf["per_round"]
     assert [x["round"] for x in pr] == [1, 2, 3, 4] and all(x["ms"] > 0 and 0 < x["frac"] < 1 for x in pr)  # nv=19: four big rounds (pairs > 2^14)
     assert abs(sum(x["ms"] * x["samples"] for x in pr) / rf["launches"] - rf["avg_launch_ms"]) < 1e-6
