@@ -286,6 +286,47 @@ def test_bench_refuses_a_multi_gpu_run_it_cannot_place():
     assert r.returncode == 2 and "power of two" in r.stderr
 
 
+def test_bench_scaling_model_is_consistent_with_the_sharded_schedule():
+    """bench.py's predicted_ms_per_step: T1(nv per GPU) + one exchange per sharded round + the gather + log2(N) extra
+    replicated rounds.  The round split it assumes is the library's (protocol.hip: sharded_tail_m, gather at 2^14 pairs): sharded and
+    replicated rounds add up to nv, N = 1 is the measured one-GPU time itself, the prediction grows with the exchange time, and the
+    variant with this run's measured exchange uses exactly that figure."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json\n"
+        f"sys.path.insert(0, {root!r}); sys.argv = ['bench.py']\n"
+        "import bench\n"
+        "out = {}\n"
+        "for cfg, nv, U in ((3, 24, 10), (4, 28, 3)):\n"
+        "    for w in (1, 2, 4, 8):\n"
+        "        for kind in ('rccl', 'p2p'):\n"
+        "            out[f'{cfg}/{w}/{kind}'] = bench.predict_ms(cfg, nv, w, U, kind, exchange_us=7.5)\n"
+        "print(json.dumps(out))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    for cfg, nv in ((3, 24), (4, 28)):
+        one = out[f"{cfg}/1/rccl"]
+        assert one["predicted_ms_per_step"] == one["t1_ms"] > 0
+        for w in (2, 4, 8):
+            k = w.bit_length() - 1
+            for kind in ("rccl", "p2p"):
+                d = out[f"{cfg}/{w}/{kind}"]
+                assert d["sharded_rounds"] + d["replicated_rounds"] == nv
+                assert d["replicated_rounds"] == 15                      # the gather leaves 2^14 pairs to the first replicated round
+                assert d["sharded_rounds"] == nv - k - (15 - k)
+                extra = (d["sharded_rounds"] * d["exchange_assumed_us"] + d["gather_assumed_us"] + d["extra_replicated_rounds_us"]) * 1e-3
+                assert abs(d["predicted_ms_per_step"] - (d["t1_ms"] + extra)) < 1e-9
+                with_meas = d["predicted_ms_per_step_with_measured_exchange"]
+                assert abs((d["predicted_ms_per_step"] - with_meas) - d["sharded_rounds"] * (d["exchange_assumed_us"] - 7.5) * 1e-3) < 1e-9
+            assert out[f"{cfg}/{w}/p2p"]["exchange_assumed_us"] <= out[f"{cfg}/{w}/rccl"]["exchange_assumed_us"]
+        # strong scaling of a fixed job: the shard's own time falls with N
+        assert out[f"{cfg}/8/rccl"]["t1_ms"] < out[f"{cfg}/4/rccl"]["t1_ms"] < out[f"{cfg}/2/rccl"]["t1_ms"] < out[f"{cfg}/1/rccl"]["t1_ms"]
+
+
 def test_bench_hands_its_ranks_the_cpus_it_started_with():
     """bench.py pins the CPU leg's OpenMP threads (OMP_PROC_BIND); the first OpenMP runtime a process loads then binds its main thread
     to one core, and child processes inherit that mask.  `--gpus N` starts its ranks through a launcher that loads such a runtime
