@@ -1,5 +1,6 @@
-"""One-off differential fuzz on a GPU box: random product lists (shared tables, repeated factors, 1..6 multiplicands, up to 14
-products) at sizes that run big rounds (merged and per-product launches), whole proofs against the C oracle.
+"""One-off differential fuzz on a GPU box: random product lists (shared tables, repeated factors, 1..8 multiplicands, up to 14
+products) at sizes that run big rounds (merged and per-product launches), whole proofs against the C oracle; a third of the cases as
+the interactive dialogue (prove_round per round, the oracle transcript's challenges, random pauses beyond the resident kernel's patience).
 python tools/fuzz.py [cases] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,16 +17,27 @@ for c in range(cases):
     nv = int(rng.choice([1, 2, 5, 9, 13, 16, 17, 18, 19], p=[.04, .04, .05, .07, .1, .1, .2, .25, .15]))
     nt = int(rng.integers(1, 9))
     K = int(rng.integers(1, 15)) if rng.random() < 0.15 else int(rng.integers(1, 6))
-    maxm = 6 if rng.random() < 0.2 else 4
+    maxm = 8 if rng.random() < 0.3 else 4
     shapes = [[int(x) for x in rng.integers(0, nt, size=int(rng.integers(1, maxm + 1)))] for _ in range(K)]
     tabs = [cref.synth_table(1000 + c, s, 1 << nv) for s in range(nt)]
     coefs = cref.synth_table(1000 + c, 1000, K)
     want, wrand = cref.ml_prove(H.desc_from(nv, shapes, tabs, coefs), threads=cref.max_threads())
     dev = "cuda:0" if rng.random() < 0.5 else None
     poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device=dev)
-    proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly)
-    got = np.stack([m.evaluations for m in proof])
-    ok = np.array_equal(got, want) and np.array_equal(state.randomness, wrand)
+    if rng.random() < 0.33:
+        st = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+        got = []
+        for i in range(nv):
+            if rng.random() < 0.1:
+                time.sleep(0.003)
+            got.append(sc.IPForMLSumcheck.prove_round(st, None if i == 0 else sc.VerifierMsg(wrand[i - 1])).evaluations)
+        got = np.stack(got)
+        ok = np.array_equal(got, want) and np.array_equal(st.randomness, wrand[: nv - 1])
+        st.close()
+    else:
+        proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly)
+        got = np.stack([m.evaluations for m in proof])
+        ok = np.array_equal(got, want) and np.array_equal(state.randomness, wrand)
     if not ok:
         bad += 1
         print("MISMATCH", c, nv, nt, shapes, dev)
