@@ -489,7 +489,9 @@ def run_rank(args, W, result):
             else:
                 exchange = {"exchange_us": W.max_float(us_mean.value), "exchange_us_min": us_min.value, "bytes": 64 * D, "iters": iters,
                             "publication": ("direct: ncclAllReduce delivers tagged lanes into the host-mapped page, no publish kernel" if direct_pub else
-                                            "the exchange kernel publishes" if comm_kind == "p2p" else "publish kernel behind the all-reduce"),
+                                            "the exchange kernel publishes" if comm_kind == "p2p" else
+                                            "the host adds the ranks' lanes (the caller's all-reduce function)" if comm_kind == "host-transport" else
+                                            "publish kernel behind the all-reduce"),
                             "what": f"{iters} back-to-back all-reduces of one round message on the {comm_kind} communicator, host-waited like a round's (max over ranks of the mean)"}
         dcomm = sharded.DistComm() if isinstance(W, ProcWorld) else None
         tail_factory = sharded.TailEngines(shapes, coefs, dev)  # only the Python loop uses it

@@ -14,3 +14,4 @@ timeout 900 python tools/bench_configs.py --config4 > gpurun_out/${TAG}_bench_co
 SC_GKR_TRACE=1 timeout 200 python tools/bench_configs.py --only-gkr 2>&1 | grep "^\[gkr\]" | tail -7 > gpurun_out/${TAG}_gkr_stage_trace.txt
 timeout 300 python tools/interactive_time.py 8 12 16 20 2>&1 | grep nv= > gpurun_out/${TAG}_interactive.txt
 timeout 200 python tools/oneshot_time.py 2>&1 | grep "nv=" > gpurun_out/${TAG}_oneshot_times.txt
+bash tools/emulate_ranks.sh $TAG > gpurun_out/${TAG}_multi_rank_launches_one_gpu.txt 2>&1; tail -5 gpurun_out/${TAG}_multi_rank_launches_one_gpu.txt | cut -c1-200
