@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsumcheck_hip.so")
 OUT_EXP = os.path.join(HERE, "libsumcheck_hip_exp.so")
-SOURCES = ["kernels_big.hip", "kernels.hip", "kernels_tail.hip", "kernels_wide.hip", "gkr.hip", "abi.hip", "protocol.hip", "comm.hip"]
-HEADERS = ["fr_device.hpp", "fe_device.hpp", "kernel_common.hpp", "finalize_device.hpp", "fe_mad_chain.inc", "fr_mac.inc", "fr_mul_gen.inc", "kernels.h", "host_fr.hpp", "transcript.hpp", "prover_internal.hpp", "load_factor.hpp", os.path.join("..", "..", "include", "sumcheck_hip.h")]
+SOURCES = ["kernels_big.hip", "kernels.hip", "kernels_tail.hip", "kernels_wide.hip", "kernels_wide16.hip", "gkr.hip", "abi.hip", "protocol.hip", "comm.hip"]
+HEADERS = ["fr_device.hpp", "fe_device.hpp", "kernel_common.hpp", "finalize_device.hpp", "fe_mad_chain.inc", "fr_mac.inc", "fr_mul_gen.inc", "kernels.h", "host_fr.hpp", "transcript.hpp", "prover_internal.hpp", "load_factor.hpp", "wide_tree.hpp", os.path.join("..", "..", "include", "sumcheck_hip.h")]
 EXTRA = os.environ.get("SC_BUILD_EXTRA", "").split()  # e.g. SC_BUILD_EXTRA="-DSC_TAIL_CLOCKS" for a one-off local build
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 

@@ -56,6 +56,11 @@ struct ProdArgs {
     Slot slot[kMaxFusedM];
     int n_slots;
 };
+constexpr int kMaxWideM = 12; // products of kMaxFusedM + 1 .. kMaxWideM multiplicands: big rounds as a tree of trees (kernels_wide16.hip)
+struct WideArgs16 {
+    Slot slot[kMaxWideM]; // one slot per FACTOR, every one in mode 0 (the tables are bound before the launch)
+    int n_slots;
+};
 
 // One launch for a whole round (every product has <= 4 multiplicands): each block walks all the round's products over its
 // own share of the pairs, so a round is one kernel with no launch gaps and the multiplier-bound products (M = 3, 4) of
@@ -226,6 +231,8 @@ hipError_t launch_prod_tree(int M, const ProdArgs &args, const BindConst &rc, ui
 // five to eight factors: the halves' product trees, extended to the product's nodes by integer combinations, one product per node
 // (kernels_wide.hip); launch_prod_tree forwards to it
 hipError_t launch_prod_tree_wide(int M, const ProdArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
+// nine to kMaxWideM multiplicands over bound tables; comp = 2^(5(M-1)) in Montgomery form: the sums leave in k_sum_generic's form
+hipError_t launch_prod_tree_wide16(int M, const WideArgs16 &args, const FrHost &comp, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
 // all products of a round in one launch (see RoundArgs); d_partials is the base of the partial-sum array
 // one product per block row: grid x n_prod blocks, `grid` partial blocks per product.  (split = false, experiments build only: the
 // previous kernels, every block walking all products)

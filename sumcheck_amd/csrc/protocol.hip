@@ -436,8 +436,25 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
         scaled = 1; // products of up to kMaxFusedM multiplicands are summed in carry-free arithmetic (2^261 radix) there too
         bind = false;
     }
-    if (bind && p->any_generic) { // generic products read bound tables: bind everything up front
-        for (uint32_t u = 0; u < p->U; ++u) HIP_TRY(bind_table(u));
+    if (bind && p->any_generic) { // products beyond kMaxFusedM read bound tables: bind everything up front, 32 tables a launch
+        for (uint32_t u0 = 0; u0 < p->U; u0 += (uint32_t)scd::kMaxSmallTables) {
+            const uint32_t cnt = std::min<uint32_t>(p->U - u0, (uint32_t)scd::kMaxSmallTables);
+            TablePtrs tp;
+            std::memset(&tp, 0, sizeof(tp));
+            for (uint32_t j = 0; j < cnt; ++j) {
+                Table &t = p->tabs[u0 + j];
+                tp.src[j] = t.cur;
+                tp.src_top[j] = t.cur_top;
+                tp.dst[j] = t.buf[t.next];
+            }
+            HIP_TRY(scd::launch_fix_multi(tp, (int)cnt, rdev, nullptr, 2 * n_pairs, p->stream));
+            for (uint32_t j = 0; j < cnt; ++j) {
+                Table &t = p->tabs[u0 + j];
+                t.cur = t.buf[t.next];
+                t.cur_top = nullptr;
+                t.next ^= 1;
+            }
+        }
         bind = false;
     }
     std::vector<uint8_t> bound(p->U, 0);
@@ -610,6 +627,23 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
                 HIP_TRY(scd::launch_prod_round_fe((int)pr.M, a, r32, n_pairs, partials, grid, p->stream));
                 scaled = 1;
             }
+        } else if (pr.M <= (uint32_t)scd::kMaxWideM && wide_tree_enabled() && p->kernel_variant == 3) {
+            // nine to twelve multiplicands: a tree of the trees (kernels_wide16.hip) over the tables the bind pass above left; one slot per
+            // FACTOR, and the sums come back in k_sum_generic's form (the kernel takes its 2^(-5(M-1)) off again)
+            scd::WideArgs16 a;
+            std::memset(&a, 0, sizeof(a));
+            const std::vector<uint32_t> &factors = p->prod_indices[k];
+            a.n_slots = (int)factors.size();
+            for (size_t f = 0; f < factors.size(); ++f) {
+                const Table &t = p->tabs[factors[f]];
+                a.slot[f].mode = 0;
+                a.slot[f].exp = 1;
+                a.slot[f].src = t.cur;
+                a.slot[f].src_top = t.cur_top;
+            }
+            sch::Fr comp = sch::kOne; // 2^(5(M-1)) in Montgomery form
+            for (uint32_t dbl = 0; dbl < 5 * (pr.M - 1); ++dbl) comp = sch::add(comp, comp);
+            HIP_TRY(scd::launch_prod_tree_wide16((int)pr.M, a, to_dev(comp), n_pairs, partials, grid, p->stream));
         } else {
             if (!ptrs_uploaded) {
                 for (uint32_t u = 0; u < p->U; ++u) p->h_cur_tables[u] = p->tabs[u].cur;

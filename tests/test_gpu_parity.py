@@ -1138,11 +1138,20 @@ WIDE_SHAPES = [
 ]
 
 
+WIDE_SHAPES += [
+    (16, 9, [[0, 1, 2, 3, 4, 5, 6, 7, 8]]),
+    (16, 10, [[0, 1, 2, 3, 4, 5, 6, 7, 8, 9]]),
+    (16, 11, [[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]]),
+    (16, 12, [[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]]),
+    (17, 7, [[0, 1, 2, 3, 4, 5, 6, 0, 1, 2, 3, 4], [6, 6, 6, 6, 6, 6, 6, 6, 6, 5], [1, 2, 3], [0, 1, 2, 3, 4, 5, 6, 6, 5, 4, 3, 2, 1]]),  # 12 / 10 with repeats, a short one, and 13 (node by node)
+]
+
+
 @pytest.mark.parametrize("nv,nt,shapes", WIDE_SHAPES)
 def test_wide_products_product_tree_with_node_extension(nv, nt, shapes):
-    """k_prod_tree_wide<5..8> (kernels_wide.hip): the big rounds of products of five to eight multiplicands -- the reference's own test
-    shapes (ml_sumcheck/test.rs:122-167) at a size that runs them -- round by round against the oracle with fixed challenges (every
-    message and the bound tables), then whole Fiat-Shamir proofs."""
+    """k_prod_tree_wide<5..8> (kernels_wide.hip) and k_prod_tree_wide16<9..12> (kernels_wide16.hip): the big rounds of products of five
+    to twelve multiplicands -- the reference's own test shapes (ml_sumcheck/test.rs:122-167: 4..12 per product) at a size that runs
+    them -- round by round against the oracle with fixed challenges (every message and the bound tables), then whole Fiat-Shamir proofs."""
     tabs = [cref.synth_table(9090 + nv, s, 1 << nv) for s in range(nt)]
     coefs = cref.synth_table(9090 + nv, 1000, len(shapes))
     chal = cref.synth_table(9090 + nv, 2000, nv)

@@ -139,6 +139,10 @@ def wide(nv, ms, reps=7):
             mb = m - 4
             ext = (m + 1 - 5) + (m + 1 - (mb + 1 if mb >= 2 else 3))
             return 11 + tree[mb] + (m + 1) + 0.5 * ext
+        if m <= 12:   # 9..12 (kernels_wide16.hip): the first eight as above at nine nodes, the rest's tree, one product per node, extensions
+            mb = m - 8
+            ext = (m + 1 - 9) + (m + 1 - (mb + 1 if mb >= 2 else 3))
+            return (11 + 11 + 9 + 0.5 * 8) + tree[mb] + (m + 1) + 0.5 * ext
         return (m - 1) * (m + 1)
     exe = sum((products(m) + m * 97 / 153) for m in ms) * ((1 << nv) - 1)
     r["executed_products_per_s"] = exe / med
@@ -146,16 +150,22 @@ def wide(nv, ms, reps=7):
     r["frac_of_hbm_peak"] = r["algorithmic_GBps"] / 8000.0
     r["multiplicands"] = ms
     r["kernels"] = ("k_round1_tree_split / k_round_tree_split (every product <= 4)" if max(ms) <= 4 else
-                    "k_prod_tree (<= 4) + k_prod_tree_wide<M> (5..8: halves' trees, node extension), one launch per product" if max(ms) <= 8 else "k_fix per table + k_sum_generic per product")
+                    "k_prod_tree (<= 4) + k_prod_tree_wide<M> (5..8: halves' trees, node extension), one launch per product" if max(ms) <= 8 else
+                    "k_fix_multi (bind pass) + k_prod_tree_wide16<M> (9..12: a tree of the trees)" if max(ms) <= 12 and os.environ.get("SC_WIDE_TREE") != "0" else "k_fix per table + k_sum_generic per product")
     return r
 
 
+if "--only-wide12" in sys.argv:  # for rocprofv3 runs of one product of twelve alone
+    print(json.dumps({"one_product_of_12": wide(20, [12])}, indent=1))
+    sys.exit(0)
 if "--wide" in sys.argv:  # the M >= 5 paths, timed
     nvw = 20
     print(json.dumps({"test_normal_shape_nv20_5_products_of_4_to_8": wide(nvw, [4, 5, 6, 7, 8]),
                       "five_products_of_5": wide(nvw, [5, 5, 5, 5, 5]),
                       "five_products_of_8": wide(nvw, [8, 8, 8, 8, 8]),
                       "one_product_of_12": wide(nvw, [12]),
+                      "one_product_of_9": wide(nvw, [9]),
+                      "test_normal_shape_nv20_5_products_of_4_to_12": wide(nvw, [4, 6, 8, 10, 12]),
                       "one_product_of_6": wide(nvw, [6]),
                       "for_scale_five_products_of_4": wide(nvw, [4, 4, 4, 4, 4])}, indent=1))
     sys.exit(0)

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p tools/ab/obj_$name
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function"
-for s in kernels_big kernels kernels_tail kernels_wide gkr abi protocol comm; do
+for s in kernels_big kernels kernels_tail kernels_wide kernels_wide16 gkr abi protocol comm; do
   case " $REUSE " in
     *" $s "*) cp sumcheck_amd/build/$s.hip.o tools/ab/obj_$name/$s.o;;
     *) /opt/rocm/bin/hipcc $FLAGS "$@" -c sumcheck_amd/csrc/$s.hip -o tools/ab/obj_$name/$s.o &;;
