@@ -119,7 +119,7 @@ __device__ __forceinline__ Fr fin_prefetch_weight(const ProdFn &prod_of, const u
     if (t >= D || k >= K) return fr_zero();
     const int M = (int)prod_of(k).M;
     if (sN > M) return fr_zero();
-    const uint64_t woff = prod_of(k).w_off + (((scaled & 1) && M <= kMaxFusedM) ? (uint64_t)D * (M + 1) : 0);
+    const uint64_t woff = prod_of(k).w_off + (((scaled & 1) && (M <= kMaxFusedM || (scaled & 4))) ? (uint64_t)D * (M + 1) : 0);
     return fr_load(Wm + 2 * (woff + (uint64_t)t * (M + 1) + sN));
 }
 // The message is in host-mapped memory (the stores above); raise its sequence flag behind it: every writing wave drains its stores (they
@@ -144,7 +144,8 @@ template <int BLOCK, typename ProdFn>
 __device__ __forceinline__ void finalize_message(const ProdFn &prod_of, const uint4 *__restrict__ Wm, const int K, const int D, uint4 *__restrict__ scratch,
                                                  uint4 *__restrict__ out, uint64_t *__restrict__ out_wide, uint4 *__restrict__ h_out,
                                                  uint32_t *__restrict__ h_flag, const uint32_t seq, const int scaled, const Fr *w_pre = nullptr) {
-    // `scaled`: bit 0 = the partials carry 2^(-5(M-1)) (second copy of the weights); bit 1 = tag the widened lanes with this round's
+    // `scaled`: bit 0 = the partials carry 2^(-5(M-1)) (second copy of the weights) -- those of products of up to kMaxFusedM multiplicands, with
+    // bit 2 those of longer products too (k_tail_slices<kMaxWideM>); bit 1 = tag the widened lanes with this round's
     // sequence number (kernels.h: wide_tag_of) -- an RCCL all-reduce then lands them in host-mapped memory as self-validating words
     const uint64_t wtag = (scaled & 2) ? ((uint64_t)wide_tag_of(seq) << kWideTagShift) : 0;
     if (fin_compact<BLOCK>(K, D)) {
@@ -176,7 +177,7 @@ __device__ __forceinline__ void finalize_message(const ProdFn &prod_of, const ui
         const int M = (int)prod_of(k).M;
         if (sN > M) continue;
         // partials from the 2^261-radix kernels carry 2^(-5(M-1)); the second copy of the matrix undoes it
-        const uint64_t woff = prod_of(k).w_off + (((scaled & 1) && M <= kMaxFusedM) ? (uint64_t)D * (M + 1) : 0);
+        const uint64_t woff = prod_of(k).w_off + (((scaled & 1) && (M <= kMaxFusedM || (scaled & 4))) ? (uint64_t)D * (M + 1) : 0);
         const uint4 *Wk = Wm + 2 * (woff + (uint64_t)t * (M + 1));
         fr_store(scratch + 2 * ((2 * K) * D + idx), fr_mul(fr_load(Wk + 2 * sN), fr_load(scratch + 2 * (k * D + sN))));
     }

@@ -207,7 +207,7 @@ struct TailSlicesArgs {
 };
 // blocks for a tail that starts with `first_pairs` pairs, or 0 when the slices do not fit LDS (the caller then takes k_tail_rounds)
 int tail_slices_blocks(uint64_t first_pairs, int n_tables, int K, int D, int n_combos, int max_multiplicands);
-hipError_t launch_tail_slices(TailSlicesArgs args, const ComboMeta &meta, const FinMeta &fin, hipStream_t stream);
+hipError_t launch_tail_slices(TailSlicesArgs args, const ComboMeta &meta, const FinMeta &fin, int max_multiplicands, hipStream_t stream);
 int tail_max_resident_blocks(int device); // co-resident blocks of the tail kernel (0: unknown -> the tail kernel is not used)
 uint32_t wait_spins_default(); // bound of the device-side polls for a challenge (SC_WAIT_SPINS overrides it: tests)
 hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream); // (a plain kernel: hipMemsetAsync may take runtime paths that wait on other streams)

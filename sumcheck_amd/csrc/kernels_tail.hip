@@ -68,6 +68,9 @@ __device__ uint64_t g_ts_clk[64 * 8];
 #define TS_STAMP(j, i)
 #endif
 
+// kSlots: distinct tables a product may have (kMaxFusedM; kMaxWideM for lists with products of nine to twelve multiplicands, whose sums then
+// carry the 2^(-5(M-1)) of the carry-free products too: finalize_message's `scaled` bit 2)
+template <int kSlots>
 __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S, const ComboMeta meta, const FinMeta fin) {
     const TailArgs &A = S.base;
     extern __shared__ uint4 dyn_lds[];
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
     // this lane's combination, once: its node and, per slot, the table's LDS base (in entries) and the multiplicity
     const Combo my_c = combo_sh[combo_live ? my_combo : 0];
     const int32_t my_nv = node_value((int)my_c.t);
-    uint32_t my_base[kMaxFusedM], my_exp[kMaxFusedM];
+    uint32_t my_base[kSlots], my_exp[kSlots];
 #pragma unroll
-    for (int sl = 0; sl < kMaxFusedM; ++sl) {
+    for (int sl = 0; sl < kSlots; ++sl) {
         const bool in = (uint32_t)sl < my_c.n_slots;
         my_base[sl] = in ? slot_table_sh[my_c.slot_off + sl] * cap : 0u;
         my_exp[sl] = in ? slot_exp_sh[my_c.slot_off + sl] : 0u;
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
                 Fe prod = fe_zero();
                 bool first = true;
 #pragma unroll
-                for (int sl = 0; sl < kMaxFusedM; ++sl) {
+                for (int sl = 0; sl < kSlots; ++sl) {
                     if (my_exp[sl] == 0) break; // (slots are dense: the first empty one ends the list)
                     const int32_t *lo_p = tabs + (my_base[sl] + 2 * pr) * (uint32_t)kTsEnt;
                     Fe val;
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(kTsBlock) void k_tail_slices(const TailSlicesArgs S
                 return;
             }
             TS_STAMP(j, 4); // node sums complete (every block's in)
-            finalize_message<kTsBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, 1, (const Fr *)nullptr);
+            finalize_message<kTsBlock>(prod_of, A.Wm, A.K, A.D, fin_lds, (uint4 *)nullptr, (uint64_t *)nullptr, A.h_out, A.h_flag, A.seq0 + (uint32_t)j, kSlots > kMaxFusedM ? 5 : 1, (const Fr *)nullptr);
             TS_STAMP(j, 5); // message published
             if (B > 1) { // the accumulators of round j + 2 (last used in round j - 2: complete and read long ago)
                 const uint32_t z0 = (uint32_t)((j + 2) & 3) * (8 * kMetaCombos * 8);
@@ -461,7 +464,19 @@ int tail_slices_blocks(uint64_t first_pairs, int n_tables, int K, int D, int n_c
     return bytes <= kTsLdsMax ? B : 0; // (more blocks than kTsMaxBlocks would be needed: the caller runs this round as launches and asks again)
 }
 
-hipError_t launch_tail_slices(TailSlicesArgs args, const ComboMeta &meta, const FinMeta &fin, hipStream_t stream) {
+template <int kSlots>
+static hipError_t launch_tail_slices_t(const TailSlicesArgs &args, const ComboMeta &meta, const FinMeta &fin, size_t lds, hipStream_t stream) {
+    static bool attr_set = false; // (more dynamic LDS than the default 64 KB limit of a launch)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail_slices<kSlots>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTsLdsMax);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_tail_slices<kSlots>, dim3(args.B), dim3(kTsBlock), lds, stream, args, meta, fin);
+    return hipGetLastError();
+}
+
+hipError_t launch_tail_slices(TailSlicesArgs args, const ComboMeta &meta, const FinMeta &fin, int max_multiplicands, hipStream_t stream) {
     const int B = args.B;
     if (B < 1 || B > kTsMaxBlocks || (B & (B - 1)) != 0) return hipErrorInvalidValue;
     args.fin_bytes = (uint32_t)ts_fin_bytes(args.base.K, args.base.D);
@@ -469,14 +484,8 @@ hipError_t launch_tail_slices(TailSlicesArgs args, const ComboMeta &meta, const 
     args.stage_off = (uint32_t)((args.fin_bytes + (size_t)args.lds_entries * args.base.n_tables * (kTsEnt * 4) + 15) & ~(size_t)15);
     const size_t lds = args.stage_off + ts_stage_bytes(args.base.n_combos, B);
     if (lds > kTsLdsMax) return hipErrorInvalidValue;
-    static bool attr_set = false; // (more dynamic LDS than the default 64 KB limit of a launch)
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail_slices), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTsLdsMax);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_tail_slices, dim3(B), dim3(kTsBlock), lds, stream, args, meta, fin);
-    return hipGetLastError();
+    if (max_multiplicands > kMaxWideM) return hipErrorInvalidValue;
+    return max_multiplicands > kMaxFusedM ? launch_tail_slices_t<kMaxWideM>(args, meta, fin, lds, stream) : launch_tail_slices_t<kMaxFusedM>(args, meta, fin, lds, stream);
 }
 
 } // namespace scd

@@ -835,7 +835,7 @@ bool tail_possible(sc_prover *p, bool slices = false) {
 // arithmetic, the slices within a CU's LDS.  SC_TAIL_SLICES=0: k_tail_rounds everywhere (A/B runs, tests of the older path).
 int tail_slices_blocks_for(sc_prover *p) {
     static const bool env_on = !(std::getenv("SC_TAIL_SLICES") && std::atoi(std::getenv("SC_TAIL_SLICES")) == 0);
-    if (!env_on || p->max_mult > (uint32_t)scd::kMaxFusedM || p->round >= p->nv) return 0;
+    if (!env_on || p->max_mult > (uint32_t)(wide_tree_enabled() ? scd::kMaxWideM : scd::kMaxFusedM) || p->round >= p->nv) return 0;
     const int B = scd::tail_slices_blocks(1ULL << (p->nv - (p->round + 1)), (int)p->U, (int)p->K, (int)p->D, p->n_combos, (int)p->max_mult);
     if (B <= 0) return 0;
     if (!p->d_tail_xw) { // tagged hand-over words, owned by the handle: zero once, tags only ever grow
@@ -913,7 +913,7 @@ int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null, uint3
         S.mail_vram = host_mailbox_only ? nullptr : p->d_vram_mail;
         p->ts_tag += n_rounds;
         grid = slices_B;
-        HIP_TRY(scd::launch_tail_slices(S, p->meta, fm, p->stream));
+        HIP_TRY(scd::launch_tail_slices(S, p->meta, fm, (int)p->max_mult, p->stream));
         return SC_OK;
     }
     HIP_TRY(scd::launch_tail_rounds(A, p->meta, fm, grid, p->stream));
