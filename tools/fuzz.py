@@ -1,4 +1,4 @@
-"""One-off differential fuzz on a GPU box: random product lists (shared tables, repeated factors, 1..8 multiplicands, up to 14
+"""One-off differential fuzz on a GPU box: random product lists (shared tables, repeated factors, 1..12 multiplicands, up to 14
 products) at sizes that run big rounds (merged and per-product launches), whole proofs against the C oracle; a third of the cases as
 the interactive dialogue (prove_round per round, the oracle transcript's challenges, random pauses beyond the resident kernel's patience).
 python tools/fuzz.py [cases] [seed]"""
@@ -17,7 +17,8 @@ for c in range(cases):
     nv = int(rng.choice([1, 2, 5, 9, 13, 16, 17, 18, 19], p=[.04, .04, .05, .07, .1, .1, .2, .25, .15]))
     nt = int(rng.integers(1, 9))
     K = int(rng.integers(1, 15)) if rng.random() < 0.15 else int(rng.integers(1, 6))
-    maxm = 8 if rng.random() < 0.3 else 4
+    um = rng.random()
+    maxm = 12 if um < 0.2 else 8 if um < 0.4 else 4
     shapes = [[int(x) for x in rng.integers(0, nt, size=int(rng.integers(1, maxm + 1)))] for _ in range(K)]
     tabs = [cref.synth_table(1000 + c, s, 1 << nv) for s in range(nt)]
     coefs = cref.synth_table(1000 + c, 1000, K)
