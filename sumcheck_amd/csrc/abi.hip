@@ -449,7 +449,7 @@ int prover_build(const sc_poly_desc *d, sc_prover *p) {
         HIP_TRY(hipMemcpyAsync(p->d_slot_table, slot_table.data(), slot_table.size() * 4, hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipMemcpyAsync(p->d_slot_exp, slot_exp.data(), slot_exp.size() * 4, hipMemcpyHostToDevice, p->stream));
     }
-    if (p->any_generic) { // (two sets: a streamed handle's chunks alternate between them, as between the staging slots)
+    if (p->any_generic || p->U > (uint32_t)scd::kMaxSmallTables) { // (two sets: a streamed handle's chunks alternate between them, as between the staging slots)
         HIP_TRY(hipMalloc(&p->d_cur_tables, 2 * p->U * sizeof(void *)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_cur_tables), 2 * p->U * sizeof(void *), hipHostMallocDefault));
     }

@@ -260,6 +260,9 @@ hipError_t launch_fix_multi(const TablePtrs &tp, int n_tables, const FrHost &r, 
 hipError_t launch_sum_combos(const TablePtrs &tp, const Combo *d_combos, int n_combos, const uint32_t *d_slot_table,
                              const uint32_t *d_slot_exp, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
 // the same with the metadata passed by value (n_combos <= kMetaCombos, slot entries <= kMetaSlots)
+// the same for more tables than TablePtrs holds: pointers from a device array (table index -> this round's evaluations)
+hipError_t launch_sum_combos_ptrs(const uint4 *const *d_cur_tables, const Combo *d_combos, int n_combos, const uint32_t *d_slot_table,
+                                  const uint32_t *d_slot_exp, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream);
 hipError_t launch_sum_combos_meta(const TablePtrs &tp, const ComboMeta &meta, int n_combos, uint64_t n_pairs, FrHost *d_partials, int grid,
                                   hipStream_t stream);
 // combine per-block partials of all products into the round polynomial (D evaluations)

@@ -318,6 +318,13 @@ __global__ __launch_bounds__(kBlock) void k_sum_combos(const TablePtrs tp, const
     __shared__ uint32_t sm[kBlock / 64][8];
     sum_combo_body([&](uint32_t u) { return tp.src[u]; }, combos[blockIdx.y], slot_table, slot_exp, n_pairs, partials, sm, blockIdx.x, gridDim.x);
 }
+// more tables than TablePtrs holds (kMaxSmallTables): the table pointers come from device memory
+__global__ __launch_bounds__(kBlock) void k_sum_combos_ptrs(const uint4 *const *__restrict__ cur_tables, const Combo *__restrict__ combos,
+                                                            const uint32_t *__restrict__ slot_table, const uint32_t *__restrict__ slot_exp,
+                                                            const uint64_t n_pairs, uint4 *__restrict__ partials) {
+    __shared__ uint32_t sm[kBlock / 64][8];
+    sum_combo_body([&](uint32_t u) { return cur_tables[u]; }, combos[blockIdx.y], slot_table, slot_exp, n_pairs, partials, sm, blockIdx.x, gridDim.x);
+}
 __global__ __launch_bounds__(kBlock) void k_sum_combos_meta(const TablePtrs tp, const ComboMeta meta, const uint64_t n_pairs,
                                                             uint4 *__restrict__ partials) {
     __shared__ uint32_t sm[kBlock / 64][8];
@@ -921,6 +928,13 @@ hipError_t launch_fix_multi(const TablePtrs &tp, int n_tables, const FrHost &r, 
 hipError_t launch_sum_combos(const TablePtrs &tp, const Combo *d_combos, int n_combos, const uint32_t *d_slot_table,
                              const uint32_t *d_slot_exp, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(k_sum_combos, dim3(grid, n_combos), dim3(kBlock), 0, stream, tp, d_combos, d_slot_table, d_slot_exp, n_pairs,
+                       (uint4 *)d_partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_combos_ptrs(const uint4 *const *d_cur_tables, const Combo *d_combos, int n_combos, const uint32_t *d_slot_table,
+                                  const uint32_t *d_slot_exp, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sum_combos_ptrs, dim3(grid, n_combos), dim3(kBlock), 0, stream, d_cur_tables, d_combos, d_slot_table, d_slot_exp, n_pairs,
                        (uint4 *)d_partials);
     return hipGetLastError();
 }

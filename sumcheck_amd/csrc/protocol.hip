@@ -370,7 +370,7 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
     const FrHost r32 = to_dev(r32v);
     int scaled = 0;
     const uint64_t small_pairs = small_pairs_limit();
-    const bool small_round = n_pairs <= small_pairs && p->U <= (uint32_t)scd::kMaxSmallTables && p->K > 0;
+    const bool small_round = n_pairs <= small_pairs && p->K > 0 && (p->U <= (uint32_t)scd::kMaxSmallTables || p->d_cur_tables != nullptr);
 #ifdef SC_EXPERIMENTS
     const bool tiled = !small_round && !p->any_generic && p->kernel_variant == 2;
 #else
@@ -408,31 +408,41 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
 
     const bool small = small_round;
     if (small) {
-        // latency-bound round: one launch binds every table, one launch sums every (product, point) combination
+        // latency-bound round: one launch binds every table (32 tables a launch), one launch sums every (product, point) combination
         TablePtrs tp;
-        std::memset(&tp, 0, sizeof(tp));
         if (bind) {
-            for (uint32_t u = 0; u < p->U; ++u) {
-                Table &t = p->tabs[u];
-                tp.src[u] = t.cur;
-                tp.src_top[u] = t.cur_top;
-                tp.dst[u] = t.buf[t.next];
-            }
-            {
-                SlowCallProbe pr("launch k_fix_multi");
-                HIP_TRY(scd::launch_fix_multi(tp, (int)p->U, rdev, r_mail, 2 * n_pairs, p->stream));
-            }
-            for (uint32_t u = 0; u < p->U; ++u) {
-                Table &t = p->tabs[u];
-                t.cur = t.buf[t.next];
-                t.cur_top = nullptr; // the latency-bound path keeps tables canonical in the reference layout
-                t.next ^= 1;
+            for (uint32_t u0 = 0; u0 < p->U; u0 += (uint32_t)scd::kMaxSmallTables) {
+                const uint32_t cnt = std::min<uint32_t>(p->U - u0, (uint32_t)scd::kMaxSmallTables);
+                std::memset(&tp, 0, sizeof(tp));
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    Table &t = p->tabs[u0 + j];
+                    tp.src[j] = t.cur;
+                    tp.src_top[j] = t.cur_top;
+                    tp.dst[j] = t.buf[t.next];
+                }
+                {
+                    SlowCallProbe pr("launch k_fix_multi");
+                    HIP_TRY(scd::launch_fix_multi(tp, (int)cnt, rdev, r_mail, 2 * n_pairs, p->stream));
+                }
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    Table &t = p->tabs[u0 + j];
+                    t.cur = t.buf[t.next];
+                    t.cur_top = nullptr; // the latency-bound path keeps tables canonical in the reference layout
+                    t.next ^= 1;
+                }
             }
         }
-        for (uint32_t u = 0; u < p->U; ++u) tp.src[u] = p->tabs[u].cur;
         SlowCallProbe pr_sum("launch k_sum_combos");
-        if (p->has_meta) HIP_TRY(scd::launch_sum_combos_meta(tp, p->meta, p->n_combos, n_pairs, p->d_partials, grid, p->stream));
-        else HIP_TRY(scd::launch_sum_combos(tp, p->d_combos, p->n_combos, p->d_slot_table, p->d_slot_exp, n_pairs, p->d_partials, grid, p->stream));
+        if (p->U <= (uint32_t)scd::kMaxSmallTables) {
+            std::memset(&tp, 0, sizeof(tp));
+            for (uint32_t u = 0; u < p->U; ++u) tp.src[u] = p->tabs[u].cur;
+            if (p->has_meta) HIP_TRY(scd::launch_sum_combos_meta(tp, p->meta, p->n_combos, n_pairs, p->d_partials, grid, p->stream));
+            else HIP_TRY(scd::launch_sum_combos(tp, p->d_combos, p->n_combos, p->d_slot_table, p->d_slot_exp, n_pairs, p->d_partials, grid, p->stream));
+        } else { // more tables than a launch's arguments hold: the pointers go through device memory (never a pipelined round: can_defer_next)
+            for (uint32_t u = 0; u < p->U; ++u) p->h_cur_tables[u] = p->tabs[u].cur;
+            HIP_TRY(hipMemcpyAsync(p->d_cur_tables, p->h_cur_tables, p->U * sizeof(void *), hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(scd::launch_sum_combos_ptrs(p->d_cur_tables, p->d_combos, p->n_combos, p->d_slot_table, p->d_slot_exp, n_pairs, p->d_partials, grid, p->stream));
+        }
         scaled = 1; // products of up to kMaxFusedM multiplicands are summed in carry-free arithmetic (2^261 radix) there too
         bind = false;
     }

@@ -1144,6 +1144,9 @@ WIDE_SHAPES += [
     (16, 11, [[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]]),
     (16, 12, [[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]]),
     (17, 7, [[0, 1, 2, 3, 4, 5, 6, 0, 1, 2, 3, 4], [6, 6, 6, 6, 6, 6, 6, 6, 6, 5], [1, 2, 3], [0, 1, 2, 3, 4, 5, 6, 6, 5, 4, 3, 2, 1]]),  # 12 / 10 with repeats, a short one, and 13 (node by node)
+    # more tables than one launch's arguments hold (40 > kMaxSmallTables): test_normal_polynomial's shape, every product over its own tables
+    (16, 40, [list(range(0, 4)), list(range(4, 10)), list(range(10, 18)), list(range(18, 28)), list(range(28, 40))]),
+    (15, 40, [list(range(8 * k, 8 * k + 8)) for k in range(5)]),
 ]
 
 
