@@ -15,7 +15,7 @@ bad = 0
 t0 = time.time()
 for c in range(cases):
     nv = int(rng.choice([1, 2, 5, 9, 13, 16, 17, 18, 19], p=[.04, .04, .05, .07, .1, .1, .2, .25, .15]))
-    nt = int(rng.integers(1, 9))
+    nt = int(rng.integers(33, 49)) if rng.random() < 0.1 else int(rng.integers(1, 9))  # (a tenth of the lists over more tables than a launch's arguments hold)
     K = int(rng.integers(1, 15)) if rng.random() < 0.15 else int(rng.integers(1, 6))
     um = rng.random()
     maxm = 12 if um < 0.2 else 8 if um < 0.4 else 4
