@@ -673,6 +673,29 @@ def run_rank(args, W, result):
                                   f"{shas['bench_py_sha']}, git {tj.get('git_head')}), profiles/hbm_traffic_latest.json (not measured in this run)")
         except Exception as e:
             traffic_source = f"not reported: {type(e).__name__}: {e}"
+        # The dominant kernel's duration as `rocprofv3 --kernel-trace --stats` of this command sees it (tools/profile.sh: 25 proofs, the
+        # tracked profiles/*_rocprofv3_kernel_stats.csv): sum of TotalDurationNs over the big-round kernels / sum of Calls.  It is what
+        # `roofline.frac` is computed from when that summary was taken on THIS tree (content hashes), so that the figure can be recomputed
+        # from profiles/ alone; the HIP-event figure of this very run stays beside it (frac_hip_events) and tests/test_host.py holds the two
+        # within 3 % of each other on the committed set.
+        rocprof, rocprof_source = None, None
+        try:
+            kj = json.load(open(os.path.join(ROOT, "profiles", "rocprof_kernel_latest.json")))
+            if not (kname in kj.get("kernel", "") and nv_local == 24 and args.config == 3 and world == 1 and merged):
+                rocprof_source = "not used: the off-line rocprofv3 summary covers config 3 at nv=24 on one GPU only"
+            elif kj.get("csrc_sha") != shas["csrc_sha"] or kj.get("bench_py_sha") != shas["bench_py_sha"]:
+                rocprof_source = (f"dropped: profiles/rocprof_kernel_latest.json was taken on another tree (csrc_sha {kj.get('csrc_sha')} / bench_py_sha "
+                                  f"{kj.get('bench_py_sha')}, git {kj.get('git_head')}); running csrc_sha {shas['csrc_sha']} / bench_py_sha {shas['bench_py_sha']}")
+            else:
+                rocprof = kj
+                rocprof_source = (f"rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5` on this tree (csrc_sha {shas['csrc_sha']}, bench_py_sha "
+                                  f"{shas['bench_py_sha']}, git {kj.get('git_head')}): {kj.get('stats_csv')}, {kj['launches']} launches, via profiles/rocprof_kernel_latest.json")
+        except Exception as e:
+            rocprof_source = f"not used: {type(e).__name__}: {e}"
+        achieved_events, avg_ms_events = achieved, avg_ms
+        if rocprof:
+            avg_ms = rocprof["avg_ns"] * 1e-6
+            achieved = (big_bytes / big_rounds) / (avg_ms * 1e-3) / 1e9
         # rounds_ms: event span of the rounds launched with events = the big rounds (late rounds are pipelined and record none)
         big_all_bytes = sum(round_bytes(nv_local, U, i) for i in big_idx)
         big_rounds_gbps = big_all_bytes * ev_steps / (rounds_ms_total * 1e-3) / 1e9 if rounds_ms_total > 0 else 0.0
@@ -708,6 +731,15 @@ def run_rank(args, W, result):
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": (f"k_round1_tree_split (round 1) + k_round_tree_split (rounds 2..{big_rounds}): all products, one launch per big round, one product per block row" if merged
                                     else f"{kname} (product {dom}, big rounds)"),
                          "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         # where `achieved` / `frac` come from: the tracked rocprofv3 summary of this command on this tree when there is one
+                         # (recomputable from profiles/), else this run's HIP events; the HIP-event figures of THIS run are always here
+                         "frac_source": ("rocprofv3: " + rocprof_source) if rocprof else ("HIP events of this run (" + str(rocprof_source) + ")"),
+                         "achieved_hip_events": achieved_events, "frac_hip_events": achieved_events / HBM_PEAK_GBPS, "avg_launch_ms_hip_events": avg_ms_events,
+                         "rocprof": ({"avg_launch_ms": rocprof["avg_ns"] * 1e-6, "launches": rocprof["launches"], "proofs": rocprof.get("proofs"),
+                                      "avg_launch_ms_warm_proofs_only": rocprof["warm"]["avg_ns"] * 1e-6,
+                                      "frac_warm_proofs_only": (big_bytes / big_rounds) / (rocprof["warm"]["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS,
+                                      "per_proof_kernel_total_ms": rocprof.get("per_proof_kernel_total_ms"),
+                                      "stats_csv": rocprof.get("stats_csv")} if rocprof else None),
                          "per_round": per_round,
                          "big_rounds_GBps_incl_finalize": big_rounds_gbps, "big_rounds_ms_per_step": rounds_ms_total / ev_steps,
                          "event_timed_steps": timed_steps, "event_timed_every": every,

@@ -349,3 +349,38 @@ def test_bench_hands_its_ranks_the_cpus_it_started_with():
     assert r.returncode == 0, r.stderr[-2000:]
     started_with, rank_sees = [int(x) for x in r.stdout.split()[-2:]]
     assert started_with == len(os.sched_getaffinity(0)) and rank_sees == started_with, r.stdout
+
+
+def test_roofline_fraction_follows_from_the_tracked_rocprof_summary():
+    """VERDICT r5 item 1.  The committed measurement set -- profiles/bench_line_latest.json (the bench line), profiles/rocprof_kernel_latest.json
+    (what bench.py read `roofline.frac` from) and the rocprofv3 stats CSV that summary names -- must tell one story: the line's frac is the
+    SURVEY 8(d) formula over the CSV (algorithmic bytes of the big rounds / launches / average duration / 8 TB/s), the HIP-event figure of the
+    bench run agrees with it within 3 %, and the kernels of a profiled proof fit inside the step time the driver's clock measured."""
+    import csv
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.load(open(os.path.join(root, "profiles", "bench_line_latest.json")))
+    kj = json.load(open(os.path.join(root, "profiles", "rocprof_kernel_latest.json")))
+    rf = line["roofline"]
+    assert rf["frac_source"].startswith("rocprofv3"), rf["frac_source"]  # the line was produced WITH the summary of its own tree
+    assert kj["csrc_sha"] in rf["frac_source"] and kj["bench_py_sha"] in rf["frac_source"]
+    # the summary is the CSV: every launch of the big-round kernels of the profiled command
+    rows = [r for r in csv.DictReader(open(os.path.join(root, kj["stats_csv"]))) if "k_round1_tree" in r["Name"] or "k_round_tree" in r["Name"]]
+    calls, total = sum(int(r["Calls"]) for r in rows), sum(int(r["TotalDurationNs"]) for r in rows)
+    assert calls == kj["launches"] and total == kj["total_ns"] and calls >= 9 * 20
+    nv, U = line["config"]["nv"], line["config"]["tables"]
+    big = [x["round"] for x in rf["per_round"]]
+    bytes_per_launch = sum(bench.round_bytes(nv, U, i) for i in big) / len(big)
+    frac = bytes_per_launch / (total / calls * 1e-9) / 1e9 / bench.HBM_PEAK_GBPS
+    assert abs(frac - rf["frac"]) < 1e-9 * frac and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert abs(rf["frac"] / rf["frac_hip_events"] - 1) < 0.03, (rf["frac"], rf["frac_hip_events"])
+    assert abs(rf["rocprof"]["frac_warm_proofs_only"] / rf["frac_hip_events"] - 1) < 0.03
+    # every kernel of a warm profiled proof (big rounds, finalize launches, the LDS-resident rounds) fits inside the measured step
+    assert kj["per_proof_kernel_total_ms"] <= line["ms_per_step"] * 1.03, (kj["per_proof_kernel_total_ms"], line["ms_per_step"])
+    assert kj["warm"]["proofs"] >= 20 and kj["per_proof_big_round_kernels_ms"] < kj["per_proof_kernel_total_ms"]
+    # the whole proof against the roof is the step time and nothing else
+    assert abs(rf["whole_proof_frac"] - bench.algorithmic_bytes(nv, U) / (line["ms_per_step"] * 1e-3) / 1e9 / bench.HBM_PEAK_GBPS) < 1e-9
+    # the traffic figure comes from counter passes on the same tree as the line
+    tj = json.load(open(os.path.join(root, "profiles", "hbm_traffic_latest.json")))
+    assert tj["csrc_sha"] == kj["csrc_sha"] and tj["bench_py_sha"] == kj["bench_py_sha"] and rf["traffic"] == tj["traffic_bytes_per_launch"]

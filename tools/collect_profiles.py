@@ -8,6 +8,7 @@ import collections
 import csv
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -39,10 +40,14 @@ try:
     cmdline = open(os.path.join(base, "command.txt")).read().strip()
 except OSError:
     cmdline = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+try:
+    pmc_cmdline = open(os.path.join(base, "command_pmc.txt")).read().strip()
+except OSError:
+    pmc_cmdline = cmdline
 summary = {
     **bench.source_shas(), "git_head": os.environ.get("GIT_HEAD"),
-    "bench_command": cmdline,
-    "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --output-format csv) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+    "bench_command": pmc_cmdline,
+    "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --output-format csv) -- " + pmc_cmdline,
     "corrections": "FETCH_SIZE x2 (MI355X_MICROARCH.md: gfx950 counts 64 B per 128-B request for 16 B/lane coalesced reads; checked on the "
                    "round-1 launch of k_prod_tree<4>: 4 x 2^24 x 32 B = 2097152 KB read, counter 1048848 KB); WRITE_SIZE x1 (calibrated on k_synth: 10 x 2^24 x 32 B "
                    "written, counter 5242880 KB)",
@@ -56,3 +61,41 @@ json.dump(summary, open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), inde
 if not no_latest:
     shutil.copy(os.path.join(out, f"{tag}_hbm_traffic.json"), os.path.join(out, "hbm_traffic_latest.json"))
 print(key, "launches", f["calls"], "traffic/launch", summary["traffic_bytes_per_launch"])
+
+# ---- the dominant kernel's duration from `rocprofv3 --kernel-trace --stats` of the same command: what bench.py's roofline.frac is computed from
+# (profiles/rocprof_kernel_latest.json, tied to the tree like the traffic file).  `avg_ns` is what the tracked stats CSV yields (every launch
+# of the profiled command: sum of TotalDurationNs over the big-round kernels / sum of Calls); `warm` the same from the trace with the
+# warm-up proofs of that command dropped; `per_proof_kernel_total_ms` every kernel of a warm proof added up (must fit inside ms_per_step).
+stats = list(csv.DictReader(open(os.path.join(base, "stats", "bench_kernel_stats.csv"))))
+dom = [r for r in stats if any(x in r["Name"] for x in kern.split("+"))]
+calls = sum(int(r["Calls"]) for r in dom)
+total_ns = sum(int(r["TotalDurationNs"]) for r in dom)
+trace = sorted(csv.DictReader(open(os.path.join(base, "stats", "bench_kernel_trace.csv"))), key=lambda r: int(r["Start_Timestamp"]))
+m = re.search(r"--warmup (\d+)", cmdline)
+warmup = int(m.group(1)) if m else 0
+proofs, cur = [], None  # a proof = everything from one k_round1_tree launch up to the next
+for r in trace:
+    name = r["Kernel_Name"]
+    if "k_round1_tree" in name:
+        cur = []
+        proofs.append(cur)
+    if cur is not None:
+        cur.append((name, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+warm = proofs[warmup:]
+wd = [d for pr in warm for (n, d) in pr if any(x in n for x in kern.split("+"))]
+ksum = {
+    **bench.source_shas(), "git_head": os.environ.get("GIT_HEAD"), "bench_command": cmdline,
+    "command": "rocprofv3 --kernel-trace --stats --output-format csv -- " + cmdline,
+    "stats_csv": f"profiles/{tag}_rocprofv3_kernel_stats.csv", "trace_csv": f"profiles/{tag}_rocprofv3_kernel_trace.csv",
+    "kernel": " + ".join(r["Name"].split("(")[0].replace("void ", "") for r in dom),
+    "launches": calls, "total_ns": total_ns, "avg_ns": total_ns / max(calls, 1),
+    "proofs": len(proofs), "warmup_proofs_dropped": warmup,
+    "warm": {"proofs": len(warm), "launches": len(wd), "avg_ns": sum(wd) / max(len(wd), 1)},
+    "launches_per_proof": calls / max(len(proofs), 1),
+    "per_proof_kernel_total_ms": (sum(d for pr in warm for (_, d) in pr) / max(len(warm), 1)) * 1e-6,
+    "per_proof_big_round_kernels_ms": sum(wd) / max(len(warm), 1) * 1e-6,
+}
+json.dump(ksum, open(os.path.join(out, f"{tag}_rocprof_kernel.json"), "w"), indent=1)
+if not no_latest:
+    shutil.copy(os.path.join(out, f"{tag}_rocprof_kernel.json"), os.path.join(out, "rocprof_kernel_latest.json"))
+print("stats: launches", calls, "avg_ns", ksum["avg_ns"], "warm avg_ns", ksum["warm"]["avg_ns"], "kernel ms per warm proof", ksum["per_proof_kernel_total_ms"])
