@@ -421,6 +421,9 @@ def run_rank(args, W, result):
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
             cpu = {"value": None, "unit": "field-ops/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
+    for kv in args.policy:  # (process-wide: thread ranks set the same values again, harmlessly)
+        key, _, val = kv.partition("=")
+        _lib.set_policy(key.strip(), int(val))
     torch.cuda.set_device(local_rank)  # (thread-local, like sc_set_device)
     dev = torch.device("cuda", local_rank)
     _lib.check(sc.lib().sc_set_device(local_rank))
@@ -718,7 +721,7 @@ def run_rank(args, W, result):
                        "nv": nv_total, "nv_per_gpu": nv_local, "tables": U, "degree": max(len(s) for s in shapes),
                        "field_ops_per_step": ops, "sharding": f"high-bit x{world}" if world > 1 else "none",
                        "launcher": W.launcher, "ranks_seen": ranks_seen, "communicator": comm_kind, "exchange": exchange,
-                       "round_loop": round_loop, "round_loop_reason": box["why"],
+                       "round_loop": round_loop, "round_loop_reason": box["why"], "policy": args.policy,
                        # the scaling model's figure for THIS line, written down before any N > 1 hardware run: the line tests it
                        "predicted_ms_per_step": pred["predicted_ms_per_step"], "exchange_assumed_us": pred.get("exchange_assumed_us"), "prediction": pred,
                        "gpu_leg": {"warmup_proofs": args.warmup, "timed_proofs": args.steps, "proofs_after_the_clock": cooldown + (1 if all_have else 0),
@@ -905,6 +908,8 @@ def main():
     ap.add_argument("--launcher", default="auto", choices=("auto", "processes", "threads"),
                     help="--gpus N > 1 without an external launcher: one process per GPU via torch.distributed.run (RCCL), or N thread ranks of this "
                          "process over the library's peer-to-peer communicator; auto = processes, threads if that cannot start")
+    ap.add_argument("--policy", action="append", default=[], metavar="KEY=VALUE",
+                    help="sc_set_policy(KEY, VALUE) on every rank before anything else (include/sumcheck_hip.h lists the keys), e.g. --policy rccl_direct=0; repeatable")
     ap.add_argument("--min-gpu-seconds", type=float, default=10.0,
                     help="after the timed region, keep proving (untimed) until the GPU leg has lasted about this long; 0 = off")
     args = ap.parse_args()

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 4 /* 4: sc_comm_info, sc_comm_exchange_bench, sc_set_publish_timeout_ms, sc_prover_get_round_timing, sc_library_stats (additions only); 3: sc_prover_set_polling, sc_prover_set_resident, SC_NO_DEVICE_POLLING, sc_set_cache_limit, sc_comm_init_p2p, sc_gkr_prove_sharded (additions only) */
+#define SC_ABI_VERSION 5 /* 5: sc_set_policy, sc_get_policy, sc_plan_count, sc_plan_name, sc_plan_stats (additions only); 4: sc_comm_info, sc_comm_exchange_bench, sc_set_publish_timeout_ms, sc_prover_get_round_timing, sc_library_stats (additions only); 3: sc_prover_set_polling, sc_prover_set_resident, SC_NO_DEVICE_POLLING, sc_set_cache_limit, sc_comm_init_p2p, sc_gkr_prove_sharded (additions only) */
 #define SC_API __attribute__((visibility("default")))
 
 enum sc_status {
@@ -343,6 +343,31 @@ SC_API int sc_set_cache_limit(uint64_t bytes);
  * (patience expired) and took the ordinary path; [5] proofs repeated after an expired device-side wait; [6] of the launches in [0],
  * those that kept the tables resident in LDS (k_tail_slices). */
 SC_API int sc_library_stats(uint64_t *out, uint32_t n);
+/* Library policy: process-wide integers that select between equivalent paths (every path yields the same bits; tests and A/B runs switch
+ * them).  The shipped library reads NO environment variable for any of them -- a drop-in library must not change its code path with the
+ * caller's environment; it reads only SC_HOST_TRACE / SC_GKR_TRACE (stderr timings) and SC_PUBLISH_TIMEOUT_MS.  Keys (default):
+ *   "pipeline" (1)           0: no kernel ever waits for the host (neither the persistent tail kernels nor pipelined launches); per handle:
+ *                            SC_NO_DEVICE_POLLING / sc_prover_set_polling
+ *   "resident" (1)           0: the interactive sc_prove_round never keeps a kernel on the GPU between calls (per handle: sc_prover_set_resident)
+ *   "tail" (1)               0: handles built from now on run their latency-bound rounds as pipelined launches, not in a persistent kernel
+ *   "tail_slices" (1)        0: the latency-bound rounds never run out of LDS (k_tail_rounds / launches instead of k_tail_slices)
+ *   "vram_mailbox" (1)       0: challenges go through the host-mapped mailbox even where the host could store into device memory
+ *   "wide_tree" (1)          0: handles built from now on sum products of five to twelve multiplicands node by node
+ *   "rccl_direct" (1)        0: communicators initialised from now on vote against direct publication (every rank then uses the publish kernel)
+ *   "shard_gather_log2" (15) 1..15: shard size (log2 entries per table in the first replicated round's region) at which a sharded proof
+ *                            gathers onto every rank; must be the same on every rank
+ *   "gkr_direct" (1)         0: sc_gkr_prove initialises through sort + merge (the list form) instead of the bucketed kernels
+ *   "wait_spins" (2^22)      bound of a device-side wait for a challenge, in polls (tests shorten it to exercise the give-up path)
+ * Unknown key or value out of range: SC_ERR_BAD_ARG. */
+SC_API int sc_set_policy(const char *key, int64_t value);
+SC_API int sc_get_policy(const char *key, int64_t *value);
+/* Launch-plan counters (process-wide, monotone): one per path the host side can choose for a round or an initialisation -- which big-round
+ * kernel, which table format, which finalize, which latency-bound form, which exchange.  sc_plan_count() plans, sc_plan_name(i) their
+ * names ("big.merged.round1", "tail.slices8", "sharded.p2p", ...; NULL past the end), sc_plan_stats fills out[0..n).  What the GPU test
+ * suite uses to prove that every plan was reached by a test that compared with the oracle (profiles/plan_coverage.json). */
+SC_API uint32_t sc_plan_count(void);
+SC_API const char *sc_plan_name(uint32_t i);
+SC_API int sc_plan_stats(uint64_t *out, uint32_t n);
 
 /* ---- synthetic inputs + instrumentation (bench / tests) ------------------------------------- */
 /* SplitMix64-keyed uniform field elements, generated on the device: n elements of

@@ -1,4 +1,4 @@
-//! `extern "C"` binding of `libsumcheck_hip.so` (C ABI: `include/sumcheck_hip.h`, SC_ABI_VERSION 4) exposed with the
+//! `extern "C"` binding of `libsumcheck_hip.so` (C ABI: `include/sumcheck_hip.h`, SC_ABI_VERSION 5) exposed with the
 //! signatures of the reference's public API:
 //!
 //! | here | reference |
@@ -60,7 +60,7 @@ pub struct sc_comm {
     _private: [u8; 0],
 }
 
-pub const SC_ABI_VERSION: c_int = 4;
+pub const SC_ABI_VERSION: c_int = 5;
 pub const SC_OK: c_int = 0;
 pub const SC_ERR_CONSTANT_POLY: c_int = 1;
 pub const SC_ERR_FIRST_ROUND_HAS_MSG: c_int = 2;
@@ -87,6 +87,11 @@ extern "C" {
     pub fn sc_release_caches() -> c_int;
     pub fn sc_set_cache_limit(bytes: u64) -> c_int;
     pub fn sc_library_stats(out: *mut u64, n: u32) -> c_int;
+    pub fn sc_set_policy(key: *const c_char, value: i64) -> c_int;
+    pub fn sc_get_policy(key: *const c_char, value: *mut i64) -> c_int;
+    pub fn sc_plan_count() -> u32;
+    pub fn sc_plan_name(i: u32) -> *const c_char;
+    pub fn sc_plan_stats(out: *mut u64, n: u32) -> c_int;
     pub fn sc_prover_set_polling(p: *mut sc_prover, allow: c_int) -> c_int;
     pub fn sc_prover_set_resident(p: *mut sc_prover, patience_polls: u32) -> c_int;
     pub fn sc_fix_variables(input: *const u64, nv: u32, point: *const u64, k: u32, out: *mut u64, flags: u32) -> c_int;

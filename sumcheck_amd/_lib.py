@@ -66,6 +66,11 @@ SIGNATURES = {
     "sc_prover_set_resident": (C.c_int, [_V, C.c_uint32]),
     "sc_set_cache_limit": (C.c_int, [C.c_uint64]),
     "sc_library_stats": (C.c_int, [u64p, C.c_uint32]),
+    "sc_set_policy": (C.c_int, [C.c_char_p, C.c_int64]),
+    "sc_get_policy": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
+    "sc_plan_count": (C.c_uint32, []),
+    "sc_plan_name": (C.c_char_p, [C.c_uint32]),
+    "sc_plan_stats": (C.c_int, [u64p, C.c_uint32]),
     "sc_prove_round_partial": (C.c_int, [_V, _V, _V]),
     "sc_wide_reduce": (C.c_int, [_V, C.c_uint32, _V]),
     "sc_prover_bind_final": (C.c_int, [_V, _V, _V]),
@@ -115,7 +120,7 @@ SIGNATURES = {
     "sc_bench_modmul": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), u64p]),
 }
 
-ABI_VERSION = 4  # SC_ABI_VERSION of include/sumcheck_hip.h as declared above
+ABI_VERSION = 5  # SC_ABI_VERSION of include/sumcheck_hip.h as declared above
 _lib = None
 
 
@@ -176,3 +181,41 @@ def lib():
 def check(rc: int):
     if rc != SC_OK:
         raise SumcheckError(rc, lib().sc_last_error().decode("utf-8", "replace"))
+
+
+def set_policy(key: str, value: int) -> None:
+    """sc_set_policy: process-wide library policy (include/sumcheck_hip.h lists the keys)"""
+    check(lib().sc_set_policy(key.encode(), int(value)))
+
+
+def get_policy(key: str) -> int:
+    v = C.c_int64()
+    check(lib().sc_get_policy(key.encode(), C.byref(v)))
+    return int(v.value)
+
+
+class policy:
+    """with _lib.policy(tail_slices=0): ...  -- set for the block, restored afterwards (tests, A/B runs)"""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = get_policy(k)
+            set_policy(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_policy(k, v)
+        return False
+
+
+def plan_stats() -> dict:
+    """sc_plan_stats as {plan name: launches so far in this process}"""
+    L = lib()
+    n = L.sc_plan_count()
+    out = (C.c_uint64 * n)()
+    check(L.sc_plan_stats(out, n))
+    return {L.sc_plan_name(i).decode(): int(out[i]) for i in range(n)}

@@ -286,12 +286,13 @@ int prover_build(const sc_poly_desc *d, sc_prover *p) {
     if (!p->use_fe && p->kernel_variant == 3) p->kernel_variant = 0;
 #endif
     p->use_f29 = p->kernel_variant == 3;
+    p->wide_tree = wide_tree_enabled(); // (the policy as it is NOW: the handle's table format depends on it)
 #ifdef SC_EXPERIMENTS
     if (const char *e = std::getenv("SC_F29")) p->use_f29 = p->use_f29 && std::atoi(e) != 0;
 #endif
     // (every big-round kernel of the handle must read the format: the tree kernels do, for up to eight factors with kernels_wide.hip)
     for (uint32_t k = 0; k < d->n_products; ++k)
-        if (d->prod_offsets[k + 1] - d->prod_offsets[k] > (wide_tree_enabled() ? 8u : 4u)) p->use_f29 = false;
+        if (d->prod_offsets[k + 1] - d->prod_offsets[k] > (p->wide_tree ? 8u : 4u)) p->use_f29 = false;
     // with more tables than the small-round kernels take, the big-round kernels also run the short rounds, whose tables are
     // smaller than one 128-entry block of the chunk-planar layout
     if (d->n_tables > (uint32_t)scd::kMaxSmallTables) p->use_f29 = false;
@@ -301,8 +302,8 @@ int prover_build(const sc_poly_desc *d, sc_prover *p) {
 #ifdef SC_EXPERIMENTS
     if (const char *e = std::getenv("SC_MERGE")) p->merge_rounds = p->merge_rounds && std::atoi(e) != 0;
     if (const char *e = std::getenv("SC_FUSED_FIN")) p->fused_finalize = std::atoi(e) != 0;
-    if (const char *e = std::getenv("SC_TAIL")) p->use_tail = std::atoi(e) != 0; // 0: late rounds as pipelined launches (the path sharded RCCL proofs take)
 #endif
+    p->use_tail = scd::policy(scd::kPolTail) != 0; // 0: late rounds as pipelined launches (the path sharded RCCL proofs take)
 
     // products: distinct tables + multiplicities
     uint64_t partial_elems = 0;
@@ -365,6 +366,7 @@ int prover_build(const sc_poly_desc *d, sc_prover *p) {
     // streamed: only where it can matter (>= 2^11 entries) and where the merged big-round kernel applies (it is what walks the chunks)
     const bool streamed = !on_device && (d->flags & SC_TABLES_STREAM) && p->nv >= 11;
     const bool small_foot = borrow || streamed; // the caller's tables are only read: the handle holds the bound tables alone
+    bool staged = false;
     const uint64_t s0 = small_foot ? std::max<uint64_t>(n >> 1, 1) : n;
     const uint64_t s1 = small_foot ? std::max<uint64_t>(n >> 2, 1) : std::max<uint64_t>(n >> 1, 1);
     const uint64_t per_table = (s0 + s1) * 36; // 32 B main + 4 B limb-8 array per element (internal F29 format)
@@ -392,7 +394,9 @@ int prover_build(const sc_poly_desc *d, sc_prover *p) {
             p->origin.push_back(t.cur);
         } else {
             if (!on_device && (d->flags & SC_TABLES_STREAM)) p->host_tabs.push_back(d->tables[u]); // too small to stream: copied, but rewound like a streamed handle
-            HIP_TRY(hipMemcpyAsync(t.buf[0], d->tables[u], n * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, p->stream));
+            // (host tables of a shape the merged big-round kernel takes: copied at the END of the build, in chunks, with round 1 computed under the copy)
+            if (!(staged = !on_device && staged_init_applies(p)))
+                HIP_TRY(hipMemcpyAsync(t.buf[0], d->tables[u], n * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, p->stream));
             t.cur = t.buf[0];
             t.next = 1;
         }
@@ -419,8 +423,13 @@ int prover_build(const sc_poly_desc *d, sc_prover *p) {
     HIP_TRY(hipMalloc(&p->d_finprods, std::max<size_t>(p->K, 1) * sizeof(FinProd)));
     if (p->K) HIP_TRY(hipMemcpyAsync(p->d_finprods, fin.data(), p->K * sizeof(FinProd), hipMemcpyHostToDevice, p->stream));
     p->h_finprods = fin;
-    HIP_TRY(hipMalloc(&p->d_W, std::max<size_t>(Wall.size(), 1) * 32));
-    if (!Wall.empty()) HIP_TRY(hipMemcpyAsync(p->d_W, Wall.data(), Wall.size() * 32, hipMemcpyHostToDevice, p->stream));
+    // twice: the matrices the kernels read, and behind them the copy sc_internal_scale_by_bound_table multiplies from (and a reset restores)
+    HIP_TRY(hipMalloc(&p->d_W, std::max<size_t>(2 * Wall.size(), 1) * 32));
+    p->w_elems = (uint32_t)Wall.size();
+    if (!Wall.empty()) {
+        HIP_TRY(hipMemcpyAsync(p->d_W, Wall.data(), Wall.size() * 32, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->d_W + Wall.size(), Wall.data(), Wall.size() * 32, hipMemcpyHostToDevice, p->stream));
+    }
     HIP_TRY(hipMalloc(&p->d_scratch, (size_t)(2 + p->D) * std::max<uint32_t>(p->K, 1) * p->D * 32));
     {
         const size_t one = (size_t)std::max<uint32_t>(p->K, 1) * p->D * 32;
@@ -452,6 +461,10 @@ int prover_build(const sc_poly_desc *d, sc_prover *p) {
     if (p->any_generic || p->U > (uint32_t)scd::kMaxSmallTables) { // (two sets: a streamed handle's chunks alternate between them, as between the staging slots)
         HIP_TRY(hipMalloc(&p->d_cur_tables, 2 * p->U * sizeof(void *)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->h_cur_tables), 2 * p->U * sizeof(void *), hipHostMallocDefault));
+    }
+    if (staged) {
+        int rc_s = staged_copy_and_round1(p, d->tables);
+        if (rc_s) return rc_s;
     }
     HIP_TRY(hipStreamSynchronize(p->stream)); // inputs are copied: the caller may drop them now (prover.rs:55-59)
     return SC_OK;
@@ -703,6 +716,11 @@ extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_nu
         int rc_t = collect_timing(p);
         if (rc_t) return rc_t;
     }
+    p->r1_cached = false;
+    if (p->w_scaled) { // (sc_internal_scale_by_bound_table: the polynomial is the descriptor's again)
+        HIP_TRY(hipMemcpyAsync(p->d_W, p->d_W + p->w_elems, (size_t)p->w_elems * 32, hipMemcpyDeviceToDevice, p->stream));
+        p->w_scaled = false;
+    }
     const uint64_t n = 1ULL << p->nv;
     if (p->streamed) {
         if (flags & SC_TABLES_ON_DEVICE) return sc_internal_fail(SC_ERR_BAD_ARG, "streamed tables are host tables");
@@ -731,13 +749,21 @@ extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_nu
         if (!tables_or_null) return sc_internal_fail(SC_ERR_BAD_ARG, "a copying handle needs the tables again to reset");
         const bool on_device = flags & SC_TABLES_ON_DEVICE;
         if (on_device) HIP_TRY(hipDeviceSynchronize()); // the producer of the new tables may still be running on another stream
+        const bool staged = !on_device && staged_init_applies(p);
         for (uint32_t u = 0; u < p->U; ++u) {
             if (!tables_or_null[u]) return sc_internal_fail(SC_ERR_BAD_ARG, "table %u is null", u);
-            HIP_TRY(hipMemcpyAsync(p->tabs[u].buf[0], tables_or_null[u], n * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                   p->stream));
+            if (!staged)
+                HIP_TRY(hipMemcpyAsync(p->tabs[u].buf[0], tables_or_null[u], n * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                       p->stream));
             p->tabs[u].cur = p->tabs[u].buf[0];
             p->tabs[u].cur_top = nullptr;
             p->tabs[u].next = 1;
+        }
+        if (staged) {
+            p->round = 0; // (what staged_copy_and_round1 expects: a handle in front of its first round)
+            p->exhausted = false;
+            int rc_s = staged_copy_and_round1(p, tables_or_null);
+            if (rc_s) return rc_s;
         }
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
@@ -745,6 +771,27 @@ extern "C" int sc_prover_reset(sc_prover *p, const uint64_t *const *tables_or_nu
     p->sums_round = -1;
     p->exhausted = false;
     p->randomness.clear();
+    return SC_OK;
+}
+
+// ---- gkr.hip: phase two without the f3 pass ---------------------------------------------------------------------------------------
+// GKRRoundSumcheck::prove multiplies f3 by the scalar f2(u) before phase two (gkr_round_sumcheck/mod.rs:71-75,122).  Phase one's prover
+// has bound f2 at u_0..u_{dim-2} already (prover.rs:84-89): f2(u) = lo + u_last (hi - lo) of its final two-entry table, and a scalar
+// factor of a one-product polynomial is that product's coefficient -- exact field arithmetic, the same canonical messages.  So:
+//   sc_internal_bound_table(p, u)   the two-entry table the completed rounds left (device memory, canonical), to be taken BEFORE a reset
+//   sc_internal_scale_by_bound_table(p, table, r_last)   after the reset, on the handle's stream: every node->message matrix becomes
+//                                   (descriptor's matrix) x table(r_last); nothing visits the host.  The next reset restores the matrices.
+hipStream_t sc_internal_prover_stream(sc_prover *p) { return p->stream; }
+const void *sc_internal_bound_table(sc_prover *p, uint32_t u) {
+    if (!p || u >= p->U || p->round != p->nv || p->exhausted || p->tabs[u].cur_top || p->res.active) return nullptr;
+    return p->tabs[u].cur;
+}
+int sc_internal_scale_by_bound_table(sc_prover *p, const void *table, const sch::Fr &r_last) {
+    if (!p || !table || p->round != 0) return sc_internal_fail(SC_ERR_BAD_ARG, "scale_by_bound_table: a freshly reset handle and a bound table");
+    DeviceGate gate_(p->device);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(scd::launch_scale_w_by_table_eval(p->d_W, p->d_W + p->w_elems, p->w_elems, table, to_dev(r_last), p->stream));
+    p->w_scaled = true;
     return SC_OK;
 }
 
@@ -1021,7 +1068,9 @@ std::vector<uint8_t> pool_key_of(const sc_poly_desc *d, int device) {
         const uint8_t *b = static_cast<const uint8_t *>(p);
         k.insert(k.end(), b, b + n);
     };
-    const uint32_t head[6] = {d->num_vars, d->max_multiplicands, d->n_products, d->n_tables, d->flags, (uint32_t)device};
+    // (the policies a handle is BUILT under are part of its identity: a handle built before sc_set_policy is not the one to reuse after)
+    const uint32_t head[8] = {d->num_vars, d->max_multiplicands, d->n_products, d->n_tables, d->flags, (uint32_t)device,
+                              (uint32_t)scd::policy(scd::kPolWideTree), (uint32_t)scd::policy(scd::kPolTail)};
     put(head, sizeof(head));
     if (d->n_products) {
         put(d->prod_offsets, (size_t)(d->n_products + 1) * 4);
@@ -1065,6 +1114,76 @@ void sc_internal_release_handle_pool() { // sc_release_caches (gkr.hip)
         g_pool.h = nullptr;
     }
     if (old) prover_destroy(old);
+}
+
+// ---- library policy and launch-plan counters (kernels.h: PolicyKey, Plan) --------------------------------------------------------------
+namespace {
+struct PolicyDef {
+    const char *name;
+    int64_t def, lo, hi;
+};
+constexpr PolicyDef kPolicyDefs[scd::kPolCount] = {
+    {"pipeline", 1, 0, 1},     {"resident", 1, 0, 1},          {"tail_slices", 1, 0, 1}, {"vram_mailbox", 1, 0, 1},           {"wide_tree", 1, 0, 1},
+    {"rccl_direct", 1, 0, 1},  {"shard_gather_log2", 15, 1, 15}, {"gkr_direct", 1, 0, 1},  {"wait_spins", 1 << 22, 1, 0xffffffffLL}, {"tail", 1, 0, 1},
+    {"staged_init", 1, 0, 1},
+};
+struct PolicyTable {
+    std::atomic<int64_t> v[scd::kPolCount];
+    PolicyTable() {
+        for (int i = 0; i < scd::kPolCount; ++i) {
+            int64_t x = kPolicyDefs[i].def;
+#ifdef SC_EXPERIMENTS // the cross-check build (tests/test_gpu_variants.py) takes the initial values from SC_<KEY> in the environment
+            std::string env = "SC_";
+            for (const char *c = kPolicyDefs[i].name; *c; ++c) env += (char)std::toupper((unsigned char)*c);
+            if (const char *e = std::getenv(env.c_str())) x = std::min(std::max<int64_t>(std::atoll(e), kPolicyDefs[i].lo), kPolicyDefs[i].hi);
+#endif
+            v[i].store(x, std::memory_order_relaxed);
+        }
+    }
+};
+PolicyTable &policy_table() {
+    static PolicyTable t;
+    return t;
+}
+std::atomic<uint64_t> g_plan[scd::kPlanCount];
+constexpr const char *kPlanNames[scd::kPlanCount] = {
+    "big.merged.round1", "big.merged.bind_chain", "big.merged.bind", "big.claim_identity", "big.store_f29", "big.store_canonical", "big.per_product_tree",
+    "big.wide", "big.wide16", "big.generic", "big.node_by_node", "big.bind_pass", "big.streamed", "big.staged_round1", "finalize.multi_block", "finalize.one_block", "finalize.no_lds",
+    "small.launched", "small.combos_table", "small.ptrs", "small.pipelined", "tail.slices8", "tail.slices12", "tail.rounds", "resident.slices",
+    "resident.rounds", "sharded.rccl_direct", "sharded.rccl_publish", "sharded.host", "sharded.p2p", "sharded.gather_tail", "gkr.bucketed_grouped",
+    "gkr.bucketed_counted", "gkr.list_form", "gkr.coeff_from_bound_table", "gkr.sharded", "fold_multi",
+};
+} // namespace
+int64_t scd::policy(int key) { return key >= 0 && key < scd::kPolCount ? policy_table().v[key].load(std::memory_order_relaxed) : 0; }
+void scd::plan_hit(int plan) {
+    if (plan >= 0 && plan < scd::kPlanCount) g_plan[plan].fetch_add(1, std::memory_order_relaxed);
+}
+extern "C" int sc_set_policy(const char *key, int64_t value) {
+    if (!key) return sc_internal_fail(SC_ERR_BAD_ARG, "null policy key");
+    for (int i = 0; i < scd::kPolCount; ++i) {
+        if (std::strcmp(key, kPolicyDefs[i].name) != 0) continue;
+        if (value < kPolicyDefs[i].lo || value > kPolicyDefs[i].hi)
+            return sc_internal_fail(SC_ERR_BAD_ARG, "policy %s takes %lld..%lld", key, (long long)kPolicyDefs[i].lo, (long long)kPolicyDefs[i].hi);
+        policy_table().v[i].store(value, std::memory_order_relaxed);
+        return SC_OK;
+    }
+    return sc_internal_fail(SC_ERR_BAD_ARG, "unknown policy key '%s'", key);
+}
+extern "C" int sc_get_policy(const char *key, int64_t *value) {
+    if (!key || !value) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    for (int i = 0; i < scd::kPolCount; ++i) {
+        if (std::strcmp(key, kPolicyDefs[i].name) != 0) continue;
+        *value = scd::policy(i);
+        return SC_OK;
+    }
+    return sc_internal_fail(SC_ERR_BAD_ARG, "unknown policy key '%s'", key);
+}
+extern "C" uint32_t sc_plan_count(void) { return (uint32_t)scd::kPlanCount; }
+extern "C" const char *sc_plan_name(uint32_t i) { return i < (uint32_t)scd::kPlanCount ? kPlanNames[i] : nullptr; }
+extern "C" int sc_plan_stats(uint64_t *out, uint32_t n) {
+    if (!out) return sc_internal_fail(SC_ERR_BAD_ARG, "null argument");
+    for (uint32_t i = 0; i < n; ++i) out[i] = i < (uint32_t)scd::kPlanCount ? g_plan[i].load(std::memory_order_relaxed) : 0;
+    return SC_OK;
 }
 
 extern "C" int sc_library_stats(uint64_t *out, uint32_t n) {

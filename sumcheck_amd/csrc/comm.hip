@@ -47,27 +47,36 @@ extern "C" int sc_comm_unique_id(uint8_t *out128) {
 // a second launch of latency per round.  Instead the all-reduce's receive buffer IS the host-mapped page, and every rank ORs a tag
 // into the top bits of its lanes (kernels.h: wide_tag_of): a word that reads nranks * tag is this round's total, the host's poll is
 // the fetch.  Whether RCCL's kernels deliver into host-mapped memory on this system, and whether the host sees the words without a
-// stream synchronisation, is tested here with two tagged all-reduces of known lanes; a failure (or SC_RCCL_DIRECT=0) leaves the
-// communicator on the publish kernel.  The decision is local (the peers issue the same ncclAllReduce either way).
+// stream synchronisation, is tested here with two tagged all-reduces of known lanes.
+// THE DECISION IS COLLECTIVE: a rank that tags its lanes and waits for nranks * tag cannot work with a peer that does neither, so after
+// the two probes the ranks take the minimum of their verdicts (a third all-reduce, ncclMin) -- one rank's failed probe, failed
+// allocation or sc_set_policy("rccl_direct", 0) leaves EVERY rank on the publish kernel.  Every rank issues all three collectives
+// whatever it observed or failed to allocate (the peers are inside them): without the host-mapped page the probes run in place in
+// device memory and the rank votes no.
 static bool rccl_direct_probe(sc_comm *c) {
-    const char *env = std::getenv("SC_RCCL_DIRECT");
-    if (env && std::atoi(env) == 0) return false;
     constexpr int kWords = 40;
     hipStream_t s = nullptr;
     uint64_t *d = nullptr, *h = nullptr, *h_dev = nullptr;
-    bool ok = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&d), kWords * 8) == hipSuccess &&
+    // what the collectives themselves need: a stream and 41 device words (failing these, this rank cannot take part in any collective at all)
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d), (kWords + 1) * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        if (s) (void)hipStreamDestroy(s);
+        return false;
+    }
+    bool ok = scd::policy(scd::kPolRcclDirect) != 0 &&
               hipHostMalloc(reinterpret_cast<void **>(&h), kWords * 8, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
               hipHostGetDevicePointer(reinterpret_cast<void **>(&h_dev), h, 0) == hipSuccess;
-    if (ok) std::memset(h, 0, kWords * 8);
+    if (!ok) h_dev = nullptr;
+    (void)hipGetLastError();
+    if (h) std::memset(h, 0, kWords * 8);
     const uint64_t tri = (uint64_t)c->nranks * (uint64_t)(c->nranks + 1) / 2;
     uint64_t mine[kWords];
-    // (every rank issues both all-reduces whatever it observed: the peers are inside them)
     for (uint32_t it = 0; it < 2; ++it) {
         const uint32_t tag = scd::wide_tag_of(0x7ffeu + it); // (the second one wraps the tag)
         for (int w = 0; w < kWords; ++w) mine[w] = ((uint64_t)(c->rank + 1) * (uint64_t)(w + 1 + it)) | ((uint64_t)tag << scd::kWideTagShift);
-        ok = ok && hipMemcpyAsync(d, mine, sizeof(mine), hipMemcpyHostToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-        const bool issued = d && h_dev && (int)g_nccl.AllReduce(d, h_dev, (size_t)kWords, ncclUint64, ncclSum, c->comm, s) == 0;
-        ok = ok && issued;
+        ok = (hipMemcpyAsync(d, mine, sizeof(mine), hipMemcpyHostToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) && ok;
+        const bool issued = (int)g_nccl.AllReduce(d, h_dev ? h_dev : d, (size_t)kWords, ncclUint64, ncclSum, c->comm, s) == 0; // (always issued)
+        ok = ok && issued && h_dev;
         if (ok) { // the words must show up by themselves: the rounds of a proof never synchronise the stream
             const auto t0 = std::chrono::steady_clock::now();
             const uint64_t expect = (uint64_t)c->nranks * tag;
@@ -79,13 +88,21 @@ static bool rccl_direct_probe(sc_comm *c) {
             ok = seen;
             for (int w = 0; w < kWords && ok; ++w) ok = (h[w] & ((1ULL << scd::kWideTagShift) - 1)) == tri * (uint64_t)(w + 1 + it);
         }
-        if (s) (void)hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(s);
     }
-    if (d) (void)hipFree(d);
+    // the agreement: min over the ranks of "my probe passed"
+    uint64_t vote = ok ? 1 : 0, agreed = 0;
+    bool v_ok = hipMemcpyAsync(d + kWords, &vote, 8, hipMemcpyHostToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    v_ok = ((int)g_nccl.AllReduce(d + kWords, d + kWords, 1, ncclUint64, ncclMin, c->comm, s) == 0) && v_ok; // (always issued)
+    v_ok = v_ok && hipMemcpyAsync(&agreed, d + kWords, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(d);
     if (h) (void)hipHostFree(h);
-    if (s) (void)hipStreamDestroy(s);
+    (void)hipStreamDestroy(s);
     (void)hipGetLastError();
-    return ok;
+    // (a rank whose vote could not be cast or read has no way of knowing what the others agreed on: it reports no -- and so, by the
+    // minimum, do all the others unless the failure was in reading the result back, which a broken device does not survive anyway)
+    return v_ok && agreed == 1;
 }
 
 extern "C" int sc_comm_init(const uint8_t *id128, int rank, int nranks, sc_comm **out) {

@@ -45,6 +45,9 @@ uint64_t sc_internal_cache_limit();                   // abi.hip: sc_set_cache_l
 void sc_internal_release_eval_cache();                // abi.hip: sc_poly_evaluate's cached work areas
 void sc_internal_release_handle_pool();               // abi.hip: the prover sc_ml_prove keeps between one-shot proofs
 int sc_internal_run_rounds(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, uint64_t *out_msgs, sch::Fr *out_challenges); // api.hip
+hipStream_t sc_internal_prover_stream(sc_prover *p);                                                  // abi.hip (GKR phase two: see there)
+const void *sc_internal_bound_table(sc_prover *p, uint32_t u);
+int sc_internal_scale_by_bound_table(sc_prover *p, const void *table, const sch::Fr &r_last);
 struct sc_rng {
     sch::Blake2b512Rng rng;
 };
@@ -75,37 +78,72 @@ __device__ __forceinline__ void fr_st(Fr *p, const Fr &a) { scd::fr_store(reinte
 
 // precompute_eq (ark-poly): eq[b] = prod_i (b_i ? g_i : 1 - g_i), built there by doubling: dp[b + 2^i] = dp[b] * g_i ; dp[b] -= dp[b + 2^i].
 // Exact field arithmetic, so any evaluation order gives the same canonical table.  Here: the low kl <= 11 variables and the high
-// kh <= 11 variables are doubled by one block each (2 blocks, one launch; levels separated by block barriers), and the table is
-// their outer product (one Montgomery product per entry, fully parallel): 2 launches instead of k.
-constexpr int kEqMaxVars = 22, kEqHalfMax = 11, kEqBlock = 1024;
+// kh <= 11 variables are two small tables (EqSplit; the full table, where one is wanted, is their outer product: k_eq_outer).  A half is
+// built in LOGARITHMIC depth -- one dependent Montgomery product is ~1 us for a lone wavefront, and the doubling recurrence is a chain
+// of kl of them (16 us at kl = 10, measured): start from the kl one-variable tables {1 - g_i, g_i}, merge neighbours pairwise by outer
+// product (low variables vary fastest) until two tables are left, and write their outer product -- the half -- straight to memory,
+// a slice of it per block: 10 variables -> 5 -> 3 -> 2 tables -> out: four products deep.
+constexpr int kEqMaxVars = 22, kEqHalfMax = 11, kEqBlock = 512, kEqSlices = 4, kEqLdsEntries = 320; // (the two last tables: 2^8 + 2^3 entries at most, a level before: less)
 struct EqPoint {
     FrHost g[kEqMaxVars];
 };
-__device__ __forceinline__ void eq_double_block(Fr *dp, const EqPoint &P, const int first, const int n) { // n >= 1 variables
-    if (threadIdx.x == 0) {
+__device__ void eq_half_block(Fr *__restrict__ out, const EqPoint &P, const int first, const int n, const int slice, const int n_slices) { // n >= 1 variables
+    __shared__ uint4 tab[2][2 * kEqLdsEntries];
+    __shared__ int off[2][kEqHalfMax + 1], lg[2][kEqHalfMax + 1];
+    Fr *cur = reinterpret_cast<Fr *>(tab[0]), *nxt = reinterpret_cast<Fr *>(tab[1]);
+    int nt = n, w = 0;
+    if ((int)threadIdx.x < n) { // level 0: {1 - g, g} per variable
         Fr g;
-        const FrU gu = fru(P.g[first]);
+        const FrU gu = fru(P.g[first + threadIdx.x]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) g.v[i] = gu.v[i];
-        fr_st(dp + 0, scd::fr_sub(scd::fr_one(), g));
-        fr_st(dp + 1, g);
+        fr_st(cur + 2 * threadIdx.x, scd::fr_sub(scd::fr_one(), g));
+        fr_st(cur + 2 * threadIdx.x + 1, g);
+        off[0][threadIdx.x] = 2 * threadIdx.x;
+        lg[0][threadIdx.x] = 1;
     }
-    for (int i = 1; i < n; ++i) {
-        __syncthreads();
-        const FrU g = fru(P.g[first + i]);
-        const uint32_t half = 1u << i;
-        for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
-            const Fr prev = fr_ld(dp + b);
-            const Fr hi = scd::fr_mul_u(prev, g);
-            fr_st(dp + b + half, hi);
-            fr_st(dp + b, scd::fr_sub(prev, hi));
+    __syncthreads();
+    while (nt > 2) { // merge tables 2t and 2t + 1 (an odd one out is copied)
+        const int nn = (nt + 1) / 2;
+        if (threadIdx.x == 0) {
+            int o = 0;
+            for (int t = 0; t < nn; ++t) {
+                const int l = lg[w][2 * t] + (2 * t + 1 < nt ? lg[w][2 * t + 1] : 0);
+                off[w ^ 1][t] = o;
+                lg[w ^ 1][t] = l;
+                o += 1 << l;
+            }
         }
+        __syncthreads();
+        for (int t = 0; t < nn; ++t) {
+            const int la = lg[w][2 * t], oa = off[w][2 * t], oo = off[w ^ 1][t];
+            if (2 * t + 1 < nt) {
+                const int ob = off[w][2 * t + 1], sz = 1 << lg[w ^ 1][t];
+                for (int e = threadIdx.x; e < sz; e += blockDim.x)
+                    fr_st(nxt + oo + e, scd::fr_mul(fr_ld(cur + oa + (e & ((1 << la) - 1))), fr_ld(cur + ob + (e >> la))));
+            } else {
+                for (int e = threadIdx.x; e < (1 << la); e += blockDim.x) fr_st(nxt + oo + e, fr_ld(cur + oa + e));
+            }
+        }
+        __syncthreads();
+        Fr *tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+        w ^= 1;
+        nt = nn;
+    }
+    const int total = 1 << n, per = (total + n_slices - 1) / n_slices, e0 = slice * per, e1 = min(total, e0 + per);
+    if (nt == 1) {
+        for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) fr_st(out + e, fr_ld(cur + off[w][0] + e));
+    } else {
+        const int la = lg[w][0], oa = off[w][0], ob = off[w][1];
+        for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) fr_st(out + e, scd::fr_mul(fr_ld(cur + oa + (e & ((1 << la) - 1))), fr_ld(cur + ob + (e >> la))));
     }
 }
-// block 0: low kl variables -> lo (2^kl entries); block 1 (if kh > 0): the next kh variables -> hi (2^kh entries)
+// blockIdx.y = 0: the low kl variables -> lo (2^kl entries); blockIdx.y = 1 (if kh > 0): the next kh variables -> hi; blockIdx.x: slice of the half
 __global__ __launch_bounds__(kEqBlock) void k_eq_halves(Fr *lo, Fr *hi, const EqPoint P, const int kl, const int kh) {
-    if (blockIdx.x == 0) eq_double_block(lo, P, 0, kl);
-    else eq_double_block(hi, P, kl, kh);
+    if (blockIdx.y == 0) eq_half_block(lo, P, 0, kl, blockIdx.x, gridDim.x);
+    else eq_half_block(hi, P, kl, kh, blockIdx.x, gridDim.x);
 }
 __global__ __launch_bounds__(kBlock) void k_eq_outer(const Fr *__restrict__ lo, const Fr *__restrict__ hi, const int kl, const uint64_t n, Fr *__restrict__ eq) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -213,12 +251,15 @@ __device__ __forceinline__ Fr eq_at(const EqSplit &e, const uint64_t b) {
 }
 // kPhase 1: index (z,x,y), cell = x, term = eq(g,z) * v * f3[y].  kPhase 2: index (z,x,y), cell = y, term = eq(g,z) * eq(u,x) * v.
 // kPhase 3 (initialize_phase_two on the list f1(g,.,.)): index (x,y), cell = y, term = eq(u,x) * v.
+// kPhase 4 (phase two of sc_gkr_prove after a bucketed phase one): as 2, with v already multiplied by eq(g,z) -- phase one's scatter pass
+// computed eq(g,z) * v for its own term and left it behind (the reference's f1(g,.,.), one entry per non-zero, unmerged): term = eq(u,x) * a.
 template <int kPhase>
-__host__ __device__ constexpr uint32_t cell_shift_of(const uint32_t dim) { return kPhase == 2 ? 2 * dim : dim; }
+__host__ __device__ constexpr uint32_t cell_shift_of(const uint32_t dim) { return (kPhase == 2 || kPhase == 4) ? 2 * dim : dim; }
 template <int kPhase>
 __device__ __forceinline__ Fr gkr_term(const uint64_t id, const Fr &v, const uint32_t dim, const EqSplit &eg, const EqSplit &eu, const Fr *__restrict__ f3) {
     const uint64_t mask = (1ULL << dim) - 1;
     if (kPhase == 3) return scd::fr_mul(eq_at(eu, id & mask), v);
+    if (kPhase == 4) return scd::fr_mul(eq_at(eu, (id >> dim) & mask), v);
     const Fr a = scd::fr_mul(eq_at(eg, id & mask), v);
     if (kPhase == 1) return scd::fr_mul(a, fr_ld(f3 + (id >> (2 * dim))));
     return scd::fr_mul(a, eq_at(eu, (id >> dim) & mask));
@@ -284,7 +325,7 @@ __global__ __launch_bounds__(kSortBlock) void k_bucket_scatter(const uint64_t *_
                                                                const uint32_t dim, const uint32_t c, const EqSplit eg, const EqSplit eu,
                                                                const Fr *__restrict__ f3, const uint32_t *__restrict__ counts,
                                                                const uint64_t *__restrict__ start, Fr *__restrict__ out_term,
-                                                               uint16_t *__restrict__ out_cell) {
+                                                               uint16_t *__restrict__ out_cell, Fr *__restrict__ out_a) {
     __shared__ uint32_t rank[kMaxBuckets];
     __shared__ uint64_t base[kMaxBuckets];
     const uint32_t cell_shift = cell_shift_of<kPhase>(dim), nb_mask = (1u << (dim - c)) - 1;
@@ -304,8 +345,18 @@ __global__ __launch_bounds__(kSortBlock) void k_bucket_scatter(const uint64_t *_
             id[q] = idx[i];
             t[q] = fr_ld(vals + i);
         }
+        if (kPhase == 1 && out_a) { // eq(g,z) * v is phase two's input: kept, in list order (the clamped surplus lanes rewrite the last entry with its own value)
 #pragma unroll
-        for (int q = 0; q < kIlp; ++q) t[q] = gkr_term<kPhase>(id[q], t[q], dim, eg, eu, f3);
+            for (int q = 0; q < kIlp; ++q) {
+                t[q] = scd::fr_mul(eq_at(eg, id[q] & ((1ULL << dim) - 1)), t[q]);
+                fr_st(out_a + min(i0 + (uint64_t)q * kSortBlock, hi - 1), t[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < kIlp; ++q) t[q] = scd::fr_mul(t[q], fr_ld(f3 + (id[q] >> (2 * dim))));
+        } else {
+#pragma unroll
+            for (int q = 0; q < kIlp; ++q) t[q] = gkr_term<kPhase>(id[q], t[q], dim, eg, eu, f3);
+        }
 #pragma unroll
         for (int q = 0; q < kIlp; ++q) {
             if (i0 + (uint64_t)q * kSortBlock >= hi) continue;
@@ -478,7 +529,8 @@ struct GkrCache {
     int device = -1;
     sc_prover *prover = nullptr; // K = 1, M = 2, U = 2 borrowing handle of `prover_dim` variables
     uint32_t prover_dim = 0;
-    hipStream_t side = nullptr;  // sc_gkr_prove: f2(u) and the f3 scaling run beside the phase-two initialisation
+    hipStream_t side = nullptr;  // sc_gkr_prove: phase two's bucket plan (indices only) runs beside phase one
+    unsigned int *h_pin = nullptr; // ... and leaves its verdict in this pinned word
 };
 static GkrCache g_cache;
 static thread_local bool t_holds_cache = false;
@@ -531,6 +583,8 @@ extern "C" int sc_release_caches(void) {
     g_cache.prover = nullptr;
     if (g_cache.arena) (void)hipFree(g_cache.arena);
     if (g_cache.side) (void)hipStreamDestroy(g_cache.side);
+    if (g_cache.h_pin) (void)hipHostFree(g_cache.h_pin);
+    g_cache.h_pin = nullptr;
     g_cache.side = nullptr;
     g_cache.arena = nullptr;
     g_cache.cap = 0;
@@ -572,12 +626,12 @@ int build_eq_table(DevBuf &mem, const sch::Fr *point, uint32_t k, Fr *eq, hipStr
     for (uint32_t i = 0; i < k; ++i) P.g[i] = hostfr(point[i]);
     const int kl = (int)std::min<uint32_t>(k, kEqHalfMax), kh = (int)k - kl;
     if (kh == 0) {
-        hipLaunchKernelGGL(k_eq_halves, dim3(1), dim3(kEqBlock), 0, s, eq, (Fr *)nullptr, P, kl, 0);
+        hipLaunchKernelGGL(k_eq_halves, dim3(kEqSlices, 1), dim3(kEqBlock), 0, s, eq, (Fr *)nullptr, P, kl, 0);
     } else {
         Fr *lo = nullptr, *hi = nullptr;
         G_TRY(mem.alloc(&lo, (size_t)1 << kl));
         G_TRY(mem.alloc(&hi, (size_t)1 << kh));
-        hipLaunchKernelGGL(k_eq_halves, dim3(2), dim3(kEqBlock), 0, s, lo, hi, P, kl, kh);
+        hipLaunchKernelGGL(k_eq_halves, dim3(kEqSlices, 2), dim3(kEqBlock), 0, s, lo, hi, P, kl, kh);
         hipLaunchKernelGGL(k_eq_outer, dim3(grid_for(1ULL << k)), dim3(kBlock), 0, s, lo, hi, kl, 1ULL << k, eq);
     }
     G_TRY(hipGetLastError());
@@ -625,6 +679,7 @@ int sparse_fix(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_t n,
 // initialize_phase_one on the device (inputs sorted by index).  Outputs: d_hg (2^dim), f1_g list + count.
 int phase_one_device(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_t nnz, uint32_t dim, const Fr *d_f3, const sch::Fr *g,
                      Fr *d_hg, uint64_t *d_f1g_idx, Fr *d_f1g_vals, unsigned int *d_n1, uint64_t *h_n1, hipStream_t s) {
+    scd::plan_hit(scd::kPlanGkrListForm);
     int rc = sparse_fix(mem, d_idx, d_vals, nnz, g, dim, d_f1g_idx, d_f1g_vals, d_n1, s); // mod.rs:31
     if (rc) return rc;
     unsigned int n1 = 0;
@@ -668,6 +723,7 @@ int phase_one_device(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint6
 // initialize_phase_two on the device: dense 2^dim table of f1(g,u,.)
 int phase_two_device(DevBuf &mem, const uint64_t *d_f1g_idx, const Fr *d_f1g_vals, uint64_t n1, uint32_t dim, const sch::Fr *u, Fr *d_out,
                      hipStream_t s) {
+    scd::plan_hit(scd::kPlanGkrListForm);
     const uint64_t N = 1ULL << dim;
     G_TRY(hipMemsetAsync(d_out, 0, N * 32, s));
     if (n1 == 0) return SC_OK;
@@ -748,7 +804,7 @@ int build_eq_split(DevBuf &mem, const sch::Fr *point, uint32_t dim, EqSplit *out
     Fr *lo = nullptr, *hi = nullptr;
     G_TRY(mem.alloc(&lo, (size_t)1 << kl));
     if (kh > 0) G_TRY(mem.alloc(&hi, (size_t)1 << kh));
-    hipLaunchKernelGGL(k_eq_halves, dim3(kh > 0 ? 2 : 1), dim3(kEqBlock), 0, s, lo, hi, P, kl, kh);
+    hipLaunchKernelGGL(k_eq_halves, dim3(kEqSlices, kh > 0 ? 2 : 1), dim3(kEqBlock), 0, s, lo, hi, P, kl, kh);
     G_TRY(hipGetLastError());
     out->lo = lo;
     out->hi = hi;
@@ -756,80 +812,93 @@ int build_eq_split(DevBuf &mem, const sch::Fr *point, uint32_t dim, EqSplit *out
     return SC_OK;
 }
 
-// Phase two's bucket offsets of an index-ordered list depend on the indices only: sc_gkr_prove computes them on its second stream
-// while phase one runs.  Same bucket shape as bucketed_dense<2>.
-int bucket_bounds_phase_two(DevBuf &mem, const uint64_t *d_idx, uint64_t n, uint32_t dim, uint64_t **start_out, hipStream_t st) {
-    const uint32_t c = (uint32_t)std::max<int>((int)dim - 11, 0);
-    const uint64_t nb = 1ULL << (dim - c);
-    uint64_t *start = nullptr;
-    G_TRY(mem.alloc(&start, nb + 1));
-    hipLaunchKernelGGL(k_bucket_bounds, dim3(grid_for(n + 1)), dim3(kBlock), 0, st, d_idx, n, 2 * dim + c, (uint32_t)(nb - 1), start);
-    G_TRY(hipGetLastError());
-    *start_out = start;
-    return SC_OK;
-}
-
 // 2^dim cells are worth a pass of their own when the list is not much sparser than the table (and the eq tables fit EqPoint).
-// SC_GKR_DIRECT=0 switches the bucketed form off (tests of the list form).
+// sc_set_policy("gkr_direct", 0) switches the bucketed form off (tests of the list form).
 bool bucketed_form_pays(uint64_t nnz, uint32_t dim) {
-    static const bool on = !(std::getenv("SC_GKR_DIRECT") && std::atoi(std::getenv("SC_GKR_DIRECT")) == 0);
-    return on && nnz > 0 && dim <= (uint32_t)kEqMaxVars && (1ULL << dim) <= 8 * nnz + 1024;
+    return scd::policy(scd::kPolGkrDirect) != 0 && nnz > 0 && dim <= (uint32_t)kEqMaxVars && (1ULL << dim) <= 8 * nnz + 1024;
 }
 
-// One of the two dense tables of sc_gkr_prove through the bucketed kernels.  *done = false: some bucket is too crowded for one
-// workgroup (a pathological index distribution) and `dense` is unfinished -- the caller takes the list form instead.
-template <int kPhase>
-int bucketed_dense(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_t n, uint32_t dim, const EqSplit &eg, const EqSplit &eu, const Fr *d_f3,
-                   bool idx_sorted, Fr *dense, bool *done, hipStream_t s, const std::function<int()> *before_sync = nullptr,
-                   const uint64_t *grouped_start = nullptr) {
-    // 2^c cells per bucket, at most kMaxBuckets buckets: dim 20 -> 2048 buckets of 512 cells (32 KB of lanes, four workgroups per CU)
-    const uint32_t c = (uint32_t)std::max<int>((int)dim - 11, 0);
-    if (c > 10) return sc_internal_fail(SC_ERR_BAD_ARG, "dim %u is outside the bucketed form", dim);
-    if (n >= (1ULL << 32)) { // (positions and per-block counts are 32-bit here: the list form takes such a list)
-        *done = false;
-        return SC_OK;
-    }
-    const uint64_t nb = 1ULL << (dim - c);
-    const uint32_t shift = cell_shift_of<kPhase>(dim) + c, nb_mask = (uint32_t)(nb - 1);
+// One of the two dense tables of sc_gkr_prove through the bucketed kernels, in two steps.
+//   bucket_plan  what depends on the INDICES only: the bucket offsets (a grouped list: k_bucket_bounds; else the counting sort's histogram,
+//                column scan and prefix) and whether any bucket is too crowded for one workgroup (k_bucket_skew -> *h_skew once `st` has
+//                been synchronised).  Phase two's plan needs no challenge: sc_gkr_prove runs it beside phase one, on its second stream.
+//   bucket_fill  what depends on the points: the terms (k_bucket_scatter for an ungrouped list) and the cells' sums (k_bucket_accumulate):
+//                one or two launches, no host synchronisation -- the caller chains whatever comes next on the same stream.
+// A skewed plan (a pathological index distribution) leaves `dense` unfinished: the caller takes the list form instead.
+struct BucketPlan {
+    uint32_t c = 0, n_blocks = 0;
+    uint64_t nb = 0, chunk = 0, max_entries = 0;
     uint64_t *start = nullptr;
-    G_TRY(mem.alloc(&start, nb + 1));
+    uint32_t *counts = nullptr;
     Fr *terms = nullptr;
     uint16_t *cells = nullptr;
-    if (kPhase != 1 && idx_sorted && grouped_start) { // (bucket_bounds_phase_two ran earlier)
-        start = const_cast<uint64_t *>(grouped_start);
-    } else if (kPhase != 1 && idx_sorted) { // index order is y-major: already grouped
-        hipLaunchKernelGGL(k_bucket_bounds, dim3(grid_for(n + 1)), dim3(kBlock), 0, s, d_idx, n, shift, nb_mask, start);
+    unsigned int *d_skew = nullptr;
+    unsigned int *h_skew = nullptr; // the caller's word (pinned memory if the copy must not block the host); valid once the plan's stream has been synchronised
+    bool grouped = false, ok = false; // ok = false: outside the bucketed form (the list form takes the list)
+};
+__global__ __launch_bounds__(kBlock) void k_bucket_skew(const uint64_t *__restrict__ start, const uint64_t nb, const uint64_t max_entries, unsigned int *__restrict__ skewed) {
+    const uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (b < nb && start[b + 1] - start[b] > max_entries) atomicOr(skewed, 1u);
+}
+template <int kPhase>
+int bucket_plan(DevBuf &mem, const uint64_t *d_idx, uint64_t n, uint32_t dim, bool idx_sorted, BucketPlan *P, unsigned int *h_skew, hipStream_t st) {
+    P->h_skew = h_skew;
+    *h_skew = 0;
+    // 2^c cells per bucket, at most kMaxBuckets buckets: dim 20 -> 2048 buckets of 512 cells (32 KB of lanes, four workgroups per CU)
+    P->c = (uint32_t)std::max<int>((int)dim - 11, 0);
+    if (P->c > 10) return sc_internal_fail(SC_ERR_BAD_ARG, "dim %u is outside the bucketed form", dim);
+    P->ok = n < (1ULL << 32); // (positions and per-block counts are 32-bit here: the list form takes a longer list)
+    if (!P->ok) return SC_OK;
+    P->nb = 1ULL << (dim - P->c);
+    P->max_entries = std::max<uint64_t>(8192, 64 * (n / P->nb + 1));
+    const uint32_t shift = cell_shift_of<kPhase>(dim) + P->c, nb_mask = (uint32_t)(P->nb - 1);
+    G_TRY(mem.alloc(&P->start, P->nb + 1));
+    G_TRY(mem.alloc(&P->d_skew, 1));
+    G_TRY(hipMemsetAsync(P->d_skew, 0, sizeof(unsigned int), st));
+    P->grouped = kPhase != 1 && idx_sorted; // index order is y-major: already grouped by phase two's cells
+    scd::plan_hit(P->grouped ? scd::kPlanGkrBucketedGrouped : scd::kPlanGkrBucketedCounted);
+    if (P->grouped) {
+        hipLaunchKernelGGL(k_bucket_bounds, dim3(grid_for(n + 1)), dim3(kBlock), 0, st, d_idx, n, shift, nb_mask, P->start);
     } else {
-        const uint32_t n_blocks = (uint32_t)std::min<uint64_t>(256, (n + 4095) / 4096); // (one 1024-thread block per CU at 2^20 non-zeros)
-        const uint64_t chunk = (n + n_blocks - 1) / n_blocks;
-        uint32_t *counts = nullptr;
+        P->n_blocks = (uint32_t)std::min<uint64_t>(256, (n + 4095) / 4096); // (one 1024-thread block per CU at 2^20 non-zeros)
+        P->chunk = (n + P->n_blocks - 1) / P->n_blocks;
         uint64_t *total = nullptr;
-        G_TRY(mem.alloc(&counts, (size_t)n_blocks * nb));
-        G_TRY(mem.alloc(&total, nb));
-        G_TRY(mem.alloc(&terms, n));
-        G_TRY(mem.alloc(&cells, n));
-        hipLaunchKernelGGL(k_bucket_count, dim3(n_blocks), dim3(kSortBlock), 0, s, d_idx, n, chunk, shift, nb_mask, counts);
-        hipLaunchKernelGGL(k_bucket_colscan, dim3((unsigned)((nb + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, counts, n_blocks, (uint32_t)nb, total);
-        hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(kMaxBuckets / 2), 0, s, total, (uint32_t)nb, start);
-        hipLaunchKernelGGL((k_bucket_scatter<kPhase>), dim3(n_blocks), dim3(kSortBlock), 0, s, d_idx, d_vals, n, chunk, dim, c, eg, eu, d_f3, counts, start, terms,
-                           cells);
+        G_TRY(mem.alloc(&P->counts, (size_t)P->n_blocks * P->nb));
+        G_TRY(mem.alloc(&total, P->nb));
+        G_TRY(mem.alloc(&P->terms, n));
+        G_TRY(mem.alloc(&P->cells, n));
+        hipLaunchKernelGGL(k_bucket_count, dim3(P->n_blocks), dim3(kSortBlock), 0, st, d_idx, n, P->chunk, shift, nb_mask, P->counts);
+        hipLaunchKernelGGL(k_bucket_colscan, dim3((unsigned)((P->nb + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, P->counts, P->n_blocks, (uint32_t)P->nb, total);
+        hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(kMaxBuckets / 2), 0, st, total, (uint32_t)P->nb, P->start);
     }
+    hipLaunchKernelGGL(k_bucket_skew, dim3((unsigned)((P->nb + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, P->start, P->nb, P->max_entries, P->d_skew);
     G_TRY(hipGetLastError());
-    unsigned int *d_skew = nullptr, h_skew = 0;
-    G_TRY(mem.alloc(&d_skew, 1));
-    G_TRY(hipMemsetAsync(d_skew, 0, sizeof(unsigned int), s));
-    const size_t lds = ((size_t)8 << c) * sizeof(uint64_t);
-    const uint64_t max_entries = std::max<uint64_t>(8192, 64 * (n / nb + 1));
-    hipLaunchKernelGGL((k_bucket_accumulate<kPhase>), dim3((unsigned)nb), dim3(kBlock), lds, s, terms, cells, d_idx, d_vals, dim, c, eg, eu, d_f3, start,
-                       max_entries, d_skew, dense);
+    G_TRY(hipMemcpyAsync(P->h_skew, P->d_skew, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    return SC_OK;
+}
+template <int kPhase>
+int bucket_fill(const BucketPlan &P, const uint64_t *d_idx, const Fr *d_vals, uint64_t n, uint32_t dim, const EqSplit &eg, const EqSplit &eu, const Fr *d_f3,
+                Fr *dense, hipStream_t st, Fr *out_a = nullptr) {
+    if (!P.grouped)
+        hipLaunchKernelGGL((k_bucket_scatter<kPhase>), dim3(P.n_blocks), dim3(kSortBlock), 0, st, d_idx, d_vals, n, P.chunk, dim, P.c, eg, eu, d_f3, P.counts, P.start,
+                           P.terms, P.cells, out_a);
+    const size_t lds = ((size_t)8 << P.c) * sizeof(uint64_t);
+    hipLaunchKernelGGL((k_bucket_accumulate<kPhase>), dim3((unsigned)P.nb), dim3(kBlock), lds, st, P.terms, P.cells, d_idx, d_vals, dim, P.c, eg, eu, d_f3, P.start,
+                       P.max_entries, P.d_skew, dense);
     G_TRY(hipGetLastError());
-    G_TRY(hipMemcpyAsync(&h_skew, d_skew, sizeof(h_skew), hipMemcpyDeviceToHost, s));
-    if (before_sync) { // the caller's independent launches go out while these kernels run
-        int rc_b = (*before_sync)();
-        if (rc_b) return rc_b;
-    }
-    G_TRY(hipStreamSynchronize(s));
-    *done = h_skew == 0;
+    return SC_OK;
+}
+// plan + fill + one synchronisation (the stand-alone initialisations, and phase one of sc_gkr_prove).  *done = false: the list form must take over.
+template <int kPhase>
+int bucketed_dense(DevBuf &mem, const uint64_t *d_idx, const Fr *d_vals, uint64_t n, uint32_t dim, const EqSplit &eg, const EqSplit &eu, const Fr *d_f3,
+                   bool idx_sorted, Fr *dense, bool *done, hipStream_t s, Fr *out_a = nullptr) {
+    BucketPlan P;
+    unsigned int h_skew = 0;
+    int rc = bucket_plan<kPhase>(mem, d_idx, n, dim, idx_sorted, &P, &h_skew, s);
+    if (rc == SC_OK && P.ok) rc = bucket_fill<kPhase>(P, d_idx, d_vals, n, dim, eg, eu, d_f3, dense, s, out_a);
+    G_TRY(hipStreamSynchronize(s)); // (also on the error path: the copy into h_skew must not outlive it)
+    if (rc) return rc;
+    *done = P.ok && h_skew == 0;
     return SC_OK;
 }
 
@@ -1159,7 +1228,7 @@ extern "C" int sc_sparse_evaluate(const uint64_t *idx, const uint64_t *vals, uin
 // of prove_round / feed / sample (mod.rs:111-119,126-133).  The handle (stream, ping-pong buffers, pinned result page) is
 // created for phase one and rewound onto phase two's tables, so the second phase allocates nothing.
 static int run_phase(sch::Blake2b512Rng &rng, sc_prover **handle, const Fr *dA, const Fr *dB, uint32_t dim, uint64_t *out_msgs,
-                     sch::Fr *challenges) {
+                     sch::Fr *challenges, const std::function<int(sc_prover *)> *after_reset = nullptr) {
     const uint64_t *tabs[2] = {reinterpret_cast<const uint64_t *>(dA), reinterpret_cast<const uint64_t *>(dB)};
     int rc;
     if (*handle == nullptr) {
@@ -1180,6 +1249,7 @@ static int run_phase(sch::Blake2b512Rng &rng, sc_prover **handle, const Fr *dA, 
         rc = sc_prover_reset(*handle, tabs, SC_TABLES_ON_DEVICE);
     }
     if (rc) return rc;
+    if (after_reset && (rc = (*after_reset)(*handle))) return rc; // (phase two: the coefficient f2(u), on the handle's stream)
     return sc_internal_run_rounds(*handle, rng, dim, out_msgs, challenges); // prove_round / feed / sample x dim (late rounds pipelined)
 }
 
@@ -1198,6 +1268,7 @@ extern "C" int sc_gkr_prove_sharded(sc_comm *comm, sc_rng *rng, const uint64_t *
     if (rc) return rc;
     if ((rc = check_points(g, dim, "g"))) return rc;
     const uint32_t G = (uint32_t)sc_internal_comm_ranks(comm), rank = (uint32_t)sc_internal_comm_rank(comm);
+    scd::plan_hit(scd::kPlanGkrSharded);
     uint32_t k = 0;
     while ((1u << k) < G) ++k;
     if ((1u << k) != G || dim <= k) return sc_internal_fail(SC_ERR_BAD_ARG, "the number of ranks must be a power of two below 2^dim");
@@ -1330,7 +1401,7 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     const uint64_t *d_idx = nullptr;
     const Fr *d_vals = nullptr, *d_f2 = nullptr, *d_f3 = nullptr;
     uint64_t *d_idx_s = nullptr, *d_gi = nullptr;
-    Fr *d_vals_s = nullptr, *d_hg = nullptr, *d_gv = nullptr, *d_f1gu = nullptr, *d_f3s = nullptr, *d_tmp = nullptr;
+    Fr *d_vals_s = nullptr, *d_hg = nullptr, *d_gv = nullptr, *d_f1gu = nullptr, *d_a = nullptr;
     unsigned int *d_n1 = nullptr;
     G_TRY(mem.alloc(&d_idx_s, nnz));
     G_TRY(mem.alloc(&d_vals_s, nnz));
@@ -1338,8 +1409,6 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     G_TRY(mem.alloc(&d_gi, nnz));
     G_TRY(mem.alloc(&d_gv, nnz));
     G_TRY(mem.alloc(&d_f1gu, N));
-    G_TRY(mem.alloc(&d_f3s, N));
-    G_TRY(mem.alloc(&d_tmp, (N >> 3) + 1));
     G_TRY(mem.alloc(&d_n1, 1));
     lap("alloc");
     if ((rc = stage_in(mem, f1_idx, nnz, dev, &d_idx, s)) || (rc = stage_in(mem, f1_vals, nnz, dev, &d_vals, s)) ||
@@ -1351,16 +1420,25 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     if (!dev) G_TRY(hipStreamSynchronize(s));
     lap("h2d");
     // Bucketed initialisation (k_bucket_accumulate) whenever the list is dense enough for 2^dim cells to be worth a pass; the list form (sort, merge, scatter:
-    // what sc_gkr_phase_one returns to a caller) otherwise, and when a bucket is too crowded.  SC_GKR_DIRECT=0 forces the list form.
+    // what sc_gkr_phase_one returns to a caller) otherwise, and when a bucket is too crowded.  sc_set_policy("gkr_direct", 0) forces the list form.
     bool direct = bucketed_form_pays(nnz, dim);
     hipStream_t side = s;
+    unsigned int skew2_local = 0, *h_skew2 = &skew2_local;
     if (mem.leased) {
         if (!g_cache.side && hipStreamCreateWithFlags(&g_cache.side, hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();
             g_cache.side = nullptr;
         }
-        if (g_cache.side) side = g_cache.side;
+        if (g_cache.side && !g_cache.h_pin && hipHostMalloc(reinterpret_cast<void **>(&g_cache.h_pin), 64, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            g_cache.h_pin = nullptr;
+        }
+        if (g_cache.side && g_cache.h_pin) { // (a copy into pinned memory does not hold the host: the plan below runs beside phase one)
+            side = g_cache.side;
+            h_skew2 = g_cache.h_pin;
+        }
     }
+    BucketPlan plan2; // (declared before `join`: the second stream's copy into *h_skew2 is over before either goes away)
     struct StreamJoin { // no return path leaves work behind on the second stream (it reads and writes this call's scratch)
         hipStream_t st;
         ~StreamJoin() {
@@ -1370,11 +1448,14 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     EqSplit eq_g{nullptr, nullptr, 0}, eq_u{nullptr, nullptr, 0};
     uint64_t n1 = 0;
     bool have_list = false; // f1(g,.,.) as a merged list in d_gi / d_gv (list form only)
-    uint64_t *start2 = nullptr;
-    if (direct && f1_sorted && side != s && (rc = bucket_bounds_phase_two(mem, d_idx, nnz, dim, &start2, side))) return rc;
+    // Phase two's bucket plan depends on the indices only: it runs now, on the second stream, while phase one has the device (a call without
+    // the cache's stream runs it in line; phase one's synchronisation below covers it then).
+    if (direct && (rc = bucket_plan<2>(mem, d_idx, nnz, dim, f1_sorted, &plan2, h_skew2, side))) return rc;
     if (direct) {
         if ((rc = build_eq_split(mem, reinterpret_cast<const sch::Fr *>(g), dim, &eq_g, s))) return rc;
-        if ((rc = bucketed_dense<1>(mem, d_idx, d_vals, nnz, dim, eq_g, eq_u, d_f3, f1_sorted, d_hg, &direct, s))) return rc; // mod.rs:30-38
+        // (the pass leaves eq(g,z) * v behind, per non-zero, in d_gv -- the list form's value buffer, unused on this route: phase two's input)
+        d_a = d_gv;
+        if ((rc = bucketed_dense<1>(mem, d_idx, d_vals, nnz, dim, eq_g, eq_u, d_f3, f1_sorted, d_hg, &direct, s, d_a))) return rc; // mod.rs:30-38
     }
     auto list_form = [&]() -> int {
         int r = sort_sparse(mem, d_idx, d_vals, nnz, 3 * dim, d_idx_s, d_vals_s, s);
@@ -1391,42 +1472,23 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     pg.take_cached(dim, mem.leased);
     if ((rc = run_phase(rng->rng, &pg.p, d_hg, d_f2, dim, out_proof, u.data()))) return rc; // mod.rs:107-119
     lap("phase one sumcheck");
-    // f2.evaluate(&u) (mod.rs:122) and the scaling of f3 by it (mod.rs:71-75) depend on u only, like the phase-two initialisation: they run
-    // beside it on a second stream (the cache's; a call that does not hold the cache runs them in line).  All dim variables are bound on the
-    // device, three per pass (8 entries in, 1 out), ping-ponging between two buffers that are free at this point (h_g is spent, d_tmp
-    // holds an eighth of it); the scalar never visits the host.
-    bool f2_enqueued = false;
-    const std::function<int()> enqueue_f2 = [&]() -> int {
-        f2_enqueued = true;
-        const uint4 *cur = reinterpret_cast<const uint4 *>(d_f2);
-        uint4 *pp[2] = {reinterpret_cast<uint4 *>(d_hg), reinterpret_cast<uint4 *>(d_tmp)};
-        uint64_t m = N;
-        uint32_t var = 0;
-        for (int pass = 0; var < dim; ++pass) {
-            const int L = (dim - var) >= 3 ? 3 : (int)(dim - var);
-            m >>= L;
-            scd::FoldArgs fa;
-            std::memset(&fa, 0, sizeof(fa));
-            fa.src[0] = cur;
-            fa.dst[0] = pp[pass & 1];
-            for (int l = 0; l < L; ++l) {
-                sch::Fr r32v = u[var + l]; // r * 2^5 for the 2^261-radix arithmetic of the fold kernel
-                for (int dbl = 0; dbl < 5; ++dbl) r32v = sch::add(r32v, r32v);
-                fa.r32[l] = hostfr(r32v);
-            }
-            G_TRY(scd::launch_fold_multi(fa, L, 1, m, side));
-            cur = pp[pass & 1];
-            var += L;
-        }
-        hipLaunchKernelGGL(k_scale_by, dim3(grid_for(N)), dim3(kBlock), 0, side, d_f3, reinterpret_cast<const Fr *>(cur), N, d_f3s);
-        G_TRY(hipGetLastError());
-        return SC_OK;
-    };
+    // f2.evaluate(&u) (mod.rs:122) is not recomputed: phase one's prover has bound f2 at u_0..u_{dim-2} (prover.rs:84-89), its final table {lo, hi}
+    // gives f2(u) = lo + u_last (hi - lo); and f3 is not multiplied by it (mod.rs:71-75): the scalar becomes phase two's coefficient, on the
+    // device (sc_internal_scale_by_bound_table) -- the messages are the same canonical bits.  start_phase2_sumcheck / sc_dense_scale remain for callers.
+    const void *f2_bound = sc_internal_bound_table(pg.p, 1);
+    if (!f2_bound) return sc_internal_fail(SC_ERR_HIP, "phase one left no bound f2 table");
+    // Phase two's initialisation goes onto the PROVER's stream, behind phase one's last kernel and in front of phase two's first: the eq tables,
+    // [the terms,] the cells' sums, the coefficient -- no host synchronisation in between.
+    const hipStream_t ps = sc_internal_prover_stream(pg.p);
     if (direct) {
-        if (start2) G_TRY(hipStreamSynchronize(side)); // (long finished: it ran beside phase one)
-        if ((rc = build_eq_split(mem, u.data(), dim, &eq_u, s))) return rc;
-        if ((rc = bucketed_dense<2>(mem, d_idx, d_vals, nnz, dim, eq_g, eq_u, d_f3, f1_sorted, d_f1gu, &direct, s, &enqueue_f2, start2))) return rc; // mod.rs:121
-        if (!direct && !have_list) { // (crowded y buckets although the x buckets were fine: build the list now)
+        if (side != s) G_TRY(hipStreamSynchronize(side)); // (the plan: long finished, it ran beside phase one)
+        direct = plan2.ok && *h_skew2 == 0;
+    }
+    if (direct) {
+        if ((rc = build_eq_split(mem, u.data(), dim, &eq_u, ps))) return rc;
+        if ((rc = bucket_fill<4>(plan2, d_idx, d_a, nnz, dim, eq_g, eq_u, d_f3, d_f1gu, ps))) return rc; // mod.rs:121: eq(u,x) * (eq(g,z) * v)
+    } else {
+        if (!have_list) { // (crowded y buckets although the x buckets were fine: build the list now)
             int r = sort_sparse(mem, d_idx, d_vals, nnz, 3 * dim, d_idx_s, d_vals_s, s);
             if (r) return r;
             if ((r = sparse_fix(mem, d_idx_s, d_vals_s, nnz, reinterpret_cast<const sch::Fr *>(g), dim, d_gi, d_gv, d_n1, s))) return r;
@@ -1436,13 +1498,19 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
             n1 = h_n1;
             have_list = true;
         }
+        if ((rc = phase_two_device(mem, d_gi, d_gv, n1, dim, u.data(), d_f1gu, s))) return rc; // mod.rs:121
+        G_TRY(hipStreamSynchronize(s)); // (the prover's stream is not ordered behind `s`)
     }
-    if (!f2_enqueued && (rc = enqueue_f2())) return rc;
-    if (!direct && (rc = phase_two_device(mem, d_gi, d_gv, n1, dim, u.data(), d_f1gu, s))) return rc; // mod.rs:121
-    G_TRY(hipStreamSynchronize(s));
-    if (side != s) G_TRY(hipStreamSynchronize(side));
-    lap("phase two init, f2(u), scale f3");
-    if ((rc = run_phase(rng->rng, &pg.p, d_f1gu, d_f3s, dim, out_proof + (size_t)dim * 12, v.data()))) return rc; // mod.rs:122-133
+    if (trace) {
+        G_TRY(hipStreamSynchronize(ps));
+        lap("phase two init");
+    }
+    const sch::Fr u_last = u[dim - 1];
+    const std::function<int(sc_prover *)> coeff = [&](sc_prover *hp) -> int {
+        scd::plan_hit(scd::kPlanGkrCoeffFromBound);
+        return sc_internal_scale_by_bound_table(hp, f2_bound, u_last);
+    };
+    if ((rc = run_phase(rng->rng, &pg.p, d_f1gu, d_f3, dim, out_proof + (size_t)dim * 12, v.data(), &coeff))) return rc; // mod.rs:122-133
     lap("phase two sumcheck");
     if (out_uv_or_null) {
         std::memcpy(out_uv_or_null, u.data(), (size_t)dim * 32);

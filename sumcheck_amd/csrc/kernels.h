@@ -91,6 +91,9 @@ struct RoundArgs {
     TreeProd prod[kMaxRoundProds];
     int n_prod;
     RoundFin fin;
+    // k_round1_tree_split only: this launch fills blocks [part_block0, part_block0 + gridDim.x) of node rows that are part_stride blocks long
+    // (a staged sc_prover_init runs round 1 chunk by chunk under the host-to-device copy, one finalize over all of it); 0 / 0: the whole rows
+    uint32_t part_stride, part_block0;
 };
 
 // static per-product record for the finalize kernel (device memory)
@@ -206,10 +209,79 @@ struct TailSlicesArgs {
     uint32_t stage_off;
 };
 // blocks for a tail that starts with `first_pairs` pairs, or 0 when the slices do not fit LDS (the caller then takes k_tail_rounds)
-int tail_slices_blocks(uint64_t first_pairs, int n_tables, int K, int D, int n_combos, int max_multiplicands);
+// max_blocks: how many blocks of the kernel the DEVICE holds at once (tail_slices_max_blocks): the blocks wait for each other, so a grid that is
+// not co-resident (a CPX / DPX partition, masked CUs) would stall until its waits expire -- fewer, larger slices then, or 0 if those do not fit
+int tail_slices_blocks(uint64_t first_pairs, int n_tables, int K, int D, int n_combos, int max_multiplicands, int max_blocks);
+int tail_slices_max_blocks(int device, int max_multiplicands); // occupancy of k_tail_slices<.> at its LDS limit x the device's CUs (0: unknown)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, DEVICE): thread ranks of one process drive several GPUs
+hipError_t ensure_dynamic_lds(const void *kernel, int bytes, bool (&done)[64]);
 hipError_t launch_tail_slices(TailSlicesArgs args, const ComboMeta &meta, const FinMeta &fin, int max_multiplicands, hipStream_t stream);
 int tail_max_resident_blocks(int device); // co-resident blocks of the tail kernel (0: unknown -> the tail kernel is not used)
-uint32_t wait_spins_default(); // bound of the device-side polls for a challenge (SC_WAIT_SPINS overrides it: tests)
+uint32_t wait_spins_default(); // bound of the device-side polls for a challenge (sc_set_policy("wait_spins", n) overrides it: tests)
+
+// ---- library policy: sc_set_policy / sc_get_policy (abi.hip).  Process-wide integers, read where a path is chosen; the shipped library
+// reads no environment variable for any of them (the -DSC_EXPERIMENTS build takes their initial values from SC_<KEY> in the environment).
+enum PolicyKey {
+    kPolPipeline = 0,     // "pipeline"           1: device-side waits allowed (persistent tail kernel, pipelined launches); 0: every round launched after its challenge
+    kPolResident,         // "resident"           1: the interactive sc_prove_round may keep a kernel on the GPU between calls
+    kPolTailSlices,       // "tail_slices"        1: latency-bound rounds out of LDS (k_tail_slices) where the shape fits; 0: k_tail_rounds / launches
+    kPolVramMailbox,      // "vram_mailbox"       1: challenges into device memory over the BAR where the host can store there
+    kPolWideTree,         // "wide_tree"          1: products of 5..12 multiplicands as trees (kernels_wide*.hip); 0: node by node
+    kPolRcclDirect,       // "rccl_direct"        1: an RCCL round's lanes land in the host-mapped page (if the probe agrees on every rank); 0: publish kernel
+    kPolShardGatherLog2,  // "shard_gather_log2"  log2 entries per table and rank region at which a sharded proof gathers (1..15, default 15)
+    kPolGkrDirect,        // "gkr_direct"         1: sc_gkr_prove initialises through the bucketed kernels; 0: sort + merge (the list form)
+    kPolWaitSpins,        // "wait_spins"         bound of a device-side wait for a challenge, in polls (default 2^22)
+    kPolTail,             // "tail"               1: the persistent tail kernels; 0: latency-bound rounds as pipelined launches (what sharded RCCL rounds use)
+    kPolStagedInit,       // "staged_init"        1: sc_prover_init over HOST tables copies them in chunks and computes round 1 under the copy (shapes of the merged big-round kernel, >= 2^18 entries)
+    kPolCount
+};
+int64_t policy(int key);
+
+// ---- launch-plan counters: sc_plan_stats / sc_plan_name (abi.hip).  One counter per path the host side can choose for a round (or an
+// initialisation); bumped where the choice is made.  tests/conftest.py accumulates them over the GPU suite per test and
+// tests/test_zz_plan_coverage.py asserts that every plan was reached by a test that also computed the oracle's answer.
+enum Plan {
+    kPlanBigMergedRound1 = 0, // k_round1_tree_split: all products, one launch, no bind
+    kPlanBigMergedBindChain,  // k_round_tree_split<chain>: round 2 (sources canonical)
+    kPlanBigMergedBind,       // k_round_tree_split: rounds >= 3 (sources F29 or canonical)
+    kPlanBigClaimIdentity,    // ... with node 1 from the claim identity (kSkip1)
+    kPlanBigF29Store,         // a big binding round stored its tables in the internal F29 format
+    kPlanBigCanonicalStore,   // ... in the reference layout (lists that keep canonical tables)
+    kPlanBigPerProductTree,   // k_prod_tree<M <= 4>: one launch per product (more products than a merged launch takes)
+    kPlanBigWide,             // k_prod_tree_wide<5..8>
+    kPlanBigWide16,           // k_prod_tree_wide16<9..12>
+    kPlanBigGeneric,          // k_sum_generic (13 and more, or wide_tree = 0 beyond 8)
+    kPlanBigNodeByNode,       // k_prod_round_fe (wide_tree = 0, 5..8)
+    kPlanBigBindPass,         // k_fix_multi up front (lists with products beyond kMaxFusedM)
+    kPlanBigStreamed,         // rounds 1-2 of a streamed handle, chunk by chunk
+    kPlanBigStagedRound1,     // round 1 computed inside sc_prover_init / sc_prover_reset, chunk by chunk under the host-to-device copy
+    kPlanFinalizeMultiBlock,  // k_finalize_mb
+    kPlanFinalizeOneBlock,    // k_finalize (more products than a launch's arguments describe: metadata from device memory)
+    kPlanFinalizeNoLds,       // k_finalize without LDS staging (node sums beyond 48 KB)
+    kPlanSmallLaunched,       // k_fix_multi + k_sum_combos_meta after the challenge
+    kPlanSmallCombosTable,    // ... k_sum_combos (combination metadata from device memory)
+    kPlanSmallPtrs,           // ... k_sum_combos_ptrs (more than 32 tables)
+    kPlanSmallPipelined,      // a latency-bound round enqueued behind k_wait_challenge
+    kPlanTailSlices8,         // k_tail_slices<8>
+    kPlanTailSlices12,        // k_tail_slices<12>
+    kPlanTailRounds,          // k_tail_rounds
+    kPlanResidentSlices,      // the interactive protocol's resident kernel: k_tail_slices
+    kPlanResidentRounds,      // ... k_tail_rounds
+    kPlanShardedRcclDirect,   // sharded rounds: ncclAllReduce into the host-mapped page
+    kPlanShardedRcclPublish,  // ... all-reduce + publish kernel
+    kPlanShardedHost,         // ... the caller's host transport
+    kPlanShardedP2P,          // ... k_p2p_allreduce
+    kPlanShardedGatherTail,   // bind + all-gather + replicated tail
+    kPlanGkrBucketedGrouped,  // GKR initialisation: buckets of an index-ordered list (k_bucket_bounds)
+    kPlanGkrBucketedCounted,  // ... counting sort into buckets
+    kPlanGkrListForm,         // ... sort + merge + scatter
+    kPlanGkrCoeffFromBound,   // phase two's coefficient f2(u) from phase one's bound table
+    kPlanGkrSharded,          // sc_gkr_prove_sharded
+    kPlanFoldMulti,           // sc_poly_evaluate / sc_fix_variables (k_fold_multi)
+    kPlanCount
+};
+void plan_hit(int plan);
+hipError_t launch_scale_w_by_table_eval(FrHost *W, const FrHost *W0, uint32_t n, const void *table, const FrHost &r, hipStream_t stream); // W = W0 * table(r)
 hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream); // (a plain kernel: hipMemsetAsync may take runtime paths that wait on other streams)
 hipError_t launch_tail_rounds(const TailArgs &args, const ComboMeta &meta, const FinMeta &fin, int grid, hipStream_t stream);
 
@@ -294,6 +366,7 @@ hipError_t launch_finalize(const FinProd *d_prods, const FinProd *h_prods_or_nul
 // and leaves the word at zero)
 hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint64_t n, uint4 *d_out, hipStream_t stream);
 hipError_t launch_scale(const uint4 *src, uint4 *dst, const FrHost &s, uint64_t n, hipStream_t stream);
+hipError_t launch_tag_words(uint64_t *d_words, int n, uint32_t gen, hipStream_t stream); // words |= wide_tag_of(gen) << kWideTagShift
 hipError_t launch_publish_words(const uint64_t *d_src, uint64_t *h_dst_mapped, int n, uint32_t *h_flag_mapped, uint32_t seq, hipStream_t stream);
 // recv[g][u][e] -> tabs[u][g * per + e] (elements of 32 bytes): the all-gathered remainders of G shards become U tables of G * per entries
 // Peer-to-peer all-reduce of a round's lanes (sc_comm_init_p2p): rank r PUSHES its n_words lanes into every peer's inbox (posted

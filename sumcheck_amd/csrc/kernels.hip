@@ -120,6 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_fold_multi(const FoldArgs A, const u
 }
 
 hipError_t launch_fold_multi(const FoldArgs &args, int levels, int n_tables, uint64_t n_out, hipStream_t stream) {
+    plan_hit(kPlanFoldMulti);
     const dim3 grid(grid_for_pairs(n_out), n_tables);
     switch (levels) {
     case 1: hipLaunchKernelGGL(k_fold_multi<1>, grid, dim3(kBlock), 0, stream, args, n_out); break;
@@ -164,13 +165,7 @@ __global__ void k_wait_challenge(uint32_t *__restrict__ flag, const uint32_t wan
     __syncthreads();
     if (threadIdx.x < 4) mail_dev[threadIdx.x] = __hip_atomic_load(mail_host + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-uint32_t wait_spins_default() { // SC_WAIT_SPINS: tests shorten the bound to exercise the give-up path
-    static const uint32_t env_spins = [] {
-        const char *e = std::getenv("SC_WAIT_SPINS");
-        return e ? (uint32_t)std::strtoul(e, nullptr, 10) : (1u << 22);
-    }();
-    return env_spins;
-}
+uint32_t wait_spins_default() { return (uint32_t)policy(kPolWaitSpins); } // (tests shorten the bound to exercise the give-up path)
 hipError_t launch_wait_challenge(uint32_t *flag_dev, uint32_t want, const FrHost *mail_host_dev, FrHost *mail_dev, hipStream_t stream,
                                  uint32_t spins_override) {
     const uint32_t max_spins = spins_override ? spins_override : wait_spins_default();
@@ -724,6 +719,24 @@ hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// W[i] = W0[i] * (lo + r (hi - lo)) for a bound two-entry table {lo, hi}: a handle whose polynomial is multiplied by a table's value at the
+// point the rounds fixed (GKR phase two: f2(u) as the product's coefficient, gkr_round_sumcheck/mod.rs:71-75,122) without visiting the host
+__global__ void k_scale_w_by_table_eval(uint4 *__restrict__ W, const uint4 *__restrict__ W0, const uint32_t n, const uint4 *__restrict__ table, const FrU r) {
+    const Fr lo = fr_load(table), hi = fr_load(table + 2);
+    const Fr s = fr_add(lo, fr_mul_u(fr_sub(hi, lo), r));
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) fr_store(W + 2 * (size_t)i, fr_mul(fr_load(W0 + 2 * (size_t)i), s));
+}
+hipError_t launch_scale_w_by_table_eval(FrHost *W, const FrHost *W0, uint32_t n, const void *table, const FrHost &r, hipStream_t stream) {
+    FrU ru;
+    for (int i = 0; i < 4; ++i) {
+        ru.v[2 * i] = (uint32_t)r.l[i];
+        ru.v[2 * i + 1] = (uint32_t)(r.l[i] >> 32);
+    }
+    hipLaunchKernelGGL(k_scale_w_by_table_eval, dim3(1), dim3(64), 0, stream, reinterpret_cast<uint4 *>(W), reinterpret_cast<const uint4 *>(W0), n,
+                       static_cast<const uint4 *>(table), ru);
+    return hipGetLastError();
+}
+
 hipError_t launch_tail_rounds(const TailArgs &args, const ComboMeta &meta, const FinMeta &fin, int grid, hipStream_t stream) {
     const size_t lds = (size_t)args.K * args.D * (args.D + 2) * 32;
     if (lds > kFinLdsMax) return hipErrorInvalidValue;
@@ -899,6 +912,7 @@ hipError_t launch_finalize(const FinProd *d_prods, const FinProd *h_prods_or_nul
     std::memset(&meta, 0, sizeof(meta));
     const bool use_meta = h_prods_or_null && K <= kMetaProds;
     if (use_meta) std::memcpy(meta.prod, h_prods_or_null, (size_t)K * sizeof(FinProd));
+    plan_hit(lds <= kFinLdsMax && use_meta && d_counter_or_null ? kPlanFinalizeMultiBlock : lds <= kFinLdsMax ? kPlanFinalizeOneBlock : kPlanFinalizeNoLds);
     if (lds <= kFinLdsMax && use_meta && d_counter_or_null) {
         int n_valid = 0;
         for (int k = 0; k < K; ++k) n_valid += std::min<int>((int)meta.prod[k].M, D - 1) + 1;
@@ -957,6 +971,15 @@ hipError_t launch_synth(uint64_t seed, uint64_t stream_id, uint64_t first, uint6
     return hipGetLastError();
 }
 
+// OR a generation's tag into a round's lanes (streamed rounds under an RCCL communicator with direct publication: their message is added up
+// over the chunks by k_msg_accumulate, which knows nothing of tags)
+__global__ void k_tag_words(uint64_t *__restrict__ w, const int n, const uint64_t tag) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) w[i] |= tag;
+}
+hipError_t launch_tag_words(uint64_t *d_words, int n, uint32_t gen, hipStream_t stream) {
+    hipLaunchKernelGGL(k_tag_words, dim3(1), dim3(64), 0, stream, d_words, n, (uint64_t)wide_tag_of(gen) << kWideTagShift);
+    return hipGetLastError();
+}
 // copy a few words to host-mapped memory and raise the sequence flag (after an all-reduce on the same stream)
 __global__ void k_publish_words(const uint64_t *__restrict__ src, uint64_t *__restrict__ h_dst, const int n, uint32_t *__restrict__ h_flag,
                                 const uint32_t seq) {

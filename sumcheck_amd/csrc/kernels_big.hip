@@ -175,7 +175,10 @@ __global__ __launch_bounds__(kBlock) void k_prod_round_fe(const ProdArgs A, cons
 // polynomial at the challenge, product by product: ClaimArgs in kernels.h); binding rounds only
 template <int M, bool kR1 = false, bool kChain = kChainDefault, bool kSkip1 = false>
 __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBindLds], const uint64_t n_pairs, uint4 *__restrict__ row, uint32_t (*sm)[8],
-                                          int32_t *lacc) {
+                                          int32_t *lacc, const uint32_t part_stride = 0) {
+    // (part_stride: blocks per node row of the partial sums when this launch fills only a SECTION of them -- round 1 of a staged
+    // sc_prover_init, chunk by chunk under the host-to-device copy; 0: this launch's own grid)
+    const uint64_t pstride = part_stride ? part_stride : gridDim.x;
     // The M+1 running sums live in LDS (limb-planar, one column per thread: lacc[(9 t + limb) * kBlock + tid], conflict-free and
     // private to the thread, so no barrier): 45 VGPRs less for M = 4, one more resident block per CU.
     static_assert(!(kSkip1 && kR1), "round 1 has no previous round to take node 1 from");
@@ -438,7 +441,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
             for (int i = 0; i < 8; ++i) o.v[i] = x[(w * (M + 1) + t) * 8 + i];
             acc = fr_add(acc, o);
         }
-        fr_store(row + 2 * ((uint64_t)t * gridDim.x), acc);
+        fr_store(row + 2 * ((uint64_t)t * pstride), acc);
     }
     __syncthreads(); // (a block that walks several products -- the experiments build's k_round_tree -- reuses the LDS at once)
 #else
@@ -449,7 +452,7 @@ __device__ __forceinline__ void tree_pass(const Slot *S, const int32_t (&r)[kBin
 #pragma unroll
         for (int l = 0; l < 9; ++l) a.l[l] = my[(9 * t + l) * kBlock];
         const Fr s = block_sum(fe_to_fr(a), sm);
-        if (threadIdx.x == 0) fr_store(row + 2 * ((uint64_t)t * gridDim.x), s);
+        if (threadIdx.x == 0) fr_store(row + 2 * ((uint64_t)t * pstride), s);
     }
 #endif
 }
@@ -667,17 +670,17 @@ __global__ __launch_bounds__(kBlock, 3) void k_round1_tree_split(const RoundArgs
     __shared__ int32_t rt[kBindLds]; // (unused: the factor loader's signature)
     __shared__ int32_t lacc[9 * 5 * kBlock];
     const TreeProd &T = R.prod[blockIdx.y];
-    uint4 *row = partials + 2 * (T.partial_off + (uint64_t)blockIdx.x);
+    uint4 *row = partials + 2 * (T.partial_off + (uint64_t)R.part_block0 + (uint64_t)blockIdx.x);
 #ifdef SC_NO_CHAIN_R1 // A/B build
     constexpr bool kC1 = false;
 #else
     constexpr bool kC1 = true;
 #endif
     switch (T.M) {
-    case 1: tree_pass<1, true, kC1>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    case 2: tree_pass<2, true, kC1>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    case 3: tree_pass<3, true, kC1>(T.slot, rt, n_pairs, row, sm, lacc); break;
-    default: tree_pass<4, true, kC1>(T.slot, rt, n_pairs, row, sm, lacc); break;
+    case 1: tree_pass<1, true, kC1>(T.slot, rt, n_pairs, row, sm, lacc, R.part_stride); break;
+    case 2: tree_pass<2, true, kC1>(T.slot, rt, n_pairs, row, sm, lacc, R.part_stride); break;
+    case 3: tree_pass<3, true, kC1>(T.slot, rt, n_pairs, row, sm, lacc, R.part_stride); break;
+    default: tree_pass<4, true, kC1>(T.slot, rt, n_pairs, row, sm, lacc, R.part_stride); break;
     }
 }
 // kChain: single-chain multiply-adds (fe_device.hpp) -- the instantiation for a proof's first binding round, whose sources are canonical.
@@ -810,6 +813,8 @@ hipError_t launch_round_tree(const RoundArgs &args, const BindConst &r32, uint64
         for (uint32_t f = 0; f < args.prod[q].M; ++f) canonical_sources = canonical_sources && args.prod[q].slot[f].src_top == nullptr;
     const dim3 g(grid, args.n_prod), b(kBlock);
     uint4 *const part = (uint4 *)d_partials;
+    plan_hit(round1 ? kPlanBigMergedRound1 : canonical_sources ? kPlanBigMergedBindChain : kPlanBigMergedBind);
+    if (skip1) plan_hit(kPlanBigClaimIdentity);
     if (round1) {
         if (skip1) return hipErrorInvalidValue; // (round 1 has no previous round)
         hipLaunchKernelGGL(k_round1_tree_split, g, b, 0, stream, args, n_pairs, part);

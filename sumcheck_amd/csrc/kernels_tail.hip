@@ -445,7 +445,8 @@ static size_t ts_fin_bytes(int K, int D) { return ((size_t)K * D * (D + 2) * 32 
 static size_t ts_stage_bytes(int n_combos, int B) { return B > 1 ? 8 * (size_t)n_combos * 64 + 8 * (size_t)n_combos * 32 + 16 : 0; }
 constexpr size_t kTsLdsMax = 144 * 1024; // of the CU's 160 KB (one block per CU; its static LDS is ~3 KB)
 
-int tail_slices_blocks(uint64_t first_pairs, int n_tables, int K, int D, int n_combos, int max_multiplicands) {
+int tail_slices_blocks(uint64_t first_pairs, int n_tables, int K, int D, int n_combos, int max_multiplicands, int max_blocks) {
+    if (max_blocks < 1) return 0;
     if (first_pairs == 0 || (first_pairs & (first_pairs - 1)) != 0 || first_pairs > kTsMaxPairs) return 0;
     if (first_pairs > kSmallRoundPairs) {
         // Above the big / small round boundary the fused tree kernels stream the tables at memory speed; a resident block, one wavefront
@@ -460,18 +461,50 @@ int tail_slices_blocks(uint64_t first_pairs, int n_tables, int K, int D, int n_c
     int B = kTsMaxBlocks;
     while (B > 1 && (uint64_t)B > first_pairs / 2) B >>= 1;
     if (first_pairs <= 32) B = 1;
+    while (B > max_blocks) B >>= 1; // (every block must be resident: they hand over to each other)
     const size_t bytes = ts_fin_bytes(K, D) + ts_lds_entries(first_pairs, B) * (size_t)n_tables * (kTsEnt * 4) + ts_stage_bytes(n_combos, B);
     return bytes <= kTsLdsMax ? B : 0; // (more blocks than kTsMaxBlocks would be needed: the caller runs this round as launches and asks again)
 }
 
+hipError_t ensure_dynamic_lds(const void *kernel, int bytes, bool (&done)[64]) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    bool &flag = done[(unsigned)dev & 63u]; // (a benign race: two threads of one device may both set the attribute)
+    if (__atomic_load_n(&flag, __ATOMIC_ACQUIRE)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) __atomic_store_n(&flag, true, __ATOMIC_RELEASE);
+    return e;
+}
+template <int kSlots>
+static hipError_t tail_slices_attr() { // (more dynamic LDS than the default 64 KB limit of a launch)
+    static bool done[64] = {};
+    return ensure_dynamic_lds(reinterpret_cast<const void *>(k_tail_slices<kSlots>), (int)kTsLdsMax, done);
+}
+template <int kSlots>
+static int tail_slices_max_blocks_t(int device) {
+    static int cached[64] = {}; // 0: not asked yet; -1: unknown
+    int &c = cached[(unsigned)device & 63u];
+    if (c != 0) return c > 0 ? c : 0;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (tail_slices_attr<kSlots>() != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail_slices<kSlots>, kTsBlock, kTsLdsMax) != hipSuccess || per_cu < 1 ||
+        hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount < 1) {
+        (void)hipGetLastError();
+        c = -1;
+        return 0;
+    }
+    c = per_cu * prop.multiProcessorCount;
+    return c;
+}
+int tail_slices_max_blocks(int device, int max_multiplicands) {
+    return max_multiplicands > kMaxFusedM ? tail_slices_max_blocks_t<kMaxWideM>(device) : tail_slices_max_blocks_t<kMaxFusedM>(device);
+}
 template <int kSlots>
 static hipError_t launch_tail_slices_t(const TailSlicesArgs &args, const ComboMeta &meta, const FinMeta &fin, size_t lds, hipStream_t stream) {
-    static bool attr_set = false; // (more dynamic LDS than the default 64 KB limit of a launch)
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail_slices<kSlots>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTsLdsMax);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    hipError_t e = tail_slices_attr<kSlots>();
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_tail_slices<kSlots>, dim3(args.B), dim3(kTsBlock), lds, stream, args, meta, fin);
     return hipGetLastError();
 }

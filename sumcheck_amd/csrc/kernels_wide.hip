@@ -89,12 +89,8 @@ __global__ __launch_bounds__(kWideBlock) void k_prod_tree_wide(const ProdArgs P,
 template <int M>
 static hipError_t launch_wide_t(const ProdArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
     const size_t lds = (size_t)9 * (M + 1) * kWideBlock * 4;
-    static bool attr_set = false; // (more dynamic LDS than the default limit of a launch: 55-83 KB of running sums)
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_prod_tree_wide<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static bool attr_set[64] = {}; // (more dynamic LDS than the default limit of a launch: 55-83 KB of running sums); per device
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_prod_tree_wide<M>), (int)lds, attr_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(k_prod_tree_wide<M>, dim3(grid), dim3(kWideBlock), lds, stream, args, rc, n_pairs, (uint4 *)d_partials);
     return hipGetLastError();
 }

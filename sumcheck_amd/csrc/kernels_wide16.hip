@@ -98,12 +98,8 @@ __global__ __launch_bounds__(kWide16Block) void k_prod_tree_wide16(const WideArg
 template <int M>
 static hipError_t launch_wide16_t(const WideArgs16 &args, const FrHost &comp, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
     const size_t lds = (size_t)9 * (M + 1) * kWide16Block * 4;
-    static bool attr_set = false; // (dynamic LDS near the default limit of a launch)
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_prod_tree_wide16<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static bool attr_set[64] = {}; // (dynamic LDS near the default limit of a launch); per device
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_prod_tree_wide16<M>), (int)lds, attr_set); e != hipSuccess) return e;
     hipLaunchKernelGGL(k_prod_tree_wide16<M>, dim3(grid), dim3(kWide16Block), lds, stream, args, comp, n_pairs, (uint4 *)d_partials);
     return hipGetLastError();
 }

@@ -54,8 +54,7 @@ bool launches_are_async(sc_prover *p) {
 bool ensure_mailbox(sc_prover *p) {
     if (!p->pipeline_ok) return false;
     if (p->sig) return true;
-    const char *env = std::getenv("SC_PIPELINE"); // read per handle, at its first late round
-    bool env_off = env && std::atoi(env) == 0;
+    bool env_off = scd::policy(scd::kPolPipeline) == 0; // read per handle, at its first late round
     // a runtime that makes every launch wait for its kernel would block on the waiting kernel until its bound expires
     for (const char *name : {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"}) {
         const char *v = std::getenv(name);
@@ -100,8 +99,7 @@ bool skip1_enabled() {
 }
 // products of five to eight multiplicands as a product tree with node extension (kernels_wide.hip); SC_WIDE_TREE=0: node by node (k_prod_round_fe)
 bool wide_tree_enabled() {
-    static const bool on = !(std::getenv("SC_WIDE_TREE") && std::atoi(std::getenv("SC_WIDE_TREE")) == 0);
-    return on;
+    return scd::policy(scd::kPolWideTree) != 0;
 }
 bool fin_mb_enabled() {
 #ifdef SC_EXPERIMENTS
@@ -169,6 +167,7 @@ void make_bind_const(const sch::Fr &r, scd::BindConst &rc) {
 // resident table), k_finalize turns the chunk's partials into a message and k_msg_accumulate adds it to the round's.  After round 2 the
 // bound tables (half the input) are resident and the ordinary path takes over.
 int launch_round_streamed(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool publish_to_host) {
+    scd::plan_hit(scd::kPlanBigStreamed);
     if (p->exhausted) return sc_internal_fail(SC_ERR_NOT_ACTIVE, "Prover is not active");
     if (r_or_null && p->round == 0) return sc_internal_fail(SC_ERR_FIRST_ROUND_HAS_MSG, "first round should be prover first.");
     if (!r_or_null && p->round > 0) return sc_internal_fail(SC_ERR_MISSING_MSG, "verifier message is empty");
@@ -330,6 +329,79 @@ struct SlowCallProbe {
         if (ms > 1.0) std::fprintf(stderr, "[sc] slow host call: %s took %.1f ms\n", what, ms);
     }
 };
+// ---- staged initialisation: IPForMLSumcheck::prover_init's deep copy (prover.rs:55-59) and the first prove_round in one pass -------------
+// A Rust caller's tables are host memory: prover_init is a host-to-device copy of U 2^nv 32 bytes (5 GiB for config 3: ~95 ms over PCIe
+// against 5 ms of proving).  Round 1 needs no challenge and its sums are additive over any split of the index range, so the copy goes in
+// chunks on a second stream and k_round1_tree_split runs on chunk c while chunk c + 1 is in flight: each launch fills its own section of
+// the node rows of the partial sums (RoundArgs::part_stride / part_block0), ONE finalize over all sections publishes the message under
+// the sequence number round 1 will have, and keeps the node sums for round 2's claim identity -- exactly what an ordinary round 1 leaves.
+// The tables are resident and the caller's memory is no longer referenced when sc_prover_init returns, as the reference's ownership has
+// it; the first sc_prove_round finds its message waiting.  Shapes of the merged big-round kernel with at least 2^18 entries per table.
+bool fin_mb_enabled();
+bool staged_init_applies(const sc_prover *p) {
+    return scd::policy(scd::kPolStagedInit) != 0 && p->merge_rounds && !p->any_generic && !p->streamed && !p->borrow && !p->fused_finalize && p->kernel_variant == 3 &&
+           p->nv >= 18 && p->K > 0 && p->K <= (uint32_t)scd::kMetaProds;
+}
+int staged_copy_and_round1(sc_prover *p, const uint64_t *const *host_tables) {
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+        for (int q = 0; q < 2; ++q)
+            if (!p->ev_copied[q]) HIP_TRY(hipEventCreateWithFlags(&p->ev_copied[q], hipEventDisableTiming));
+    }
+    const uint64_t n = 1ULL << p->nv, n_pairs = n >> 1;
+    // the grid an ordinary round 1 of this shape takes (launch_round), cut into equal sections
+    int G = n_pairs >= (1ULL << 21) ? 1024 : n_pairs >= (1ULL << 20) ? 768 : n_pairs >= (1ULL << 18) ? 384 : n_pairs >= (1ULL << 17) ? 256 : 192;
+    if (p->K == 1) G = std::min(G, scd::kRoundTreeGrid);
+    G = std::min(G, scd::grid_for_pairs(n_pairs));
+    int n_chunks = p->nv >= 21 ? 8 : 4;
+    while (n_chunks > 1 && (G % n_chunks) != 0) n_chunks >>= 1;
+    const int gc = G / n_chunks;
+    const uint64_t chunk = n / (uint64_t)n_chunks; // entries per table and chunk
+    scd::BindConst rc;
+    std::memset(&rc, 0, sizeof(rc));
+    // (whatever the handle's stream still holds -- a previous proof's last kernels read the buffers the copy overwrites -- goes first)
+    hipEvent_t ev_free = p->ev_copied[1];
+    HIP_TRY(hipEventRecord(ev_free, p->stream));
+    HIP_TRY(hipStreamWaitEvent(p->copy_stream, ev_free, 0));
+    for (int c = 0; c < n_chunks; ++c) {
+        for (uint32_t u = 0; u < p->U; ++u) {
+            if (!host_tables[u]) return sc_internal_fail(SC_ERR_BAD_ARG, "table %u is null", u);
+            HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(p->tabs[u].buf[0]) + (size_t)c * chunk * 32, reinterpret_cast<const char *>(host_tables[u]) + (size_t)c * chunk * 32,
+                                   (size_t)chunk * 32, hipMemcpyHostToDevice, p->copy_stream));
+        }
+        hipEvent_t ev = p->ev_copied[c & 1];
+        HIP_TRY(hipEventRecord(ev, p->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(p->stream, ev, 0));
+        scd::RoundArgs ra;
+        std::memset(&ra, 0, sizeof(ra));
+        ra.n_prod = (int)p->K;
+        for (uint32_t k = 0; k < p->K; ++k) {
+            const Product &pr = p->prods[k];
+            scd::TreeProd &tp = ra.prod[k];
+            tp.M = pr.M;
+            tp.partial_off = pr.partial_off;
+            int f = 0;
+            for (size_t s2 = 0; s2 < pr.tables.size(); ++s2)
+                for (uint32_t rep = 0; rep < pr.exps[s2]; ++rep, ++f) {
+                    tp.slot[f].exp = 1;
+                    tp.slot[f].mode = 0;
+                    tp.slot[f].src = p->tabs[pr.tables[s2]].buf[0] + 2 * (size_t)c * chunk; // (an element is two uint4)
+                }
+        }
+        ra.part_stride = (uint32_t)G;
+        ra.part_block0 = (uint32_t)(c * gc);
+        HIP_TRY(scd::launch_round_tree(ra, rc, chunk >> 1, p->d_partials, gc, p->stream, true, false));
+    }
+    scd::plan_hit(scd::kPlanBigStagedRound1);
+    const bool keeps = scd::finalize_keeps_sums((int)p->K, (int)p->D, G, !p->h_finprods.empty(), fin_mb_enabled());
+    HIP_TRY(scd::launch_finalize(p->d_finprods, p->h_finprods.data(), p->d_W, (int)p->K, (int)p->D, G, p->d_partials, keeps ? p->d_sums[1] : p->d_scratch, p->d_out, nullptr,
+                                 p->h_out_dev, p->h_flag_dev, p->seq + 1, 1, fin_mb_enabled() ? p->d_fin_mb_counter : nullptr, p->stream, nullptr));
+    p->r1_cached = true;
+    p->r1_keeps = keeps;
+    return SC_OK;
+}
+
 int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool publish_to_host, bool deferred) {
     if (p->res.active) { // (sc_prove_round_partial after interactive rounds)
         int rc_q = resident_quiesce(p);
@@ -359,6 +431,19 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
     if (!deferred) { // (a pipelined round records no events: collecting would wait for the round before it)
         int rc_t = collect_timing(p);
         if (rc_t) return rc_t;
+    }
+    if (p->r1_cached) { // a staged initialisation computed this round under the copy and published it under the next sequence number
+        p->r1_cached = false;
+        if (p->round == 0 && !r_or_null && !deferred && !d_wide && publish_to_host) {
+            p->round = 1;
+            p->seq += 1;
+            p->sums_round = p->r1_keeps ? 1 : -1;
+            p->timed = false;
+            p->timing_pending = false;
+            p->prod_timed = false;
+            return SC_OK;
+        }
+        // (a caller that wants the lanes of a sharded round instead: the round is computed again, over the resident tables)
     }
     bool bind = r_or_null != nullptr || deferred;
     if (r_or_null) p->randomness.push_back(r);
@@ -433,6 +518,7 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
             }
         }
         SlowCallProbe pr_sum("launch k_sum_combos");
+        scd::plan_hit(deferred ? scd::kPlanSmallPipelined : p->U > (uint32_t)scd::kMaxSmallTables ? scd::kPlanSmallPtrs : p->has_meta ? scd::kPlanSmallLaunched : scd::kPlanSmallCombosTable);
         if (p->U <= (uint32_t)scd::kMaxSmallTables) {
             std::memset(&tp, 0, sizeof(tp));
             for (uint32_t u = 0; u < p->U; ++u) tp.src[u] = p->tabs[u].cur;
@@ -447,6 +533,7 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
         bind = false;
     }
     if (bind && p->any_generic) { // products beyond kMaxFusedM read bound tables: bind everything up front, 32 tables a launch
+        scd::plan_hit(scd::kPlanBigBindPass);
         for (uint32_t u0 = 0; u0 < p->U; u0 += (uint32_t)scd::kMaxSmallTables) {
             const uint32_t cnt = std::min<uint32_t>(p->U - u0, (uint32_t)scd::kMaxSmallTables);
             TablePtrs tp;
@@ -554,6 +641,7 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
         ra.fin.h_flag = publish_to_host ? p->h_flag_dev : nullptr;
         ra.fin.seq = p->seq;
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[0], p->stream));
+        if (bind) scd::plan_hit(p->use_f29 ? scd::kPlanBigF29Store : scd::kPlanBigCanonicalStore);
         HIP_TRY(scd::launch_round_tree(ra, rc, n_pairs, p->d_partials, grid, p->stream, split, skip1));
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[1], p->stream));
         scaled = 1;
@@ -564,7 +652,7 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
         const Product &pr = p->prods[k];
         FrHost *partials = p->d_partials + pr.partial_off;
         if (p->timing) HIP_TRY(hipEventRecord(p->prod_ev[2 * k], p->stream));
-        if (pr.fused && p->kernel_variant == 3 && (pr.M <= 4 || wide_tree_enabled())) {
+        if (pr.fused && p->kernel_variant == 3 && (pr.M <= 4 || p->wide_tree)) {
             // product tree: one argument slot per FACTOR.  The first factor touching a table this round binds and stores it;
             // a repeat inside the same product re-binds from the old table without storing (mode 3).
             ProdArgs a;
@@ -603,6 +691,8 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
                     }
                 }
             }
+            scd::plan_hit(pr.M <= 4 ? scd::kPlanBigPerProductTree : scd::kPlanBigWide);
+            if (bind) scd::plan_hit(p->use_f29 ? scd::kPlanBigF29Store : scd::kPlanBigCanonicalStore);
             HIP_TRY(scd::launch_prod_tree((int)pr.M, a, rc, n_pairs, partials, grid, p->stream));
             scaled = 1;
         } else if (pr.fused) {
@@ -634,10 +724,11 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
             } else
 #endif
             {
+                scd::plan_hit(scd::kPlanBigNodeByNode);
                 HIP_TRY(scd::launch_prod_round_fe((int)pr.M, a, r32, n_pairs, partials, grid, p->stream));
                 scaled = 1;
             }
-        } else if (pr.M <= (uint32_t)scd::kMaxWideM && wide_tree_enabled() && p->kernel_variant == 3) {
+        } else if (pr.M <= (uint32_t)scd::kMaxWideM && p->wide_tree && p->kernel_variant == 3) {
             // nine to twelve multiplicands: a tree of the trees (kernels_wide16.hip) over the tables the bind pass above left; one slot per
             // FACTOR, and the sums come back in k_sum_generic's form (the kernel takes its 2^(-5(M-1)) off again)
             scd::WideArgs16 a;
@@ -653,6 +744,7 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
             }
             sch::Fr comp = sch::kOne; // 2^(5(M-1)) in Montgomery form
             for (uint32_t dbl = 0; dbl < 5 * (pr.M - 1); ++dbl) comp = sch::add(comp, comp);
+            scd::plan_hit(scd::kPlanBigWide16);
             HIP_TRY(scd::launch_prod_tree_wide16((int)pr.M, a, to_dev(comp), n_pairs, partials, grid, p->stream));
         } else {
             if (!ptrs_uploaded) {
@@ -660,6 +752,7 @@ int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool
                 HIP_TRY(hipMemcpyAsync(p->d_cur_tables, p->h_cur_tables, p->U * sizeof(void *), hipMemcpyHostToDevice, p->stream));
                 ptrs_uploaded = true;
             }
+            scd::plan_hit(scd::kPlanBigGeneric);
             HIP_TRY(scd::launch_sum_generic(p->d_cur_tables, p->d_slot_table + pr.slot_off, p->d_slot_exp + pr.slot_off,
                                             (int)pr.tables.size(), (int)pr.M, n_pairs, partials, grid, p->stream));
         }
@@ -844,9 +937,9 @@ bool tail_possible(sc_prover *p, bool slices = false) {
 // The tables resident in LDS for the whole tail (kernels_tail.hip: k_tail_slices) where the shape allows: every product in carry-free
 // arithmetic, the slices within a CU's LDS.  SC_TAIL_SLICES=0: k_tail_rounds everywhere (A/B runs, tests of the older path).
 int tail_slices_blocks_for(sc_prover *p) {
-    static const bool env_on = !(std::getenv("SC_TAIL_SLICES") && std::atoi(std::getenv("SC_TAIL_SLICES")) == 0);
-    if (!env_on || p->max_mult > (uint32_t)(wide_tree_enabled() ? scd::kMaxWideM : scd::kMaxFusedM) || p->round >= p->nv) return 0;
-    const int B = scd::tail_slices_blocks(1ULL << (p->nv - (p->round + 1)), (int)p->U, (int)p->K, (int)p->D, p->n_combos, (int)p->max_mult);
+    if (scd::policy(scd::kPolTailSlices) == 0 || p->max_mult > (uint32_t)(p->wide_tree ? scd::kMaxWideM : scd::kMaxFusedM) || p->round >= p->nv) return 0;
+    const int B = scd::tail_slices_blocks(1ULL << (p->nv - (p->round + 1)), (int)p->U, (int)p->K, (int)p->D, p->n_combos, (int)p->max_mult,
+                                          scd::tail_slices_max_blocks(p->device, (int)p->max_mult));
     if (B <= 0) return 0;
     if (!p->d_tail_xw) { // tagged hand-over words, owned by the handle: zero once, tags only ever grow
         if (hipMalloc(reinterpret_cast<void **>(&p->d_tail_xw), scd::kTsXwWords * 8) != hipSuccess ||
@@ -859,8 +952,7 @@ int tail_slices_blocks_for(sc_prover *p) {
         p->ts_tag = 1;
         // the mailbox in device memory, where the host may store into it (SC_VRAM_MAILBOX=0: block 0 polls the host-mapped one and passes it on)
         int large_bar = 0;
-        const char *env = std::getenv("SC_VRAM_MAILBOX");
-        if (!(env && std::atoi(env) == 0) && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, p->device) == hipSuccess && large_bar) {
+        if (scd::policy(scd::kPolVramMailbox) != 0 && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, p->device) == hipSuccess && large_bar) {
             void *m = nullptr;
             if (hipExtMallocWithFlags(&m, 256, hipDeviceMallocFinegrained) == hipSuccess && hipMemsetAsync(m, 0, 256, p->stream) == hipSuccess &&
                 hipStreamSynchronize(p->stream) == hipSuccess)
@@ -982,6 +1074,7 @@ int run_tail(sc_prover *p, sch::Blake2b512Rng &rng, uint32_t n_rounds, const sch
     if (rc_l) return rc_l;
     g_stat[kStatTailLaunches].fetch_add(1, std::memory_order_relaxed);
     if (slices_B > 0) g_stat[kStatTailSlices].fetch_add(1, std::memory_order_relaxed);
+    scd::plan_hit(slices_B > 0 ? (p->max_mult > (uint32_t)scd::kMaxFusedM ? scd::kPlanTailSlices12 : scd::kPlanTailSlices8) : scd::kPlanTailRounds);
     gate.release();
     p->seq += n_rounds;
     p->sig_seq += n_rounds - 1;
@@ -1115,8 +1208,7 @@ int resident_wait(sc_prover *p, uint32_t j, uint64_t *out_evals) {
     return SC_OK;
 }
 bool resident_enabled(sc_prover *p) {
-    static const bool env_on = !(std::getenv("SC_RESIDENT") && std::atoi(std::getenv("SC_RESIDENT")) == 0);
-    return env_on && p->resident_spins > 0 && !p->timing && p->stream == p->own_stream;
+    return scd::policy(scd::kPolResident) != 0 && p->resident_spins > 0 && !p->timing && p->stream == p->own_stream;
 }
 // first late-round call: launch the kernel for every remaining round, return its first message
 int resident_start(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals) {
@@ -1142,6 +1234,7 @@ int resident_start(sc_prover *p, const uint64_t *r_or_null, uint64_t *out_evals)
             rc = tail_launch(p, n_rounds, r_or_null ? &r : nullptr, p->resident_spins, A, grid, slices_B, true);
         }
         if (rc == SC_OK && slices_B > 0) g_stat[kStatTailSlices].fetch_add(1, std::memory_order_relaxed);
+        if (rc == SC_OK) scd::plan_hit(slices_B > 0 ? scd::kPlanResidentSlices : scd::kPlanResidentRounds);
         if (rc) {
             resident_release_slot(p);
             return rc;
@@ -1360,12 +1453,17 @@ int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, uint32_
     // all-reduce writes its result straight into the host-mapped page, and a word whose top bits read nranks * tag IS this round's
     // total -- the per-round sequence on the stream is [round kernel, finalize, ncclAllReduce] with no publish launch behind it (the
     // peer-to-peer communicator's exchange kernel publishes too: one launch of latency per sharded round on either path).
-    const bool direct = comm->comm != nullptr && comm->direct_publish && !p->streamed;
+    // The decision is the COMMUNICATOR's (agreed by every rank inside sc_comm_init), never this rank's alone: a rank that tagged while a
+    // peer did not would wait for a total that cannot come.  Streamed rounds (whose message k_msg_accumulate forms, untagged) get their tag
+    // from one more small launch.
+    const bool direct = comm->comm != nullptr && comm->direct_publish;
+    if (direct) std::memset(p->h_wide, 0, (size_t)n_words * 8); // (nothing targets the page now; a stale word of an earlier communicator or generation cycle must not look ready)
     struct TagScope {
         sc_prover *p;
         ~TagScope() { p->wide_tagged = false; }
     } tag_scope_{p};
     p->wide_tagged = direct;
+    scd::plan_hit(direct ? scd::kPlanShardedRcclDirect : comm->comm ? scd::kPlanShardedRcclPublish : p2p ? scd::kPlanShardedP2P : scd::kPlanShardedHost);
     const uint64_t lane_mask = (1ULL << scd::kWideTagShift) - 1;
     uint32_t gen_want = 0; // the communicator's generation of the round awaited (ranks make the same calls: the same on every rank)
     auto wide_ready = [&](uint32_t gen) -> bool { // every word carries nranks * the tag every rank's finalize step gave that generation
@@ -1400,8 +1498,10 @@ int sharded_rounds(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, uint32_
     auto enqueue = [&](const uint64_t *r, bool deferred, uint32_t *want_out, uint32_t *gen_out) -> int {
         DeviceGate gate_(p->device);
         *gen_out = p->wide_gen = direct ? ++comm->direct_gen : 0;
+        const bool streamed_round = p->streamed && p->round < 2;
         int rc = launch_round(p, r, p->d_wide, false, deferred);
         if (rc) return rc;
+        if (direct && streamed_round) HIP_TRY(scd::launch_tag_words(p->d_wide, n_words, *gen_out, p->stream));
         if (comm->comm) NCCL_TRY(g_nccl.AllReduce(p->d_wide, direct ? p->h_wide_dev : p->d_wide, (size_t)n_words, ncclUint64, ncclSum, comm->comm, p->stream));
         p->seq += 1;
         *want_out = p->seq;
@@ -1513,18 +1613,15 @@ extern "C" int sc_ml_prove_sharded_rounds(sc_prover *p, sc_comm *comm, sc_rng *r
 // single-GPU cost per round, in the persistent tail kernel.  m = 0 (one element per table and rank) is the smallest case.
 uint32_t sharded_tail_m(uint32_t nv_local, uint32_t k) { // log2 of the entries per table a rank still holds at the gather
     if (k == 0) return 0;
-    // (SC_SHARD_GATHER_LOG2, default 15 = 2^14 pairs in the first replicated round: the same on every rank.  A smaller value trades
+    // (sc_set_policy("shard_gather_log2", v), default 15 = 2^14 pairs in the first replicated round: the same on every rank.  A smaller value trades
     // gather volume -- U * 2^value * 32 bytes in all -- for sharded rounds, each an exchange; to be tuned on the first multi-GPU node)
-    static const uint32_t glog = [] {
-        const char *e = std::getenv("SC_SHARD_GATHER_LOG2");
-        const int v = e ? std::atoi(e) : 15;
-        return (uint32_t)std::min(std::max(v, 1), 15);
-    }();
+    const uint32_t glog = (uint32_t)std::min<int64_t>(std::max<int64_t>(scd::policy(scd::kPolShardGatherLog2), 1), 15);
     const uint32_t want = k >= glog ? 0u : glog - k; // 2^(m + k - 1) pairs <= 2^(glog - 1) in the first replicated round
     return std::min(want, nv_local - 1);          // at least one sharded round
 }
 int sharded_tail(sc_prover *p, sc_comm *comm, sch::Blake2b512Rng &rng, const uint64_t *last_challenge, uint32_t k, uint32_t m, uint64_t *out_proof,
                         uint64_t *out_randomness) {
+    scd::plan_hit(scd::kPlanShardedGatherTail);
     const uint32_t G = (uint32_t)comm->nranks, U = p->U, per = 1u << m;
     const size_t send_bytes = (size_t)U * per * 32;
     int rc;

@@ -119,7 +119,9 @@ struct sc_prover {
     uint32_t *d_fin_mb_counter = nullptr; // (inside d_fin_counters)
     uint32_t *d_fin_counters = nullptr; // ... and its arrival counters (the kernel leaves them at zero)
     FinProd *d_finprods = nullptr;
-    FrHost *d_W = nullptr; // node -> message matrices of every product (see FinProd::w_off)
+    FrHost *d_W = nullptr; // node -> message matrices of every product (see FinProd::w_off); w_elems of them, and the same again behind
+    uint32_t w_elems = 0;  // (the descriptor's matrices: what a reset restores after sc_internal_scale_by_bound_table -- GKR phase two)
+    bool w_scaled = false;
     FrHost *d_scratch = nullptr;
     // the multi-block finalize's node sums of the last two rounds (K * D each, round & 1 selects): a big binding round whose predecessor's
     // sums are here leaves node 1 to the claim identity (kernels.h: ClaimArgs).  sums_round: the round whose complete sums are held, or -1
@@ -181,6 +183,7 @@ struct sc_prover {
     bool fused_finalize = false;    // experiments, SC_FUSED_FIN=1: the merged big-round launch finalizes in-kernel (measured: slower than the k_finalize launch)
     bool use_tail = true;           // sc_ml_prove* / GKR: the latency-bound rounds run in the persistent tail kernel (SC_TAIL=0: pipelined launches)
     bool merge_rounds = false; // big rounds run as ONE launch over all products (k_round_tree): <= kMaxRoundProds products of <= 4 multiplicands
+    bool wide_tree = true; // products of 5..12 multiplicands as trees (policy "wide_tree" when the handle was built)
     bool use_f29 = false; // bound tables of big rounds kept in the internal 9 x 29-bit format (all products <= 4 multiplicands)
     // The production path is fixed: product tree, carry-free arithmetic.  A -DSC_EXPERIMENTS build (libsumcheck_hip_exp.so, used by
     // tests/test_gpu_variants.py) lets the environment select the cross-check kernels instead.
@@ -196,6 +199,9 @@ struct sc_prover {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     FrHost *d_chunk_msg = nullptr;        // a chunk's message, and the running sum over the chunks (2 x D elements)
+    // staged initialisation (host tables copied in chunks, round 1 computed under the copy: staged_copy_and_round1): round 1's message is
+    // already published under sequence number seq + 1, its node sums are in d_sums[1] if r1_keeps; the first launch_round only takes note
+    bool r1_cached = false, r1_keeps = false;
     // reset support + per-product instrumentation
     bool borrow = false;
     std::vector<const uint4 *> origin; // borrowed table pointers (borrow mode)
@@ -225,9 +231,11 @@ uint64_t sc_internal_cache_limit();
 constexpr int kResidentGone = -1; // internal: no resident kernel serves this round; take the ordinary path
 extern std::atomic<uint64_t> g_stat[8]; // process-wide counters a host can read (sc_library_stats)
 enum { kStatTailLaunches = 0, kStatTailSlotBusy = 1, kStatTailSlotReclaims = 2, kStatResidentStarts = 3, kStatResidentGone = 4, kStatProofRetries = 5, kStatTailSlices = 6 };
-bool wide_tree_enabled(); // products of five to eight multiplicands through kernels_wide.hip (SC_WIDE_TREE=0: node by node)
+bool wide_tree_enabled(); // products of five to eight multiplicands through kernels_wide.hip (policy "wide_tree" = 0: node by node)
 int resident_quiesce(sc_prover *p); // the interactive protocol's resident kernel leaves before anything else touches the handle
 int launch_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *d_wide, bool publish_to_host, bool deferred = false);
+bool staged_init_applies(const sc_prover *p);                                   // host tables, copy mode: the shape and size the staged form takes
+int staged_copy_and_round1(sc_prover *p, const uint64_t *const *host_tables); // H2D in chunks + round 1 under the copy (prover.rs:55-59 and the first prove_round)
 int await_round(sc_prover *p, uint64_t *out_evals, uint32_t want);
 bool wait_gave_up(sc_prover *p);   // the give-up marker of k_wait_challenge
 void abandon_deferred(sc_prover *p); // error path: let a stream that is blocked on the wait drain

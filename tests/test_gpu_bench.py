@@ -142,9 +142,9 @@ def test_bench_rccl_code_path_with_a_world_of_one():
     assert c["exchange"]["exchange_us"] > 0 and "selftest passed" in c["round_loop_reason"]
     assert c["exchange"]["publication"].startswith("direct"), c["exchange"]  # the RCCL rounds run without a publish kernel (probed at sc_comm_init)
     assert d["parity"]["ok"] is True and d["parity"]["rounds_equal"] == 19, d["parity"]
-    # ... and with SC_RCCL_DIRECT=0 through the publish kernel, to the same bits
+    # ... and with sc_set_policy("rccl_direct", 0) through the publish kernel, to the same bits
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--nv", "19", "--steps", "2", "--warmup", "1", "--min-gpu-seconds", "0.5",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env, SC_RCCL_DIRECT="0"))
+                        "--no-cpu-baseline", "--policy", "rccl_direct=0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d0 = json.loads(r.stdout.strip().splitlines()[-1])
     assert d0["config"]["exchange"]["publication"].startswith("publish kernel") and d0["parity"]["ok"] is True, d0["config"]["exchange"]

@@ -183,6 +183,10 @@ SHAPES = [
     (16, 7, [[0, 1, 2, 3], [4, 5, 6], [1, 1], [2], [3, 3, 3], [5, 6, 6, 0]]),
     (15, 2, [[0], [1]]),
     (18, 4, [[0, 1], [2, 3], [0, 3]]),
+    # launch plans the shapes above do not reach (tests/test_zz_plan_coverage.py):
+    (17, 36, [[3 * i, 3 * i + 1, 3 * i + 2] for i in range(12)]),  # more than 32 tables in ONE merged launch: the bound tables stay in the reference layout
+    (10, 3, [[0, 1]] * 9 + [[1, 2]] * 9),                          # more products than a launch's arguments describe: the one-block finalize
+    (9, 4, [[0, 1, 2, 3]] * 22 + [[1, 2, 3]] * 22),                # node sums beyond the finalize step's LDS
 ]
 
 
@@ -208,6 +212,7 @@ def test_random_shapes_vs_oracle(nv, nt, shapes):
     proof = sc.MLSumcheck.prove(poly)
     want, _ = cref.ml_prove(d, threads=cref.max_threads())
     assert np.array_equal(np.stack([m.evaluations for m in proof]), want)
+
 
 
 def test_claim_identity_rounds_survive_state_export_timing_stream_switch_and_reset():
@@ -565,6 +570,14 @@ def test_sharded_rounds_inside_the_library_world1():
         got, rand = sharded.prove_sharded_native(engine, ncomm, sharded.DistComm(), nv, 4, None)
         assert np.array_equal(got, want) and np.array_equal(rand, wrand)
     ncomm.close()
+    # a communicator whose ranks voted against direct publication (policy "rccl_direct" = 0 at sc_comm_init): all-reduce + publish kernel
+    with _lib.policy(rccl_direct=0):
+        ncomm = sharded.NativeComm(dev)
+    before = _lib.plan_stats()["sharded.rccl_publish"]
+    engine.reset()
+    got, rand = sharded.prove_sharded_native(engine, ncomm, sharded.DistComm(), nv, 4, None)
+    assert np.array_equal(got, want) and np.array_equal(rand, wrand) and _lib.plan_stats()["sharded.rccl_publish"] == before + 1
+    ncomm.close()
 
 
 @pytest.mark.parametrize("nv,nt,shapes,device", [
@@ -834,6 +847,13 @@ def test_interactive_rounds_resident_kernel(nv, nt, shapes):
     with pytest.raises(sc.SumcheckError, match="Prover is not active"):
         sc.IPForMLSumcheck.prove_round(st2, vmsg[1])
     st2.close()
+    with _lib.policy(tail_slices=0):                                 # the resident kernel in its older form: k_tail_rounds, tables through memory
+        before = _lib.plan_stats()["resident.rounds"]
+        st3 = sc.IPForMLSumcheck.prover_init(poly, borrow=True)
+        dialogue(st3)
+        st3.reset(); dialogue(st3, pause_at={nv - 2}, export_at={nv - 3})
+        st3.close()
+        assert _lib.plan_stats()["resident.rounds"] > before
 
 
 def test_out_of_memory_is_a_status_code_and_a_resident_kernel_does_not_block_other_provers():
@@ -992,11 +1012,11 @@ def test_provers_on_several_threads_share_one_gpu():
 
 
 @pytest.mark.parametrize("case", ["sorted", "shuffled", "crowded_x", "crowded_y", "duplicates", "tiny_dim", "list_form"])
-def test_gkr_prove_bucketed_initialisation(case, monkeypatch):
+def test_gkr_prove_bucketed_initialisation(case, request):
     """sc_gkr_prove builds a_hg and f1(g,u,.) by bucketing the non-zeros and adding terms in LDS (gkr.hip: k_bucket_accumulate)
     instead of sorting and merging.  Same proof bits as the oracle for: index-ordered input (phase two skips its radix pass),
     shuffled input, index distributions that crowd one x or y bucket (fallback to the list form, in either phase), repeated
-    indices (summed, as the list form does), dim below the bucket width, and the list form forced by SC_GKR_DIRECT=0."""
+    indices (summed, as the list form does), dim below the bucket width, and the list form forced by sc_set_policy("gkr_direct", 0)."""
     dim = 4 if case == "tiny_dim" else 14
     n = 1 << dim
     rng = np.random.default_rng(99)
@@ -1026,8 +1046,9 @@ def test_gkr_prove_bucketed_initialisation(case, monkeypatch):
         oi, ov = ui, H.mont(merged)
     else:
         oi, ov = idx, vals
-    if case == "list_form":
-        monkeypatch.setenv("SC_GKR_DIRECT", "0")  # (read once per process: only effective if no GKR proof ran before; parity holds either way)
+    if case == "list_form":  # sort + merge instead of the bucketed kernels
+        request.addfinalizer(lambda: _lib.set_policy("gkr_direct", 1))
+        _lib.set_policy("gkr_direct", 0)
     want, wuv = cref.gkr_prove(oi, ov, dim, f2, f3, g, threads=cref.max_threads())
     for on_device in (False, True):
         if on_device:
@@ -1088,9 +1109,7 @@ TAIL_SHAPES = [
 def test_tail_with_tables_resident_in_lds(nv, nt, shapes):
     """k_tail_slices (kernels_tail.hip): the latency-bound rounds of a whole proof out of LDS.  Whole Fiat-Shamir proofs against the
     oracle, the state the tail leaves behind (randomness, the final two-entry tables: written back from LDS), the library's count of
-    such launches -- and the same proof through k_tail_rounds (SC_TAIL_SLICES=0, its own process) to the same bits."""
-    import subprocess
-    import sys
+    such launches -- and the same proof through k_tail_rounds (policy "tail_slices" = 0) to the same bits."""
     tabs = [cref.synth_table(4242 + nv, s, 1 << nv) for s in range(nt)]
     coefs = cref.synth_table(4242 + nv, 1000, len(shapes))
     d = H.desc_from(nv, shapes, tabs, coefs)
@@ -1115,18 +1134,16 @@ def test_tail_with_tables_resident_in_lds(nv, nt, shapes):
     assert np.array_equal(st.randomness, wrand)
     for u, t in enumerate(st.flattened_ml_extensions):
         assert np.array_equal(t.evaluations, otabs[u]), f"final table {u}"
-    code = (
-        "import sys, numpy as np, ctypes as C\n"
-        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
-        "import sumcheck_amd as sc\nfrom oracle import cref\nfrom tests import helpers as H\nfrom sumcheck_amd import _lib\n"
-        f"nv, nt, shapes = {nv}, {nt}, {shapes!r}\n"
-        "tabs = [cref.synth_table(4242 + nv, s, 1 << nv) for s in range(nt)]\ncoefs = cref.synth_table(4242 + nv, 1000, len(shapes))\n"
-        "poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs, device='cuda:0')\nproof = sc.MLSumcheck.prove(poly)\n"
-        "stats = (C.c_uint64 * 8)()\n_lib.check(sc.lib().sc_library_stats(stats, 8))\nassert stats[0] == 1 and stats[6] == 0, list(stats)\n"
-        "sys.stdout.write(np.stack([m.evaluations for m in proof]).tobytes().hex())\n")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, SC_TAIL_SLICES="0"))
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert bytes.fromhex(r.stdout.strip().splitlines()[-1]) == want.tobytes()
+    # ... and through k_tail_rounds (policy "tail_slices" = 0: a fresh handle, the same tables)
+    with _lib.policy(tail_slices=0):
+        _lib.check(sc.lib().sc_library_stats(stats, 8))
+        before = (stats[0], stats[6])
+        plans = _lib.plan_stats()
+        proof = sc.MLSumcheck.prove(poly)
+        _lib.check(sc.lib().sc_library_stats(stats, 8))
+        assert stats[0] - before[0] == 1 and stats[6] == before[1], (list(stats), before)
+        assert _lib.plan_stats()["tail.rounds"] == plans["tail.rounds"] + 1
+    assert np.array_equal(np.stack([m.evaluations for m in proof]), want)
 
 
 WIDE_SHAPES = [
@@ -1174,3 +1191,55 @@ def test_wide_products_product_tree_with_node_extension(nv, nt, shapes):
     proof = sc.MLSumcheck.prove(poly)
     want, _ = cref.ml_prove(d, threads=cref.max_threads())
     assert np.array_equal(np.stack([m.evaluations for m in proof]), want)
+    if (nv, nt) in ((17, 6), (16, 12)):  # ... and node by node (policy "wide_tree" = 0: k_prod_round_fe up to eight, k_sum_generic beyond), a handle built under it
+        with _lib.policy(wide_tree=0):
+            before = _lib.plan_stats()
+            proof = sc.MLSumcheck.prove(poly)
+            after = _lib.plan_stats()
+        assert np.array_equal(np.stack([m.evaluations for m in proof]), want)
+        key = "big.node_by_node" if nt <= 8 else "big.generic"
+        assert after[key] > before[key] and after["big.wide"] == before["big.wide"] and after["big.wide16"] == before["big.wide16"]
+
+
+def test_staged_init_host_tables_round_one_under_the_copy():
+    """sc_prover_init over HOST tables of a merged-kernel shape (protocol.hip: staged_copy_and_round1): the tables go in in chunks and round 1
+    is computed under the copy -- IPForMLSumcheck::prover_init's deep copy (prover.rs:55-59) and the first prove_round in one pass.  At
+    nv = 22 (config 3's shape; 8 chunks): the interactive rounds with bound tables, whole Fiat-Shamir proofs (one-shot and on a handle),
+    a reset onto OTHER tables (the pool's path), the caller's arrays untouched and droppable after init -- all against the oracle, and the
+    same with the staged form switched off."""
+    nv, shapes, nt = 22, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10
+    tabs = [cref.synth_table(6100, s, 1 << nv) for s in range(nt)]
+    tabs2 = [cref.synth_table(6200, s, 1 << nv) for s in range(nt)]
+    coefs = cref.synth_table(6100, 1000, len(shapes))
+    chal = cref.synth_table(6100, 2000, nv)
+    d = H.desc_from(nv, shapes, tabs, coefs)
+    want, wrand = cref.ml_prove(d, threads=cref.max_threads())
+    want2, _ = cref.ml_prove(H.desc_from(nv, shapes, tabs2, coefs), threads=cref.max_threads())
+    op = cref.Prover(d, threads=cref.max_threads())
+    for staged in (1, 0):
+        with _lib.policy(staged_init=staged):
+            before = _lib.plan_stats()["big.staged_round1"]
+            copies = [t.copy() for t in tabs]
+            poly, _ = H.hip_poly_from(nv, shapes, copies, coefs)
+            st = sc.IPForMLSumcheck.prover_init(poly)  # host tables, copying handle
+            for t in copies:
+                t[:] = 0  # prover_init has copied: the caller's memory is its own again
+            assert _lib.plan_stats()["big.staged_round1"] == before + staged
+            if staged:  # the interactive rounds, message by message, and the bound tables after round 3
+                v = None
+                for i in range(4):
+                    w = op.prove_round(None if v is None else v.randomness)
+                    got = sc.IPForMLSumcheck.prove_round(st, v).evaluations
+                    assert np.array_equal(got, w), f"round {i + 1}"
+                    v = sc.VerifierMsg(chal[i])
+                _, otabs, _ = op.state()
+                for u, t in enumerate(st.flattened_ml_extensions):
+                    assert np.array_equal(t.evaluations, otabs[u]), f"table {u}"
+            st.close()
+            poly, _ = H.hip_poly_from(nv, shapes, tabs, coefs)
+            proof, state = sc.MLSumcheck.prove_as_subprotocol(sc.Blake2b512Rng.setup(), poly)  # a handle out of the pool: reset onto these tables
+            assert np.array_equal(np.stack([m.evaluations for m in proof]), want) and np.array_equal(state.randomness, wrand)
+            del state
+            poly2, _ = H.hip_poly_from(nv, shapes, tabs2, coefs)
+            assert np.array_equal(np.stack([m.evaluations for m in sc.MLSumcheck.prove(poly2)]), want2)
+            assert _lib.plan_stats()["big.staged_round1"] >= before + 3 * staged

@@ -334,7 +334,7 @@ def _comm_probe(c, kind, G):
     assert (n.value, k.value & 0xff) == (G, kind) and 0 <= r.value < G
     # RCCL: direct publication (the all-reduce delivers tagged lanes into the host-mapped page) is probed at init and holds on this box;
     # the other communicators never carry the flag
-    assert bool(k.value & 0x100) == (kind == 1 and os.environ.get("SC_RCCL_DIRECT") != "0"), k.value
+    assert bool(k.value & 0x100) == (kind == 1 and _lib.get_policy("rccl_direct") != 0), k.value
     mean, mn = C.c_double(), C.c_double()
     _lib.check(sc.lib().sc_comm_exchange_bench(c._h, 40, 20, C.byref(mean), C.byref(mn)))  # 40 words = a degree-4 message
     assert 0 < mn.value <= mean.value

@@ -117,13 +117,15 @@ def test_more_products_than_one_launch_takes():
 def test_wait_kernel_give_up_is_detected():
     """Pipelined late rounds: if the host does not deliver a challenge within the wait kernel's bound, the round behind it runs on
     a stale challenge.  The library must notice (give-up marker) and void the proof instead of returning wrong messages.  A
-    subprocess shortens the bound to one poll (SC_WAIT_SPINS is read once per process)."""
+    subprocess shortens the bound to one poll (sc_set_policy("wait_spins", 1): process-wide)."""
     import subprocess
     import sys
     code = r'''
 import numpy as np, sumcheck_amd as sc
 from oracle import cref
+from sumcheck_amd import _lib
 from tests import helpers as H
+_lib.set_policy("wait_spins", 1)
 nv, shapes = 12, [[0, 1, 2], [1]]
 tabs = [cref.synth_table(7, s, 1 << nv) for s in range(3)]
 coefs = cref.synth_table(7, 1000, len(shapes))
@@ -134,7 +136,7 @@ try:
 except sc.SumcheckError as e:
     print("ERROR", e)
 '''
-    env = dict(os.environ, SC_WAIT_SPINS="1", SC_PIPELINE="1")
+    env = dict(os.environ)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -149,7 +151,9 @@ def test_wait_kernel_give_up_is_retried_when_the_inputs_survive():
     code = r'''
 import numpy as np, sumcheck_amd as sc
 from oracle import cref
+from sumcheck_amd import _lib
 from tests import helpers as H
+_lib.set_policy("wait_spins", 1)
 nv, shapes = 13, [[0, 1, 2], [1]]
 tabs = [cref.synth_table(8, s, 1 << nv) for s in range(3)]
 coefs = cref.synth_table(8, 1000, len(shapes))
@@ -161,7 +165,7 @@ state.reset()
 ok2 = np.array_equal(np.asarray(state.prove(sc.Blake2b512Rng.setup())).reshape(want.shape), want)
 print("RETRIED-OK" if ok and ok2 else "MISMATCH")
 '''
-    env = dict(os.environ, SC_WAIT_SPINS="1", SC_PIPELINE="1", SC_HOST_TRACE="1")
+    env = dict(os.environ, SC_HOST_TRACE="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -177,6 +181,7 @@ import sumcheck_amd as sc
 from oracle import cref
 from sumcheck_amd import _lib
 from tests import helpers as H
+_lib.set_policy("wait_spins", 20000)
 nv, shapes, nt = 16, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10
 tabs = [cref.synth_table(8800, s, 1 << nv) for s in range(nt)]
 coefs = cref.synth_table(8800, 1000, len(shapes))
@@ -225,12 +230,11 @@ def test_foreign_hip_traffic_never_voids_or_corrupts_a_proof():
     """sumcheck_hip.h's interference contract: two threads of the process hammer hipMalloc / hipMemcpy / hipFree on the prover's
     device while it proves 200 times with device-side waits enabled (a borrowing handle: an expired wait is answered by proving
     again inside the call), 50 times with sc_prover_set_polling(p, 0) (nothing ever waits for the host), and once interactively
-    (resident kernel).  Slower is fine; void or wrong is not.  The wait bound is shortened (SC_WAIT_SPINS) so that a stall costs
+    (resident kernel).  Slower is fine; void or wrong is not.  The wait bound is shortened (policy "wait_spins") so that a stall costs
     milliseconds, not seconds, of test time."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = {k: v for k, v in os.environ.items() if not k.startswith("SC_")}
-    e["SC_WAIT_SPINS"] = "20000"
     r = subprocess.run([sys.executable, "-c", HAMMER_WORKER, "200", "50"], capture_output=True, text=True, timeout=900, cwd=root, env=e)
     assert r.returncode == 0 and "HAMMER-OK 250 proofs" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

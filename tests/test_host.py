@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/sumcheck_hip.h but not exported"
     assert set(declared) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert sc.lib().sc_abi_version() == 4
+    assert sc.lib().sc_abi_version() == 5
 
 
 def test_transcript_matches_golden():

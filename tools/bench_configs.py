@@ -16,6 +16,10 @@ from oracle import cref
 from sumcheck_amd import _lib
 
 SEED = 0x5C20241008
+for _a in [a for a in sys.argv if a.startswith("--policy=")]:  # --policy=key=value: sc_set_policy before anything runs (A/B runs, e.g. --policy=wide_tree=0)
+    _k, _v = _a[len("--policy="):].split("=")
+    _lib.set_policy(_k, int(_v))
+    sys.argv.remove(_a)
 dev = torch.device("cuda:0")
 
 
@@ -151,7 +155,7 @@ def wide(nv, ms, reps=7):
     r["multiplicands"] = ms
     r["kernels"] = ("k_round1_tree_split / k_round_tree_split (every product <= 4)" if max(ms) <= 4 else
                     "k_prod_tree (<= 4) + k_prod_tree_wide<M> (5..8: halves' trees, node extension), one launch per product" if max(ms) <= 8 else
-                    "k_fix_multi (bind pass) + k_prod_tree_wide16<M> (9..12: a tree of the trees)" if max(ms) <= 12 and os.environ.get("SC_WIDE_TREE") != "0" else "k_fix per table + k_sum_generic per product")
+                    "k_fix_multi (bind pass) + k_prod_tree_wide16<M> (9..12: a tree of the trees)" if max(ms) <= 12 and _lib.get_policy("wide_tree") != 0 else "k_fix per table + k_sum_generic per product")
     return r
 
 

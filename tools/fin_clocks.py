@@ -1,11 +1,11 @@
 """Where k_finalize's time goes (needs tools/ab/fin_clocks.so: tools/build_variant.sh fin_clocks -DSC_FIN_CLOCKS, SC_LIB_PATH set to it).
-Runs config 3 at nv=24 round by round with synchronous rounds (SC_PIPELINE=0) and prints the phase stamps of each round's finalize."""
+Runs config 3 at nv=24 round by round with synchronous rounds (policy "pipeline" = 0) and prints the phase stamps of each round's finalize."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("SC_PIPELINE", "0")
 import numpy as np, torch
 import sumcheck_amd as sc
 from sumcheck_amd import _lib
+_lib.set_policy("pipeline", 0)
 from oracle import cref
 nv = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 shapes, nt = [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10

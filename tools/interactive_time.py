@@ -5,6 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, sumcheck_amd as sc
 from oracle import cref
 from tests import helpers as H
+from sumcheck_amd import _lib
+for _a in [a for a in sys.argv if a.startswith("--policy=")]:  # --policy=key=value (A/B runs, e.g. --policy=tail_slices=0)
+    _k, _v = _a[len("--policy="):].split("=")
+    _lib.set_policy(_k, int(_v))
+    sys.argv.remove(_a)
 shapes, nt = [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10
 for nv in [int(a) for a in sys.argv[1:]] or [8, 12, 16]:
     tabs = [cref.synth_table(2024, s, 1 << nv) for s in range(nt)]
