@@ -389,6 +389,53 @@ def comm_info(sc, comm):
     return r.value, n.value, {1: "rccl", 2: "host-transport", 3: "p2p"}.get(k.value & 0xff, str(k.value)), bool(k.value & 0x100)
 
 
+def end_to_end(sc, _lib, torch, tables, shapes, coefs, nv, dev, want, reps=3):
+    """SURVEY 8d's t_end_to_end: the path a Rust caller takes -- HOST tables in, proof out (`MLSumcheck::prove(&poly)`, mod.rs:42-53, whose
+    prover_init deep copy, prover.rs:55-59, is the host-to-device copy here).  Measured AFTER the timed region, never part of `value`:
+    the bare copy of the same bytes (pinned and pageable), and whole one-shot proofs from host tables with the staged initialisation
+    (round 1 under the copy; protocol.hip staged_copy_and_round1) and without it.  Every proof is compared with the timed region's."""
+    def wall(f):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        r = f()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) * 1e3, r
+
+    out = {"bytes": int(sum(t.numel() * 8 for t in tables)), "reps": reps,
+           "what": "after the timed region; one-shot sc_ml_prove over HOST tables (the reference's calling convention), best of reps; h2d_ms = the bare hipMemcpy of the same bytes"}
+    host = [t.cpu() for t in tables]  # pageable
+    scratch = torch.empty_like(tables[0])
+    ok = True
+    for kind in ("pageable", "pinned"):
+        if kind == "pinned":
+            host = [h.pin_memory() for h in host]
+
+        def bare():
+            for h in host:
+                scratch.copy_(h, non_blocking=True)
+        h2d = min(wall(bare)[0] for _ in range(reps))
+        mles = [sc.DenseMultilinearExtension(nv, h) for h in host]
+        poly = sc.ListOfProductsOfPolynomials(nv)
+        for kk, sh in enumerate(shapes):
+            poly.add_product([mles[i] for i in sh], coefs[kk])
+        res = {"h2d_ms": h2d, "h2d_GBps": out["bytes"] / h2d / 1e6}
+        for staged in (1, 0):
+            with _lib.policy(staged_init=staged):
+                ts = []
+                for _ in range(reps + 1):  # (the first call builds the prover the library keeps for this shape)
+                    ms, proof = wall(lambda: sc.MLSumcheck.prove(poly))
+                    ts.append(ms)
+                    ok = ok and bool(np.array_equal(np.stack([m.evaluations for m in proof]).reshape(want.shape), want))
+            key = "staged" if staged else "copy_then_prove"
+            res[key + "_total_ms"] = min(ts[1:])
+            res[key + "_first_call_ms"] = ts[0]
+        res["total_ms"] = res["staged_total_ms"]
+        res["prove_beyond_h2d_ms"] = res["staged_total_ms"] - h2d
+        out[kind] = res
+    out["proofs_equal_timed_region"] = ok
+    return out
+
+
 def run_rank(args, W, result):
     """the measurement on one rank; rank 0 leaves the JSON line's dictionary in result['line'] and every rank its exit status"""
     import torch
@@ -625,6 +672,13 @@ def run_rank(args, W, result):
             step()
         torch.cuda.synchronize(dev)
 
+    e2e = None
+    if rank == 0 and not sharded_path and not args.no_end_to_end and nv_local <= 24:
+        try:
+            e2e = end_to_end(sc, _lib, torch, tables, shapes, coefs, nv_local, dev, timed_proof)
+        except Exception as e:  # a report beside the line, never a reason to lose it
+            e2e = {"failed": f"{type(e).__name__}: {e}"}
+
     if box["python"]:
         round_loop = "torch.distributed"
     ms, ln = ms_acc, ln_acc
@@ -723,6 +777,7 @@ def run_rank(args, W, result):
                        "launcher": W.launcher, "ranks_seen": ranks_seen, "communicator": comm_kind, "exchange": exchange,
                        "round_loop": round_loop, "round_loop_reason": box["why"], "policy": args.policy,
                        # the scaling model's figure for THIS line, written down before any N > 1 hardware run: the line tests it
+                       "end_to_end": e2e,
                        "predicted_ms_per_step": pred["predicted_ms_per_step"], "exchange_assumed_us": pred.get("exchange_assumed_us"), "prediction": pred,
                        "gpu_leg": {"warmup_proofs": args.warmup, "timed_proofs": args.steps, "proofs_after_the_clock": cooldown + (1 if all_have else 0),
                                    "event_sampled_proofs": timed_steps,
@@ -903,6 +958,7 @@ def main():
                     help="config 3 at N>1: strong = the nv=24 instance split N ways (the metric as worded), weak = nv=24 per GPU")
     ap.add_argument("--nv", type=int, default=0, help="override the GLOBAL number of variables (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip config.end_to_end (host tables in, proof out; measured after the timed region)")
     ap.add_argument("--time-every", type=int, default=8,
                     help="HIP events around the dominant kernel's launches (the roofline's live duration) on every N-th timed step (at least 4 steps are sampled); 1 = every step")
     ap.add_argument("--launcher", default="auto", choices=("auto", "processes", "threads"),

@@ -55,6 +55,12 @@ def test_bench_line_single_gpu():
     fc = rf["fixed_cost"]
     assert 0 < rf["fixed_cost_ms"] < d["ms_per_step"] and abs(fc["big_round_kernels_ms"] + rf["fixed_cost_ms"] - d["ms_per_step"]) < 1e-9
     assert fc["latency_bound_rounds"] == 19 - 4 and fc["finalize_inside_big_rounds_ms"] >= 0 and fc["turnaround_and_latency_bound_rounds_ms"] > 0
+    # VERDICT r5 item 4 (SURVEY 8d t_end_to_end): host tables in, proof out, measured after the timed region; every such proof equals the timed one
+    ee = d["config"]["end_to_end"]
+    assert ee["proofs_equal_timed_region"] is True and ee["bytes"] == 10 * 32 << 19
+    for kind in ("pageable", "pinned"):
+        e = ee[kind]
+        assert e["h2d_ms"] > 0 and e["staged_total_ms"] > 0 and e["copy_then_prove_total_ms"] > 0 and e["total_ms"] == e["staged_total_ms"]
 
 
 def _two_ranks(extra, launcher=None, timeout=900):
