@@ -389,7 +389,7 @@ def comm_info(sc, comm):
     return r.value, n.value, {1: "rccl", 2: "host-transport", 3: "p2p"}.get(k.value & 0xff, str(k.value)), bool(k.value & 0x100)
 
 
-def end_to_end(sc, _lib, torch, tables, shapes, coefs, nv, dev, want, reps=3):
+def end_to_end(sc, _lib, torch, tables, shapes, coefs, nv, dev, want, reps=5):
     """SURVEY 8d's t_end_to_end: the path a Rust caller takes -- HOST tables in, proof out (`MLSumcheck::prove(&poly)`, mod.rs:42-53, whose
     prover_init deep copy, prover.rs:55-59, is the host-to-device copy here).  Measured AFTER the timed region, never part of `value`:
     the bare copy of the same bytes (pinned and pageable), and whole one-shot proofs from host tables with the staged initialisation

@@ -350,14 +350,16 @@ int staged_copy_and_round1(sc_prover *p, const uint64_t *const *host_tables) {
             if (!p->ev_copied[q]) HIP_TRY(hipEventCreateWithFlags(&p->ev_copied[q], hipEventDisableTiming));
     }
     const uint64_t n = 1ULL << p->nv, n_pairs = n >> 1;
-    // the grid an ordinary round 1 of this shape takes (launch_round), cut into equal sections
+    // the grid an ordinary round 1 of this shape takes (launch_round), cut into sections in proportion to the chunks
     int G = n_pairs >= (1ULL << 21) ? 1024 : n_pairs >= (1ULL << 20) ? 768 : n_pairs >= (1ULL << 18) ? 384 : n_pairs >= (1ULL << 17) ? 256 : 192;
     if (p->K == 1) G = std::min(G, scd::kRoundTreeGrid);
     G = std::min(G, scd::grid_for_pairs(n_pairs));
-    int n_chunks = p->nv >= 21 ? 8 : 4;
-    while (n_chunks > 1 && (G % n_chunks) != 0) n_chunks >>= 1;
-    const int gc = G / n_chunks;
-    const uint64_t chunk = n / (uint64_t)n_chunks; // entries per table and chunk
+    // Chunks of a half, a quarter, ... and the last two of equal size: what is left of round 1 when the last byte has arrived is the
+    // kernel over the LAST chunk alone (1/16 of the tables from 2^21 entries: < 0.1 ms for config 3), and the copy is 5 U calls, not
+    // 2^levels U (each hipMemcpyAsync costs the copy engine a few microseconds between transfers).
+    int levels = p->nv >= 21 ? 4 : 2; // the last chunk is n / 2^levels
+    while (levels > 0 && (G % (1 << levels)) != 0) --levels;
+    const int n_chunks = levels + 1;
     scd::BindConst rc;
     std::memset(&rc, 0, sizeof(rc));
     // (whatever the handle's stream still holds -- a previous proof's last kernels read the buffers the copy overwrites -- goes first)
@@ -365,9 +367,12 @@ int staged_copy_and_round1(sc_prover *p, const uint64_t *const *host_tables) {
     HIP_TRY(hipEventRecord(ev_free, p->stream));
     HIP_TRY(hipStreamWaitEvent(p->copy_stream, ev_free, 0));
     for (int c = 0; c < n_chunks; ++c) {
+        const int sh = c < levels ? c + 1 : levels;
+        const uint64_t chunk = n >> sh, first = n - (n >> c); // entries per table in this chunk, entries before it
+        const int gc = G >> sh, block0 = G - (G >> c);        // its section of the grid
         for (uint32_t u = 0; u < p->U; ++u) {
             if (!host_tables[u]) return sc_internal_fail(SC_ERR_BAD_ARG, "table %u is null", u);
-            HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(p->tabs[u].buf[0]) + (size_t)c * chunk * 32, reinterpret_cast<const char *>(host_tables[u]) + (size_t)c * chunk * 32,
+            HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(p->tabs[u].buf[0]) + (size_t)first * 32, reinterpret_cast<const char *>(host_tables[u]) + (size_t)first * 32,
                                    (size_t)chunk * 32, hipMemcpyHostToDevice, p->copy_stream));
         }
         hipEvent_t ev = p->ev_copied[c & 1];
@@ -386,11 +391,11 @@ int staged_copy_and_round1(sc_prover *p, const uint64_t *const *host_tables) {
                 for (uint32_t rep = 0; rep < pr.exps[s2]; ++rep, ++f) {
                     tp.slot[f].exp = 1;
                     tp.slot[f].mode = 0;
-                    tp.slot[f].src = p->tabs[pr.tables[s2]].buf[0] + 2 * (size_t)c * chunk; // (an element is two uint4)
+                    tp.slot[f].src = p->tabs[pr.tables[s2]].buf[0] + 2 * (size_t)first; // (an element is two uint4)
                 }
         }
         ra.part_stride = (uint32_t)G;
-        ra.part_block0 = (uint32_t)(c * gc);
+        ra.part_block0 = (uint32_t)block0;
         HIP_TRY(scd::launch_round_tree(ra, rc, chunk >> 1, p->d_partials, gc, p->stream, true, false));
     }
     scd::plan_hit(scd::kPlanBigStagedRound1);

@@ -1164,6 +1164,8 @@ WIDE_SHAPES += [
     # more tables than one launch's arguments hold (40 > kMaxSmallTables): test_normal_polynomial's shape, every product over its own tables
     (16, 40, [list(range(0, 4)), list(range(4, 10)), list(range(10, 18)), list(range(18, 28)), list(range(28, 40))]),
     (15, 40, [list(range(8 * k, 8 * k + 8)) for k in range(5)]),
+    # nine-to-twelve trees that share tables with each other and with shorter products, with repeats, behind one bind pass per round
+    (17, 12, [list(range(12)), list(range(9)), [3] * 10, [1, 2, 3, 4], [5, 6, 7, 8, 9, 10, 11, 11], [11, 10, 0, 0, 9, 9, 9, 4, 2, 2, 7]]),
 ]
 
 
@@ -1204,7 +1206,7 @@ def test_wide_products_product_tree_with_node_extension(nv, nt, shapes):
 def test_staged_init_host_tables_round_one_under_the_copy():
     """sc_prover_init over HOST tables of a merged-kernel shape (protocol.hip: staged_copy_and_round1): the tables go in in chunks and round 1
     is computed under the copy -- IPForMLSumcheck::prover_init's deep copy (prover.rs:55-59) and the first prove_round in one pass.  At
-    nv = 22 (config 3's shape; 8 chunks): the interactive rounds with bound tables, whole Fiat-Shamir proofs (one-shot and on a handle),
+    nv = 22 (config 3's shape; chunks of 1/2, 1/4, 1/8, 1/16, 1/16): the interactive rounds with bound tables, whole Fiat-Shamir proofs (one-shot and on a handle),
     a reset onto OTHER tables (the pool's path), the caller's arrays untouched and droppable after init -- all against the oracle, and the
     same with the staged form switched off."""
     nv, shapes, nt = 22, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10

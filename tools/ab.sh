@@ -12,6 +12,7 @@
 #            small        tools/small_proofs.py: whole proofs at nv 8..16 (latency-bound rounds)                     [SC_SHAPE=c3|c2|gkr]
 #            configs      tools/bench_configs.py: BASELINE configs 2, README shape, 5                                (+ config 4 with configs4)
 #            gkr          tools/bench_configs.py --only-gkr
+#            wide         tools/bench_configs.py --wide: products of 5..12 multiplicands at nv=20
 #            interactive  tools/interactive_time.py 8 12 16 20
 #            tailclocks   tools/tail_clocks.py 12 (needs a -DSC_TAIL_CLOCKS build)
 #   -r     repetitions of the bench / small / configs legs (default 3), interleaved across the LIBs
@@ -35,6 +36,7 @@ for rep in $(seq 1 $REPS); do
     if has small; then echo "small $L"; env $(libenv $L) timeout 300 python tools/small_proofs.py 2>&1 | grep "nv="; fi
     if has configs; then echo -n "configs $L  "; env $(libenv $L) timeout 600 python tools/bench_configs.py 2>/dev/null | grep -E "gpu_ms_median" | tr '\n' ' '; echo; fi
     if has configs4; then echo -n "configs4 $L  "; env $(libenv $L) timeout 900 python tools/bench_configs.py --config4 2>/dev/null | grep -E "gpu_ms_median" | tr '\n' ' '; echo; fi
+    if has wide; then echo "wide $L"; env $(libenv $L) timeout 600 python tools/bench_configs.py --wide 2>/dev/null | python -c 'import sys,json; [print("  ",k,round(v["gpu_ms_median"],3),round(v["gpu_ms_min"],3)) for k,v in json.load(sys.stdin).items()]'; fi
     if has gkr; then echo -n "gkr $L  "; env $(libenv $L) timeout 300 python tools/bench_configs.py --only-gkr 2>/dev/null | grep gpu_ms_median | tr '\n' ' '; echo; fi
   done
 done
