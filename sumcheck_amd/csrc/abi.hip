@@ -130,6 +130,9 @@ void prover_destroy(sc_prover *p) {
     }
     if (p->d_chunk_msg) (void)hipFree(p->d_chunk_msg);
     if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+    if (p->copy_stream2) (void)hipStreamDestroy(p->copy_stream2);
+    for (int q = 0; q < 2; ++q)
+        if (p->ev_copied2[q]) (void)hipEventDestroy(p->ev_copied2[q]);
     if (p->tail) prover_destroy(p->tail);
     if (p->d_tail_send) (void)hipFree(p->d_tail_send);
     if (p->d_tail_recv) (void)hipFree(p->d_tail_recv);

@@ -344,40 +344,57 @@ bool staged_init_applies(const sc_prover *p) {
 }
 int staged_copy_and_round1(sc_prover *p, const uint64_t *const *host_tables) {
     HIP_TRY(hipSetDevice(p->device));
-    if (!p->copy_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
-        for (int q = 0; q < 2; ++q)
-            if (!p->ev_copied[q]) HIP_TRY(hipEventCreateWithFlags(&p->ev_copied[q], hipEventDisableTiming));
+    if (!p->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    if (!p->copy_stream2) HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream2, hipStreamNonBlocking));
+    for (int q = 0; q < 2; ++q) {
+        if (!p->ev_copied[q]) HIP_TRY(hipEventCreateWithFlags(&p->ev_copied[q], hipEventDisableTiming));
+        if (!p->ev_copied2[q]) HIP_TRY(hipEventCreateWithFlags(&p->ev_copied2[q], hipEventDisableTiming));
     }
     const uint64_t n = 1ULL << p->nv, n_pairs = n >> 1;
-    // the grid an ordinary round 1 of this shape takes (launch_round), cut into sections in proportion to the chunks
+    // the grid an ordinary round 1 of this shape takes (launch_round), cut into one section per chunk
     int G = n_pairs >= (1ULL << 21) ? 1024 : n_pairs >= (1ULL << 20) ? 768 : n_pairs >= (1ULL << 18) ? 384 : n_pairs >= (1ULL << 17) ? 256 : 192;
     if (p->K == 1) G = std::min(G, scd::kRoundTreeGrid);
     G = std::min(G, scd::grid_for_pairs(n_pairs));
-    // Chunks of a half, a quarter, ... and the last two of equal size: what is left of round 1 when the last byte has arrived is the
-    // kernel over the LAST chunk alone (1/16 of the tables from 2^21 entries: < 0.1 ms for config 3), and the copy is 5 U calls, not
-    // 2^levels U (each hipMemcpyAsync costs the copy engine a few microseconds between transfers).
-    int levels = p->nv >= 21 ? 4 : 2; // the last chunk is n / 2^levels
-    while (levels > 0 && (G % (1 << levels)) != 0) --levels;
-    const int n_chunks = levels + 1;
+    // Chunks of a half, a quarter, ... and the last two of equal size (1/32 of the tables from 2^21 entries, a quarter below): what is
+    // left of round 1 when the last byte has arrived is the kernel over the LAST chunk alone.  The sections of the grid are not in
+    // proportion: the early chunks' kernels hide under the copy whatever their grid, the late ones get an eighth of the blocks each so
+    // that a small chunk still fills the chip (measured with proportional sections: 0.21 ms for 1/16 of config 3 on 64 blocks a product,
+    // against 0.08 ms of work; profiles/r6e_staged_init_timeline.txt).
+    // The copies alternate between two streams by table: a transfer costs the copy engine some 35 us of start-up and turn-around
+    // (60 copies: 2 ms on one stream, against 94 ms of bytes), which a second transfer in flight hides.
+    int levels = p->nv >= 21 ? 5 : 2;
+    int sec[6], n_chunks = levels + 1;
+    if (levels == 5 && G % 8 == 0) {
+        sec[0] = G / 4, sec[1] = G / 8, sec[2] = G / 8;
+        sec[3] = G / 8, sec[4] = G / 8, sec[5] = G / 4; // (the chunk the proof waits for gets a quarter)
+    } else {
+        levels = 2;
+        while (levels > 0 && (G % (1 << levels)) != 0) --levels;
+        n_chunks = levels + 1;
+        for (int c = 0; c < n_chunks; ++c) sec[c] = G >> (c < levels ? c + 1 : levels);
+    }
     scd::BindConst rc;
     std::memset(&rc, 0, sizeof(rc));
     // (whatever the handle's stream still holds -- a previous proof's last kernels read the buffers the copy overwrites -- goes first)
-    hipEvent_t ev_free = p->ev_copied[1];
-    HIP_TRY(hipEventRecord(ev_free, p->stream));
-    HIP_TRY(hipStreamWaitEvent(p->copy_stream, ev_free, 0));
+    HIP_TRY(hipEventRecord(p->ev_copied[1], p->stream));
+    HIP_TRY(hipStreamWaitEvent(p->copy_stream, p->ev_copied[1], 0));
+    HIP_TRY(hipStreamWaitEvent(p->copy_stream2, p->ev_copied[1], 0));
+    int block0 = 0;
     for (int c = 0; c < n_chunks; ++c) {
         const int sh = c < levels ? c + 1 : levels;
         const uint64_t chunk = n >> sh, first = n - (n >> c); // entries per table in this chunk, entries before it
-        const int gc = G >> sh, block0 = G - (G >> c);        // its section of the grid
+        const int gc = sec[c];                                // its section of the grid
         for (uint32_t u = 0; u < p->U; ++u) {
             if (!host_tables[u]) return sc_internal_fail(SC_ERR_BAD_ARG, "table %u is null", u);
             HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(p->tabs[u].buf[0]) + (size_t)first * 32, reinterpret_cast<const char *>(host_tables[u]) + (size_t)first * 32,
-                                   (size_t)chunk * 32, hipMemcpyHostToDevice, p->copy_stream));
+                                   (size_t)chunk * 32, hipMemcpyHostToDevice, (u & 1) ? p->copy_stream2 : p->copy_stream));
         }
-        hipEvent_t ev = p->ev_copied[c & 1];
-        HIP_TRY(hipEventRecord(ev, p->copy_stream));
-        HIP_TRY(hipStreamWaitEvent(p->stream, ev, 0));
+        HIP_TRY(hipEventRecord(p->ev_copied[c & 1], p->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_copied[c & 1], 0));
+        if (p->U > 1) {
+            HIP_TRY(hipEventRecord(p->ev_copied2[c & 1], p->copy_stream2));
+            HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_copied2[c & 1], 0));
+        }
         scd::RoundArgs ra;
         std::memset(&ra, 0, sizeof(ra));
         ra.n_prod = (int)p->K;
@@ -397,7 +414,9 @@ int staged_copy_and_round1(sc_prover *p, const uint64_t *const *host_tables) {
         ra.part_stride = (uint32_t)G;
         ra.part_block0 = (uint32_t)block0;
         HIP_TRY(scd::launch_round_tree(ra, rc, chunk >> 1, p->d_partials, gc, p->stream, true, false));
+        block0 += gc;
     }
+    if (block0 != G) return sc_internal_fail(SC_ERR_HIP, "staged initialisation: the sections do not cover the grid");
     scd::plan_hit(scd::kPlanBigStagedRound1);
     const bool keeps = scd::finalize_keeps_sums((int)p->K, (int)p->D, G, !p->h_finprods.empty(), fin_mb_enabled());
     HIP_TRY(scd::launch_finalize(p->d_finprods, p->h_finprods.data(), p->d_W, (int)p->K, (int)p->D, G, p->d_partials, keeps ? p->d_sums[1] : p->d_scratch, p->d_out, nullptr,

@@ -197,6 +197,8 @@ struct sc_prover {
     std::vector<const uint64_t *> host_tabs;
     void *ring[2] = {nullptr, nullptr};   // U x 2^chunk_log2 x 32 bytes each
     hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream2 = nullptr;                      // staged initialisation: the odd tables' copies (a second transfer in flight hides the first one's start-up)
+    hipEvent_t ev_copied2[2] = {nullptr, nullptr};
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     FrHost *d_chunk_msg = nullptr;        // a chunk's message, and the running sum over the chunks (2 x D elements)
     // staged initialisation (host tables copied in chunks, round 1 computed under the copy: staged_copy_and_round1): round 1's message is

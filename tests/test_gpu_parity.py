@@ -1203,13 +1203,14 @@ def test_wide_products_product_tree_with_node_extension(nv, nt, shapes):
         assert after[key] > before[key] and after["big.wide"] == before["big.wide"] and after["big.wide16"] == before["big.wide16"]
 
 
-def test_staged_init_host_tables_round_one_under_the_copy():
+@pytest.mark.parametrize("nv", [22, 19])
+def test_staged_init_host_tables_round_one_under_the_copy(nv):
     """sc_prover_init over HOST tables of a merged-kernel shape (protocol.hip: staged_copy_and_round1): the tables go in in chunks and round 1
     is computed under the copy -- IPForMLSumcheck::prover_init's deep copy (prover.rs:55-59) and the first prove_round in one pass.  At
-    nv = 22 (config 3's shape; chunks of 1/2, 1/4, 1/8, 1/16, 1/16): the interactive rounds with bound tables, whole Fiat-Shamir proofs (one-shot and on a handle),
+    nv = 22 (config 3's shape; chunks of 1/2 ... 1/32, 1/32 on two copy streams) and nv = 19 (1/2, 1/4, 1/4): the interactive rounds with bound tables, whole Fiat-Shamir proofs (one-shot and on a handle),
     a reset onto OTHER tables (the pool's path), the caller's arrays untouched and droppable after init -- all against the oracle, and the
     same with the staged form switched off."""
-    nv, shapes, nt = 22, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10
+    shapes, nt = [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10
     tabs = [cref.synth_table(6100, s, 1 << nv) for s in range(nt)]
     tabs2 = [cref.synth_table(6200, s, 1 << nv) for s in range(nt)]
     coefs = cref.synth_table(6100, 1000, len(shapes))
