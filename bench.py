@@ -745,7 +745,7 @@ def run_rank(args, W, result):
                                   f"{kj.get('bench_py_sha')}, git {kj.get('git_head')}); running csrc_sha {shas['csrc_sha']} / bench_py_sha {shas['bench_py_sha']}")
             else:
                 rocprof = kj
-                rocprof_source = (f"rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5` on this tree (csrc_sha {shas['csrc_sha']}, bench_py_sha "
+                rocprof_source = (f"rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-end-to-end` on this tree (csrc_sha {shas['csrc_sha']}, bench_py_sha "
                                   f"{shas['bench_py_sha']}, git {kj.get('git_head')}): {kj.get('stats_csv')}, {kj['launches']} launches, via profiles/rocprof_kernel_latest.json")
         except Exception as e:
             rocprof_source = f"not used: {type(e).__name__}: {e}"

@@ -109,7 +109,7 @@ SC_API int sc_prove_round(sc_prover *p, const uint64_t *r_or_null, uint64_t *out
  * its challenge and takes the next message.  The kernel's patience is short, `patience_polls` polls of ~2 us (default 256; 0 = never
  * use a resident kernel): a verifier that takes longer finds it gone -- it leaves after the last round it completed -- and the call
  * proceeds with ordinary launches.  Any other call on the handle makes it leave first.  Not used while sc_prover_set_timing is on,
- * on a caller's stream, with sc_prover_set_polling(p, 0) / SC_PIPELINE=0, or with SC_RESIDENT=0 in the environment.) */
+ * on a caller's stream, with sc_prover_set_polling(p, 0) / sc_set_policy("pipeline", 0), or with sc_set_policy("resident", 0).) */
 SC_API int sc_prover_set_resident(sc_prover *p, uint32_t patience_polls);
 /* MLSumcheck::prove_as_subprotocol pushes the final challenge without binding it (mod.rs:65-67). */
 SC_API int sc_prover_push_randomness(sc_prover *p, const uint64_t *r);
@@ -128,14 +128,14 @@ SC_API int sc_prover_set_stream(sc_prover *p, void *hip_stream, int use_own);
  * kernel waits, the calling thread must be able to finish its HIP calls.  The library's own threads are serialised per device (see
  * THREADING); HIP calls made by OTHER code of the process on the same device (hipMalloc / hipFree / synchronous copies take
  * process-wide locks inside the runtime) can hold the calling thread up.  What then happens, in this order:
- *   - nothing, if the delay is shorter than the wait's bound (seconds; SC_WAIT_SPINS): the proof is slower, never different;
+ *   - nothing, if the delay is shorter than the wait's bound (seconds; policy "wait_spins"): the proof is slower, never different;
  *   - the wait expires: messages computed on a stale challenge are never returned.  A handle whose inputs are intact (borrowed or
  *     streamed tables) proves again from round 0 with synchronous rounds inside the same call; a copying handle returns SC_ERR_HIP
  *     ("... the proof is void") and must be reset with its tables.
  * A host that runs its own HIP work on the device concurrently (a Rust application with its own streams, an ML framework) should
  * switch the device-side waits off for its handles: allow = 0 makes every round of this handle launch after its challenge is known
- * (about 0.3 ms more per 24-variable proof, no kernel ever waits for the host, nothing can expire).  SC_PIPELINE=0 in the
- * environment does the same for every handle of the process.  Returns SC_OK; the setting holds until changed. */
+ * (about 0.3 ms more per 24-variable proof, no kernel ever waits for the host, nothing can expire).  sc_set_policy("pipeline", 0)
+ * does the same for every handle of the process.  Returns SC_OK; the setting holds until changed. */
 SC_API int sc_prover_set_polling(sc_prover *p, int allow);
 
 /* Sharded use: this handle holds one contiguous high-bit shard of every table.
@@ -195,7 +195,7 @@ SC_API void sc_comm_free(sc_comm *comm);
 #define SC_COMM_HOST 2
 #define SC_COMM_P2P 3
 #define SC_COMM_DIRECT_PUBLISH 0x100 /* flag on SC_COMM_RCCL: the communicator's all-reduces deliver a round's (tagged) lanes straight into the
-                                      * host-mapped page the host polls -- no publishing kernel behind them (probed by sc_comm_init; SC_RCCL_DIRECT=0
+                                      * host-mapped page the host polls -- no publishing kernel behind them (probed by sc_comm_init; sc_set_policy("rccl_direct", 0)
                                       * switches it off) */
 SC_API int sc_comm_info(sc_comm *comm, int *rank_out, int *nranks_out, int *kind_out);
 /* measurement, collective (every rank calls it): `iters` back-to-back exchanges of n_words (<= 64) uint64 lanes in exactly the form a
@@ -236,7 +236,7 @@ SC_API void sc_rng_sample_fr(sc_rng *rng, uint64_t *out);                       
  * the calling thread only hashes and answers.  Every device-side wait is bounded (seconds); if the calling thread is stalled for
  * longer, messages computed on a stale challenge are never returned: a handle whose inputs are still there (borrowed or streamed
  * tables) proves again from round 0 with synchronous rounds inside the same call; otherwise the call returns SC_ERR_HIP ("... the
- * proof is void") -- reset the handle with its tables and prove again.  SC_PIPELINE=0 in the environment (or a runtime that serialises kernel launches, e.g. a counter-collecting
+ * proof is void") -- reset the handle with its tables and prove again.  sc_set_policy("pipeline", 0) (or a runtime that serialises kernel launches, e.g. a counter-collecting
  * profiler, detected by a probe) turns all of it off: every round is then launched after its challenge is known. */
 SC_API int sc_ml_prove(const sc_poly_desc *desc, sc_rng *rng_or_null, uint64_t *out_proof, sc_prover **out_state_or_null);
 /* (One-shot use -- MLSumcheck::prove(&poly) in a loop -- does not pay for a prover per call: the library keeps the last one it built
@@ -358,6 +358,8 @@ SC_API int sc_library_stats(uint64_t *out, uint32_t n);
  *                            gathers onto every rank; must be the same on every rank
  *   "gkr_direct" (1)         0: sc_gkr_prove initialises through sort + merge (the list form) instead of the bucketed kernels
  *   "wait_spins" (2^22)      bound of a device-side wait for a challenge, in polls (tests shorten it to exercise the give-up path)
+ *   "staged_init" (1)        0: sc_prover_init over HOST tables copies them whole before round 1 instead of in chunks with round 1 computed
+ *                            under the copy (shapes of the merged big-round kernel from 2^18 entries per table)
  * Unknown key or value out of range: SC_ERR_BAD_ARG. */
 SC_API int sc_set_policy(const char *key, int64_t value);
 SC_API int sc_get_policy(const char *key, int64_t *value);

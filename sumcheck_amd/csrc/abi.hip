@@ -8,7 +8,7 @@
 // error plumbing
 // ---------------------------------------------------------------------------------------------------
 // How long a host loop waits for a round's message (or a peer's lanes) before it declares the proof dead: sc_set_publish_timeout_ms,
-// SC_PUBLISH_TIMEOUT_MS in the environment, 20 s by default (a device-side wait's own bound -- SC_WAIT_SPINS -- expires long before).
+// SC_PUBLISH_TIMEOUT_MS in the environment, 20 s by default (a device-side wait's own bound -- policy "wait_spins" -- expires long before).
 static std::atomic<uint32_t> g_publish_timeout_ms{0}; // 0: not set yet
 std::chrono::milliseconds publish_timeout() {
     uint32_t ms = g_publish_timeout_ms.load(std::memory_order_relaxed);

@@ -49,7 +49,7 @@ bool launches_are_async(sc_prover *p) {
 }
 
 // The host-mapped mailbox (two challenge slots + the signal word the device polls) of the pipelined rounds and of the persistent
-// tail kernel.  First use sets it up; any failure -- or a runtime that serialises launches, or SC_PIPELINE=0 -- switches both off
+// tail kernel.  First use sets it up; any failure -- or a runtime that serialises launches, or sc_set_policy("pipeline", 0) -- switches both off
 // for this handle.
 bool ensure_mailbox(sc_prover *p) {
     if (!p->pipeline_ok) return false;
@@ -97,7 +97,7 @@ bool skip1_enabled() {
     return true;
 #endif
 }
-// products of five to eight multiplicands as a product tree with node extension (kernels_wide.hip); SC_WIDE_TREE=0: node by node (k_prod_round_fe)
+// products of five to eight multiplicands as a product tree with node extension (kernels_wide.hip); sc_set_policy("wide_tree", 0): node by node (k_prod_round_fe)
 bool wide_tree_enabled() {
     return scd::policy(scd::kPolWideTree) != 0;
 }
@@ -878,7 +878,7 @@ int await_round(sc_prover *p, uint64_t *out_evals, const uint32_t want) {
 
 // ---- the persistent tail: every remaining latency-bound round in ONE kernel launch (kernels.hip: k_tail_rounds) -------------
 // Usable when the round metadata fits kernel arguments (tail_shape_ok), the next round is a small one, and launches are
-// asynchronous (the kernel waits for the host; SC_PIPELINE=0 switches it off together with the pipelined rounds).
+// asynchronous (the kernel waits for the host; sc_set_policy("pipeline", 0) switches it off together with the pipelined rounds).
 constexpr size_t kTailSyncBytes = 4 * (16 + (size_t)scd::kTailMaxGrid);
 // ONE tail kernel per device at a time: its grid barrier needs every launched block resident, and the grid is sized for an otherwise
 // idle GPU (tail_max_resident_blocks); two of them from two proving threads could each end up partially resident and wait for
@@ -959,7 +959,7 @@ bool tail_possible(sc_prover *p, bool slices = false) {
 // Launch k_tail_rounds for the handle's next n_rounds rounds (the caller holds the device gate and the device's tail slot);
 // r_or_null = the challenge the first of them binds; max_spins = how long block 0 waits for each later challenge.
 // The tables resident in LDS for the whole tail (kernels_tail.hip: k_tail_slices) where the shape allows: every product in carry-free
-// arithmetic, the slices within a CU's LDS.  SC_TAIL_SLICES=0: k_tail_rounds everywhere (A/B runs, tests of the older path).
+// arithmetic, the slices within a CU's LDS.  sc_set_policy("tail_slices", 0): k_tail_rounds everywhere (A/B runs, tests of the older path).
 int tail_slices_blocks_for(sc_prover *p) {
     if (scd::policy(scd::kPolTailSlices) == 0 || p->max_mult > (uint32_t)(p->wide_tree ? scd::kMaxWideM : scd::kMaxFusedM) || p->round >= p->nv) return 0;
     const int B = scd::tail_slices_blocks(1ULL << (p->nv - (p->round + 1)), (int)p->U, (int)p->K, (int)p->D, p->n_combos, (int)p->max_mult,
@@ -974,7 +974,7 @@ int tail_slices_blocks_for(sc_prover *p) {
             return 0;
         }
         p->ts_tag = 1;
-        // the mailbox in device memory, where the host may store into it (SC_VRAM_MAILBOX=0: block 0 polls the host-mapped one and passes it on)
+        // the mailbox in device memory, where the host may store into it (sc_set_policy("vram_mailbox", 0): block 0 polls the host-mapped one and passes it on)
         int large_bar = 0;
         if (scd::policy(scd::kPolVramMailbox) != 0 && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, p->device) == hipSuccess && large_bar) {
             void *m = nullptr;

@@ -170,7 +170,7 @@ struct sc_prover {
     uint64_t arena_bytes = 0;       // size of the bound-table arena (what a pooled handle keeps allocated)
     std::vector<uint8_t> pool_key;  // non-empty: created by sc_ml_prove; sc_prover_free offers it back to the pool (handle_pool_*)
     uint32_t n_retries = 0;         // proofs repeated after an expired device-side wait (sc_ml_prove_handle)
-    bool pipeline_ok = true;        // cleared when the wait-value path is unavailable (or SC_PIPELINE=0, SC_NO_DEVICE_POLLING, sc_prover_set_polling(p, 0))
+    bool pipeline_ok = true;        // cleared when the wait-value path is unavailable (or sc_set_policy("pipeline", 0), SC_NO_DEVICE_POLLING, sc_prover_set_polling(p, 0))
     bool polling_off_by_caller = false; // ... by the caller: survives what re-enables pipeline_ok internally
     // the interactive sc_prove_round's resident kernel (k_tail_rounds kept across calls: see resident_start)
     struct Resident {
@@ -181,7 +181,7 @@ struct sc_prover {
     uint32_t resident_spins = kResidentSpinsDefault; // its patience for the next call, in polls of the host-mapped mailbox (~2 us each); 0: not used
     bool deferred_pending = false;  // a round is enqueued behind the wait and still needs its challenge
     bool fused_finalize = false;    // experiments, SC_FUSED_FIN=1: the merged big-round launch finalizes in-kernel (measured: slower than the k_finalize launch)
-    bool use_tail = true;           // sc_ml_prove* / GKR: the latency-bound rounds run in the persistent tail kernel (SC_TAIL=0: pipelined launches)
+    bool use_tail = true;           // sc_ml_prove* / GKR: the latency-bound rounds run in the persistent tail kernel (sc_set_policy("tail", 0): pipelined launches)
     bool merge_rounds = false; // big rounds run as ONE launch over all products (k_round_tree): <= kMaxRoundProds products of <= 4 multiplicands
     bool wide_tree = true; // products of 5..12 multiplicands as trees (policy "wide_tree" when the handle was built)
     bool use_f29 = false; // bound tables of big rounds kept in the internal 9 x 29-bit format (all products <= 4 multiplicands)

@@ -39,7 +39,7 @@ w = {"calls": sum(counters["WRITE_SIZE"][k]["calls"] for k in keys), "sum_KB": s
 try:
     cmdline = open(os.path.join(base, "command.txt")).read().strip()
 except OSError:
-    cmdline = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+    cmdline = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end"
 try:
     pmc_cmdline = open(os.path.join(base, "command_pmc.txt")).read().strip()
 except OSError:

@@ -6,6 +6,7 @@
 TAG=${1:?tag}
 cd "$(dirname "$0")/.."
 timeout 1800 python -m pytest tests -q -m gpu --durations=10 > gpurun_out/${TAG}_gpu_suite.log 2>&1; grep -E "passed|failed" gpurun_out/${TAG}_gpu_suite.log | tail -1
+cp gpurun_out/plan_coverage.json gpurun_out/${TAG}_plan_coverage.json 2>/dev/null  # (the plan -> oracle-comparing tests table of THIS full run: tests/conftest.py; later partial runs overwrite the plain name)
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 bash tools/profile.sh $TAG 2>&1 | tail -2
 python tools/collect_profiles.py $TAG 2>&1 | tail -1
