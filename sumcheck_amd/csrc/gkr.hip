@@ -771,9 +771,14 @@ int stage_in(DevBuf &mem, const void *src, uint64_t n, bool on_device, const T *
     return SC_OK;
 }
 // every index below 2^bits (bits < 64); host arrays are checked on the host, device arrays by a kernel
+// (meanwhile: work the caller wants on the device while the host waits for the verdict; it must not depend on the indices being valid)
 int check_index_range(DevBuf &mem, const uint64_t *idx, uint64_t n, uint32_t bits, bool on_device, const char *what, hipStream_t s,
-                      bool *sorted_out = nullptr) {
+                      bool *sorted_out = nullptr, const std::function<int()> *meanwhile = nullptr) {
     if (sorted_out) *sorted_out = true;
+    if (bits >= 64 || n == 0 || !on_device) {
+        int rc_m = meanwhile ? (*meanwhile)() : SC_OK;
+        if (rc_m) return rc_m;
+    }
     if (bits >= 64 || n == 0) return SC_OK;
     if (!on_device) {
         bool sorted = true;
@@ -788,8 +793,15 @@ int check_index_range(DevBuf &mem, const uint64_t *idx, uint64_t n, uint32_t bit
     G_TRY(mem.alloc(&d_flag, 1));
     G_TRY(hipMemsetAsync(d_flag, 0, sizeof(unsigned int), s));
     hipLaunchKernelGGL(k_idx_range, dim3(grid_for(n)), dim3(kBlock), 0, s, idx, n, bits, d_flag);
-    G_TRY(hipMemcpyAsync(&h, d_flag, sizeof(h), hipMemcpyDeviceToHost, s));
+    // (into pinned memory where the caller holds the cache's page: a copy into pageable memory waits for the device inside the call)
+    unsigned int *h_dst = (mem.leased && g_cache.h_pin) ? g_cache.h_pin + 1 : &h;
+    G_TRY(hipMemcpyAsync(h_dst, d_flag, sizeof(h), hipMemcpyDeviceToHost, s));
+    if (meanwhile) {
+        int rc_m = (*meanwhile)();
+        if (rc_m) return rc_m;
+    }
     G_TRY(hipStreamSynchronize(s));
+    h = *h_dst;
     if (h & 1u) return sc_internal_fail(SC_ERR_BAD_ARG, "%s has an index out of range", what);
     if (sorted_out) *sorted_out = !(h & 2u);
     return SC_OK;
@@ -1387,7 +1399,21 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     DevBuf mem;
     (void)mem.reserve(gkr_scratch_estimate(nnz, 1ULL << dim));
     bool f1_sorted = true;
-    if ((rc = check_index_range(mem, f1_idx, nnz, 3 * dim, dev, "f1", s, &f1_sorted))) return rc;
+    if (mem.leased) { // the cache's second stream and pinned page (the index check's verdict and phase two's plan verdict land there)
+        if (!g_cache.side && hipStreamCreateWithFlags(&g_cache.side, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            g_cache.side = nullptr;
+        }
+        if (g_cache.side && !g_cache.h_pin && hipHostMalloc(reinterpret_cast<void **>(&g_cache.h_pin), 64, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            g_cache.h_pin = nullptr;
+        }
+    }
+    // the eq(g, .) tables need only g: they are built while the host waits for the verdict on the indices
+    bool direct = bucketed_form_pays(nnz, dim);
+    EqSplit eq_g{nullptr, nullptr, 0}, eq_u{nullptr, nullptr, 0};
+    const std::function<int()> eq_meanwhile = [&]() -> int { return direct ? build_eq_split(mem, reinterpret_cast<const sch::Fr *>(g), dim, &eq_g, s) : SC_OK; };
+    if ((rc = check_index_range(mem, f1_idx, nnz, 3 * dim, dev, "f1", s, &f1_sorted, &eq_meanwhile))) return rc;
     const bool trace = std::getenv("SC_GKR_TRACE") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -1421,18 +1447,9 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
     lap("h2d");
     // Bucketed initialisation (k_bucket_accumulate) whenever the list is dense enough for 2^dim cells to be worth a pass; the list form (sort, merge, scatter:
     // what sc_gkr_phase_one returns to a caller) otherwise, and when a bucket is too crowded.  sc_set_policy("gkr_direct", 0) forces the list form.
-    bool direct = bucketed_form_pays(nnz, dim);
     hipStream_t side = s;
     unsigned int skew2_local = 0, *h_skew2 = &skew2_local;
     if (mem.leased) {
-        if (!g_cache.side && hipStreamCreateWithFlags(&g_cache.side, hipStreamNonBlocking) != hipSuccess) {
-            (void)hipGetLastError();
-            g_cache.side = nullptr;
-        }
-        if (g_cache.side && !g_cache.h_pin && hipHostMalloc(reinterpret_cast<void **>(&g_cache.h_pin), 64, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            g_cache.h_pin = nullptr;
-        }
         if (g_cache.side && g_cache.h_pin) { // (a copy into pinned memory does not hold the host: the plan below runs beside phase one)
             side = g_cache.side;
             h_skew2 = g_cache.h_pin;
@@ -1445,15 +1462,13 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
             if (st) (void)hipStreamSynchronize(st);
         }
     } join{side != s ? side : nullptr};
-    EqSplit eq_g{nullptr, nullptr, 0}, eq_u{nullptr, nullptr, 0};
     uint64_t n1 = 0;
     bool have_list = false; // f1(g,.,.) as a merged list in d_gi / d_gv (list form only)
     // Phase two's bucket plan depends on the indices only: it runs now, on the second stream, while phase one has the device (a call without
     // the cache's stream runs it in line; phase one's synchronisation below covers it then).
     if (direct && (rc = bucket_plan<2>(mem, d_idx, nnz, dim, f1_sorted, &plan2, h_skew2, side))) return rc;
     if (direct) {
-        if ((rc = build_eq_split(mem, reinterpret_cast<const sch::Fr *>(g), dim, &eq_g, s))) return rc;
-        // (the pass leaves eq(g,z) * v behind, per non-zero, in d_gv -- the list form's value buffer, unused on this route: phase two's input)
+        // (eq(g, .) was built during the index check; the pass leaves eq(g,z) * v behind, per non-zero, in d_gv -- the list form's value buffer, unused on this route: phase two's input)
         d_a = d_gv;
         if ((rc = bucketed_dense<1>(mem, d_idx, d_vals, nnz, dim, eq_g, eq_u, d_f3, f1_sorted, d_hg, &direct, s, d_a))) return rc; // mod.rs:30-38
     }
@@ -1465,11 +1480,13 @@ extern "C" int sc_gkr_prove(sc_rng *rng, const uint64_t *f1_idx, const uint64_t 
         return phase_one_device(mem, d_idx_s, d_vals_s, nnz, dim, d_f3, reinterpret_cast<const sch::Fr *>(g), d_hg, d_gi, d_gv, d_n1, &n1, s); // mod.rs:106
     };
     if (!direct && (rc = list_form())) return rc;
-    G_TRY(hipStreamSynchronize(s));
-    lap("phase one init");
     std::vector<sch::Fr> u(dim), v(dim);
     ProverGuard pg;
     pg.take_cached(dim, mem.leased);
+    // (phase one's sumcheck runs on the prover's stream, which is not ordered behind `s`: the host waits.  Ordering the prover's stream behind an
+    // event on `s` instead was measured in round 6: the cross-queue dependency costs more than the wake-up it saves, 1.02 against 0.98 ms)
+    G_TRY(hipStreamSynchronize(s));
+    lap("phase one init");
     if ((rc = run_phase(rng->rng, &pg.p, d_hg, d_f2, dim, out_proof, u.data()))) return rc; // mod.rs:107-119
     lap("phase one sumcheck");
     // f2.evaluate(&u) (mod.rs:122) is not recomputed: phase one's prover has bound f2 at u_0..u_{dim-2} (prover.rs:84-89), its final table {lo, hi}

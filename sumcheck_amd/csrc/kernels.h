@@ -282,7 +282,7 @@ enum Plan {
 };
 void plan_hit(int plan);
 hipError_t launch_scale_w_by_table_eval(FrHost *W, const FrHost *W0, uint32_t n, const void *table, const FrHost &r, hipStream_t stream); // W = W0 * table(r)
-hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream); // (a plain kernel: hipMemsetAsync may take runtime paths that wait on other streams)
+hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream, uint32_t *p2 = nullptr, uint32_t n2 = 0); // (a plain kernel: hipMemsetAsync may take runtime paths that wait on other streams)
 hipError_t launch_tail_rounds(const TailArgs &args, const ComboMeta &meta, const FinMeta &fin, int grid, hipStream_t stream);
 
 int grid_for_pairs(uint64_t n_pairs);

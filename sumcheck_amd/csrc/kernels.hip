@@ -711,11 +711,13 @@ int tail_max_resident_blocks(int device) {
     return cached;
 }
 
-__global__ void k_zero_words(uint32_t *p, const uint32_t n) {
+// (two regions in one launch: k_tail_slices' synchronisation words and its accumulator ring -- a second launch is 5-8 us on the critical path)
+__global__ void k_zero_words(uint32_t *p, const uint32_t n, uint32_t *p2, const uint32_t n2) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += gridDim.x * blockDim.x) p2[i] = 0u;
 }
-hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream) {
-    hipLaunchKernelGGL(k_zero_words, dim3(4), dim3(256), 0, stream, p, n);
+hipError_t launch_zero_words(uint32_t *p, uint32_t n, hipStream_t stream, uint32_t *p2, uint32_t n2) {
+    hipLaunchKernelGGL(k_zero_words, dim3(4), dim3(256), 0, stream, p, n, p2, p2 ? n2 : 0u);
     return hipGetLastError();
 }
 

@@ -1027,9 +1027,9 @@ int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null, uint3
         const uint64_t sum_blocks = ((A.first_pairs + scd::kBlock - 1) / scd::kBlock) * (uint64_t)p->n_combos;
         grid = (int)std::min<uint64_t>((uint64_t)p->tail_max_blocks, std::max(bind_blocks, sum_blocks));
     }
-    HIP_TRY(scd::launch_zero_words(p->d_tail_sync, (uint32_t)((kTailSyncBytes + 64) / 4), p->stream));
     if (slices_B > 0) {
-        HIP_TRY(scd::launch_zero_words(reinterpret_cast<uint32_t *>(p->d_tail_xw), (uint32_t)(scd::kTsAccWords * 2), p->stream)); // the accumulator ring
+        HIP_TRY(scd::launch_zero_words(p->d_tail_sync, (uint32_t)((kTailSyncBytes + 64) / 4), p->stream, reinterpret_cast<uint32_t *>(p->d_tail_xw),
+                                       (uint32_t)(scd::kTsAccWords * 2))); // ... and the accumulator ring, in the same launch
         scd::TailSlicesArgs S;
         std::memset(&S, 0, sizeof(S));
         S.base = A;
@@ -1042,6 +1042,7 @@ int tail_launch(sc_prover *p, uint32_t n_rounds, const sch::Fr *r_or_null, uint3
         HIP_TRY(scd::launch_tail_slices(S, p->meta, fm, (int)p->max_mult, p->stream));
         return SC_OK;
     }
+    HIP_TRY(scd::launch_zero_words(p->d_tail_sync, (uint32_t)((kTailSyncBytes + 64) / 4), p->stream));
     HIP_TRY(scd::launch_tail_rounds(A, p->meta, fm, grid, p->stream));
     return SC_OK;
 }
