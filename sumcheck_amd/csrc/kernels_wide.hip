@@ -16,7 +16,7 @@ namespace scd {
 
 constexpr int kWideBlock = 256;
 template <int M>
-__global__ __launch_bounds__(kWideBlock) void k_prod_tree_wide(const ProdArgs P, const BindConst r, const uint64_t n_pairs, uint4 *__restrict__ partials) {
+__device__ __forceinline__ void prod_tree_wide_body(const ProdArgs &P, const BindConst &r, const uint64_t n_pairs, uint4 *__restrict__ partials) {
     static_assert(M >= 5 && M <= 8, "five to eight multiplicands");
     __shared__ uint32_t sm[kWideBlock / 64][8];
     __shared__ int32_t rt[kBindLds];
@@ -87,11 +87,30 @@ __global__ __launch_bounds__(kWideBlock) void k_prod_tree_wide(const ProdArgs P,
 }
 
 template <int M>
+__global__ __launch_bounds__(kWideBlock) void k_prod_tree_wide(const ProdArgs P, const BindConst r, const uint64_t n_pairs, uint4 *__restrict__ partials) {
+    prod_tree_wide_body<M>(P, r, n_pairs, partials);
+}
+// Seven multiplicands: 281 registers as the compiler schedules it freely -- one wavefront per SIMD -- although two blocks' running sums
+// (74 KB each) fit a CU's LDS.  Held to 256 registers (18 of them spilled) two blocks are resident: the 4 / 5 / 6 / 7 / 8 mix at nv = 20
+// 2.98 -> 2.88 ms on the same box (profiles/r6i_wide_occupancy_ab.txt).  Eight multiplicands stay as they are: their 83 KB of running sums
+// allow one block per CU whatever the registers, and the spills alone cost 4 % (4.52 -> 4.69 ms for five products of eight).
+template <int M>
+__global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_prod_tree_wide_two_blocks(const ProdArgs P, const BindConst r, const uint64_t n_pairs,
+                                                                                                                uint4 *__restrict__ partials) {
+    prod_tree_wide_body<M>(P, r, n_pairs, partials);
+}
+
+template <int M>
 static hipError_t launch_wide_t(const ProdArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
     const size_t lds = (size_t)9 * (M + 1) * kWideBlock * 4;
     static bool attr_set[64] = {}; // (more dynamic LDS than the default limit of a launch: 55-83 KB of running sums); per device
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_prod_tree_wide<M>), (int)lds, attr_set); e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_prod_tree_wide<M>, dim3(grid), dim3(kWideBlock), lds, stream, args, rc, n_pairs, (uint4 *)d_partials);
+    if constexpr (M == 7) {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_prod_tree_wide_two_blocks<M>), (int)lds, attr_set); e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_prod_tree_wide_two_blocks<M>, dim3(grid), dim3(kWideBlock), lds, stream, args, rc, n_pairs, (uint4 *)d_partials);
+    } else {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_prod_tree_wide<M>), (int)lds, attr_set); e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_prod_tree_wide<M>, dim3(grid), dim3(kWideBlock), lds, stream, args, rc, n_pairs, (uint4 *)d_partials);
+    }
     return hipGetLastError();
 }
 
