@@ -15,28 +15,42 @@
 namespace scd {
 
 constexpr int kWideBlock = 256;
-template <int M>
+// kPairSums: adjacent lanes add their node products (one DPP add per limb) and the even lane alone keeps the running sum -- half the LDS, so
+// that two blocks of an eight-multiplicand product fit a CU (2 x 41.5 KB instead of 83 KB each)
+template <int M, bool kPairSums = false>
 __device__ __forceinline__ void prod_tree_wide_body(const ProdArgs &P, const BindConst &r, const uint64_t n_pairs, uint4 *__restrict__ partials) {
     static_assert(M >= 5 && M <= 8, "five to eight multiplicands");
+    constexpr int kCols = kPairSums ? kWideBlock / 2 : kWideBlock;
     __shared__ uint32_t sm[kWideBlock / 64][8];
     __shared__ int32_t rt[kBindLds];
-    extern __shared__ int32_t wide_lacc[]; // the M + 1 running sums, limb-planar, one column per thread (private: no barrier)
+    extern __shared__ int32_t wide_lacc[]; // the M + 1 running sums, limb-planar, one column per thread or lane pair (private: no barrier)
     bind_consts_to_lds(r, rt);
     __syncthreads();
-    int32_t *my = wide_lacc + threadIdx.x;
+    int32_t *my = wide_lacc + (kPairSums ? threadIdx.x >> 1 : threadIdx.x);
+    const bool keeper = !kPairSums || (threadIdx.x & 1u) == 0;
+    if (keeper) {
 #pragma unroll
-    for (int i = 0; i < 9 * (M + 1); ++i) my[i * kWideBlock] = 0;
+        for (int i = 0; i < 9 * (M + 1); ++i) my[i * kCols] = 0;
+    }
     const uint64_t stride = (uint64_t)gridDim.x * kWideBlock;
     uint32_t iter = 0;
+    // (n_pairs and the stride are even: the two lanes of a pair leave the loop together)
     for (uint64_t b = (uint64_t)blockIdx.x * kWideBlock + threadIdx.x; b < n_pairs; b += stride, ++iter) {
-        auto accumulate = [&](const int t, const Fe &v) {
-            Fe acc;
+        auto accumulate = [&](const int t, const Fe &v_in) {
+            Fe v = v_in;
+            if constexpr (kPairSums) {
 #pragma unroll
-            for (int l = 0; l < 9; ++l) acc.l[l] = my[(9 * t + l) * kWideBlock];
-            acc = fe_carry_pass(fe_add(acc, v));
-            if ((iter & 31u) == 31u) acc = fe_from_fr(fe_to_fr(acc)); // keep the top limb far from 2^31 on long grid-stride loops
+                for (int l = 0; l < 9; ++l) v.l[l] += __builtin_amdgcn_mov_dpp(v_in.l[l], 0xB1, 0xF, 0xF, true); // quad_perm [1, 0, 3, 2]: the neighbour's limb
+            }
+            if (keeper) {
+                Fe acc;
 #pragma unroll
-            for (int l = 0; l < 9; ++l) my[(9 * t + l) * kWideBlock] = acc.l[l];
+                for (int l = 0; l < 9; ++l) acc.l[l] = my[(9 * t + l) * kCols];
+                acc = fe_carry_pass(fe_add(acc, v));
+                if ((iter & (kPairSums ? 15u : 31u)) == (kPairSums ? 15u : 31u)) acc = fe_from_fr(fe_to_fr(acc)); // keep the top limb far from 2^31 on long grid-stride loops
+#pragma unroll
+                for (int l = 0; l < 9; ++l) my[(9 * t + l) * kCols] = acc.l[l];
+            }
         };
         Fe A[5], B[5], lo1, hi1;
         wide_half<0, 4, kChainDefault>(P.slot, b, rt, A, lo1, hi1);
@@ -53,7 +67,7 @@ __device__ __forceinline__ void prod_tree_wide_body(const ProdArgs &P, const Bin
     for (int t = 0; t <= M; ++t) {
         Fe a;
 #pragma unroll
-        for (int l = 0; l < 9; ++l) a.l[l] = my[(9 * t + l) * kWideBlock];
+        for (int l = 0; l < 9; ++l) a.l[l] = keeper ? my[(9 * t + l) * kCols] : 0;
         sv[t] = fe_to_fr(a);
     }
 #pragma unroll
@@ -92,22 +106,24 @@ __global__ __launch_bounds__(kWideBlock) void k_prod_tree_wide(const ProdArgs P,
 }
 // Seven multiplicands: 281 registers as the compiler schedules it freely -- one wavefront per SIMD -- although two blocks' running sums
 // (74 KB each) fit a CU's LDS.  Held to 256 registers (18 of them spilled) two blocks are resident: the 4 / 5 / 6 / 7 / 8 mix at nv = 20
-// 2.98 -> 2.88 ms on the same box (profiles/r6i_wide_occupancy_ab.txt).  Eight multiplicands stay as they are: their 83 KB of running sums
-// allow one block per CU whatever the registers, and the spills alone cost 4 % (4.52 -> 4.69 ms for five products of eight).
+// 2.98 -> 2.88 ms on the same box (profiles/r6i_wide_occupancy_ab.txt).  Eight multiplicands: 83 KB of running sums allow one block per CU
+// whatever the registers (held to 256 alone, the 60 spilled registers cost 4 %: 4.52 -> 4.69 ms for five products of eight); with the
+// sums of lane PAIRS (kPairSums: 41.5 KB a block) two blocks fit.
 template <int M>
 __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_prod_tree_wide_two_blocks(const ProdArgs P, const BindConst r, const uint64_t n_pairs,
                                                                                                                 uint4 *__restrict__ partials) {
-    prod_tree_wide_body<M>(P, r, n_pairs, partials);
+    prod_tree_wide_body<M, (M == 8)>(P, r, n_pairs, partials);
 }
 
 template <int M>
 static hipError_t launch_wide_t(const ProdArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
-    const size_t lds = (size_t)9 * (M + 1) * kWideBlock * 4;
     static bool attr_set[64] = {}; // (more dynamic LDS than the default limit of a launch: 55-83 KB of running sums); per device
-    if constexpr (M == 7) {
+    if constexpr (M >= 7) {
+        const size_t lds = (size_t)9 * (M + 1) * (M == 8 ? kWideBlock / 2 : kWideBlock) * 4;
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_prod_tree_wide_two_blocks<M>), (int)lds, attr_set); e != hipSuccess) return e;
         hipLaunchKernelGGL(k_prod_tree_wide_two_blocks<M>, dim3(grid), dim3(kWideBlock), lds, stream, args, rc, n_pairs, (uint4 *)d_partials);
     } else {
+        const size_t lds = (size_t)9 * (M + 1) * kWideBlock * 4;
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_prod_tree_wide<M>), (int)lds, attr_set); e != hipSuccess) return e;
         hipLaunchKernelGGL(k_prod_tree_wide<M>, dim3(grid), dim3(kWideBlock), lds, stream, args, rc, n_pairs, (uint4 *)d_partials);
     }
