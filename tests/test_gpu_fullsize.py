@@ -21,6 +21,10 @@ SEED = 0x5C20241008
 C3 = (24, [[0, 1, 2, 3], [4, 5, 6], [7, 8], [9]], 10)       # BASELINE config 3 (the metric's workload), 5 GiB of tables
 C3S = (24, [[2, 3, 0, 1], [1, 4, 4], [3, 2, 1], [0, 0]], 5)  # shared tables (shape of reference test.rs:224-252)
 C4SHARD = (25, [[0, 1, 2]], 3)                               # one GPU's share of BASELINE config 4 (nv=28 over 8 GPUs)
+# products of 8, 7 and 12 multiplicands (the reference's test range, ml_sumcheck/test.rs:125) at a size where one lane of the wide tree kernels
+# walks more than 16 / 32 pairs: the running sums' re-canonicalisation inside the grid-stride loop (kernels_wide.hip, kernels_wide16.hip) only runs there
+WIDE23 = (23, [[0, 1, 2, 3, 4, 5, 6, 7], [1, 2, 3, 4, 5, 6, 7], [0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3]], 8)  # (a product beyond eight: bind pass, canonical tables)
+WIDE23F = (23, [[0, 1, 2, 3, 4, 5, 6, 7], [7, 6, 5, 4, 3, 2, 1], [2, 2, 5, 5, 5]], 8)                          # (up to eight: binds fused in, F29 tables, repeats)
 
 
 def _device_poly(nv, shapes, nt, seed):
@@ -44,7 +48,8 @@ def _oracle_desc(nv, shapes, mles, coefs):
     return H.desc_from(nv, shapes, tabs, coefs)
 
 
-@pytest.mark.parametrize("nv,shapes,nt", [C3, C3S, C4SHARD], ids=["config3", "config3_shared", "config4_shard_nv25"])
+@pytest.mark.parametrize("nv,shapes,nt", [C3, C3S, C4SHARD, WIDE23, WIDE23F],
+                         ids=["config3", "config3_shared", "config4_shard_nv25", "wide_8_7_12_nv23", "wide_8_7_5_nv23"])
 def test_full_size_fiat_shamir_proof_bit_exact_vs_oracle(nv, shapes, nt):
     """the whole non-interactive proof (every round polynomial and every challenge) of the production path -- merged big-round
     kernel, F29 bound tables, pipelined late rounds -- equals the oracle's, at the size bench.py measures"""
