@@ -117,10 +117,12 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(2, 2
 
 template <int M>
 static hipError_t launch_wide_t(const ProdArgs &args, const BindConst &rc, uint64_t n_pairs, FrHost *d_partials, int grid, hipStream_t stream) {
-    static bool attr_set[64] = {}; // (more dynamic LDS than the default limit of a launch: 55-83 KB of running sums); per device
-    if constexpr (M >= 7) {
+    static bool attr_set[64] = {}, attr_set_two[64] = {}; // (more dynamic LDS than the default limit of a launch: 41-83 KB of running sums); per device and kernel
+    // (the pair sums assume that the two lanes of a pair leave the grid-stride loop together: an even number of pairs -- every big round has a
+    // power of two of at least 2^15; anything else takes the one-block kernel)
+    if (M >= 7 && (M == 7 || (n_pairs & 1) == 0)) {
         const size_t lds = (size_t)9 * (M + 1) * (M == 8 ? kWideBlock / 2 : kWideBlock) * 4;
-        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_prod_tree_wide_two_blocks<M>), (int)lds, attr_set); e != hipSuccess) return e;
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(k_prod_tree_wide_two_blocks<M>), (int)lds, attr_set_two); e != hipSuccess) return e;
         hipLaunchKernelGGL(k_prod_tree_wide_two_blocks<M>, dim3(grid), dim3(kWideBlock), lds, stream, args, rc, n_pairs, (uint4 *)d_partials);
     } else {
         const size_t lds = (size_t)9 * (M + 1) * kWideBlock * 4;

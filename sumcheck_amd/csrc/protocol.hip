@@ -373,6 +373,8 @@ int staged_copy_and_round1(sc_prover *p, const uint64_t *const *host_tables) {
         n_chunks = levels + 1;
         for (int c = 0; c < n_chunks; ++c) sec[c] = G >> (c < levels ? c + 1 : levels);
     }
+    for (uint32_t u = 0; u < p->U; ++u) // (before the first copy is enqueued: no return path leaves transfers from the caller's memory in flight)
+        if (!host_tables[u]) return sc_internal_fail(SC_ERR_BAD_ARG, "table %u is null", u);
     scd::BindConst rc;
     std::memset(&rc, 0, sizeof(rc));
     // (whatever the handle's stream still holds -- a previous proof's last kernels read the buffers the copy overwrites -- goes first)
@@ -385,7 +387,6 @@ int staged_copy_and_round1(sc_prover *p, const uint64_t *const *host_tables) {
         const uint64_t chunk = n >> sh, first = n - (n >> c); // entries per table in this chunk, entries before it
         const int gc = sec[c];                                // its section of the grid
         for (uint32_t u = 0; u < p->U; ++u) {
-            if (!host_tables[u]) return sc_internal_fail(SC_ERR_BAD_ARG, "table %u is null", u);
             HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(p->tabs[u].buf[0]) + (size_t)first * 32, reinterpret_cast<const char *>(host_tables[u]) + (size_t)first * 32,
                                    (size_t)chunk * 32, hipMemcpyHostToDevice, (u & 1) ? p->copy_stream2 : p->copy_stream));
         }
